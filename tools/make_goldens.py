@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE, imported from
+/root/reference in the build container (CPU, torch fp32).
+
+Only data (inputs' seeds / inputs / expected outputs) is written; no reference
+source travels.  Re-run:  python tools/make_goldens.py
+Harness-side shims (none of them edits the reference):
+  * torch.Tensor.cuda -> identity, because the reference hard-codes .cuda()
+    (nets/psmnet/psmnet_3.py:150-154, psmnet_submodule_3.py:83-85);
+  * empty stand-in modules for `cupy` / `pynvrtc` so that utils/reprojection.py
+    (which imports utils/warp_ops.py at module level) can be imported; the
+    NVRTC scatter warp itself is NOT run (it cannot be).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("AZ_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(1, REF)
+
+from tests._weights import load_procedural, seeded  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self  # shim 1
+for name in ("cupy", "cupy.cuda", "pynvrtc", "pynvrtc.compiler"):  # shim 2
+    sys.modules.setdefault(name, types.ModuleType(name))
+sys.modules["cupy.cuda"].function = types.SimpleNamespace(Module=object)
+sys.modules["pynvrtc.compiler"].Program = object
+
+from nets.psmnet import psmnet as ref_psmnet6  # noqa: E402
+from nets.psmnet import psmnet_3 as ref_psmnet3  # noqa: E402
+from nets.raft.corr import CorrBlock1D  # noqa: E402
+from utils import reprojection as ref_reproj  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  keys={list(out)}")
+
+
+class _Stop(Exception):
+    pass
+
+
+class _Fn(torch.nn.Module):
+    """wrap a callable so it can replace a registered child module"""
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, *a):
+        return self.fn(*a)
+
+
+# ---------------------------------------------------------------- G1 cost volume
+def g1_cost_volume():
+    b, c, h, w, nd = 2, 32, 8, 40, 12
+    feat_l = seeded((b, c, h, w), 101).requires_grad_()
+    feat_r = seeded((b, c, h, w), 102).requires_grad_()
+    cot = seeded((b, 2 * c, nd, h, w), 103)
+    model = ref_psmnet3.PSMNet(maxdisp=4 * nd)
+    feats = iter([feat_l, feat_r])
+    model.feature_extraction = _Fn(lambda _img: next(feats))
+    grabbed = {}
+
+    def grab(_m, args):
+        grabbed["cost"] = args[0]
+        raise _Stop
+
+    model.dres0.register_forward_pre_hook(grab)
+    try:
+        model(torch.zeros(1), torch.zeros(1))
+    except _Stop:
+        pass
+    cost = grabbed["cost"]
+    gl, gr = torch.autograd.grad(cost, (feat_l, feat_r), cot)
+    save("g1_cost_volume", seeds=[101, 102, 103], shape=[b, c, h, w, nd], cost=cost,
+         grad_l=gl, grad_r=gr)
+
+
+# ---------------------------------------------------------------- G2 soft-argmin head
+def g2_softargmin():
+    b, d, h, w = 2, 6, 5, 7
+    k1 = (4 * seeded((b, 1, d, h, w), 201)).requires_grad_()
+    d2 = (4 * seeded((b, 1, d, h, w), 202)).requires_grad_()
+    d3 = (4 * seeded((b, 1, d, h, w), 203)).requires_grad_()
+    cots = [seeded((b, 1, 4 * h, 4 * w), 204 + i) for i in range(3)]
+    stub = types.SimpleNamespace(
+        maxdisp=4 * d, training=True,
+        feature_extraction=lambda _x: torch.zeros(b, 32, h, w),
+        dres0=lambda c: c, dres1=lambda c: c,
+        dres2=lambda x, p, q: (x, None, None), dres3=lambda x, p, q: (x, None, None),
+        dres4=lambda x, p, q: (x, None, None),
+        classif1=lambda _x: k1, classif2=lambda _x: d2, classif3=lambda _x: d3)
+    p3, p2, p1 = ref_psmnet3.PSMNet.forward(stub, torch.zeros(1), torch.zeros(1))
+    c1 = k1.detach()
+    c2 = d2.detach() + c1
+    c3 = d3.detach() + c2
+    g1 = torch.autograd.grad(p1, k1, cots[0], retain_graph=True)[0]
+    g2 = torch.autograd.grad(p2, d2, cots[1], retain_graph=True)[0]
+    g3 = torch.autograd.grad(p3, d3, cots[2])[0]
+    stub.training = False
+    p3_eval = ref_psmnet3.PSMNet.forward(stub, torch.zeros(1), torch.zeros(1))
+    assert torch.equal(p3_eval, p3)
+    save("g2_softargmin", maxdisp=4 * d, cost1=c1, cost2=c2, cost3=c3, pred1=p1, pred2=p2,
+         pred3=p3, cot1=cots[0], cot2=cots[1], cot3=cots[2], grad1=g1, grad2=g2, grad3=g3)
+    # a full-size-in-D case (D=192 -> d=48) on a tiny image, forward only
+    b, d, h, w = 1, 48, 3, 4
+    k = (6 * seeded((b, 1, d, h, w), 211)).requires_grad_()
+    z = torch.zeros_like(k)
+    stub = types.SimpleNamespace(
+        maxdisp=192, training=False, feature_extraction=lambda _x: torch.zeros(b, 32, h, w),
+        dres0=lambda c: c, dres1=lambda c: c, dres2=lambda x, p, q: (x, None, None),
+        dres3=lambda x, p, q: (x, None, None), dres4=lambda x, p, q: (x, None, None),
+        classif1=lambda _x: z, classif2=lambda _x: z, classif3=lambda _x: k)
+    p = ref_psmnet3.PSMNet.forward(stub, torch.zeros(1), torch.zeros(1))
+    cot = seeded(tuple(p.shape), 212)
+    g = torch.autograd.grad(p, k, cot)[0]
+    save("g2_softargmin_d192", maxdisp=192, cost=k, pred=p, cot=cot, grad=g)
+
+
+# ---------------------------------------------------------------- G3 3-D blocks
+def g3_blocks():
+    x = seeded((1, 32, 8, 8, 12), 301)
+    pre = seeded((1, 64, 4, 4, 6), 302)
+    post = seeded((1, 64, 4, 4, 6), 303)
+    cot = seeded((1, 32, 8, 8, 12), 304)
+    out = {}
+    for mode in ("eval", "train"):
+        for skips in (False, True):
+            hg = load_procedural(ref_psmnet3.hourglass(32), "g3.hg.")
+            hg.train(mode == "train")
+            xi = x.clone().requires_grad_()
+            o, p, q = hg(xi, pre if skips else None, post if skips else None)
+            loss = (o * cot).sum() + p.sum() * 0.25 + q.sum() * 0.5
+            loss.backward()
+            tag = f"{mode}_{'skip' if skips else 'noskip'}"
+            out[f"{tag}_out"], out[f"{tag}_pre"], out[f"{tag}_post"] = o, p, q
+            out[f"{tag}_gx"] = xi.grad
+            out[f"{tag}_gw_conv1"] = hg.conv1[0][0].weight.grad[:8, :8]
+            out[f"{tag}_gw_conv5"] = hg.conv5[0].weight.grad[:8, :8]
+            out[f"{tag}_gw_conv6"] = hg.conv6[0].weight.grad[:8, :8]
+            out[f"{tag}_ggamma_conv2"] = hg.conv2[1].weight.grad
+            out[f"{tag}_gbeta_conv6"] = hg.conv6[1].bias.grad
+            if mode == "train":
+                out[f"{tag}_rm_conv1"] = hg.conv1[0][1].running_mean
+                out[f"{tag}_rv_conv1"] = hg.conv1[0][1].running_var
+    save("g3_hourglass", seeds=[301, 302, 303, 304], **out)
+
+    # single convbn_3d layers (the unit the HIP conv kernels are tested against)
+    out = {}
+    for cin, cout, stride in ((64, 32, 1), (32, 32, 1), (32, 64, 2), (64, 64, 2), (64, 64, 1)):
+        layer = load_procedural(ref_psmnet3.convbn_3d(cin, cout, 3, stride, 1),
+                                f"g3.cb{cin}_{cout}_{stride}.")
+        xin = seeded((2, cin, 4, 6, 8), 310 + cin + cout + stride).requires_grad_()
+        for mode in ("eval", "train"):
+            layer.train(mode == "train")
+            y = layer(xin)
+            ct = seeded(tuple(y.shape), 320)
+            gx, gw, gg, gb = torch.autograd.grad(
+                y, (xin, layer[0].weight, layer[1].weight, layer[1].bias), ct)
+            tag = f"cb{cin}_{cout}_{stride}_{mode}"
+            out[tag + "_y"], out[tag + "_gx"], out[tag + "_gw"] = y, gx, gw[:8, :8]
+            out[tag + "_gg"], out[tag + "_gb"] = gg, gb
+    save("g3_convbn3d", **out)
+
+
+# ---------------------------------------------------------------- G4 full PSMNet
+def g4_full():
+    h = w = 256
+    maxdisp = 32
+    nb = 2  # train-mode BatchNorm after the 64x64 SPP pooling needs > 1 value per channel
+    gt = 1.0 + 28.0 * torch.sigmoid(
+        F.interpolate(seeded((nb, 1, 8, 8), 404, -3, 3), size=(h, w), mode="bilinear",
+                      align_corners=False))
+    gt[:, :, :40, :30] = 0.0  # invalid region -> exercised by the mask
+    mask = (gt < maxdisp) * (gt > 0)
+    for variant, mod, nin in (("psmnet3", ref_psmnet3, 3), ("psmnet6", ref_psmnet6, 6)):
+        imgs = [seeded((nb, 3, h, w), 400 + i, -2.0, 2.0) for i in range(4)]
+        args = imgs[:2] if nin == 3 else imgs
+        model = load_procedural(mod.PSMNet(maxdisp=maxdisp), "g4.")
+        nkeys = len(model.state_dict())
+        model.eval()
+        with torch.no_grad():
+            pred_eval = model(*args)
+        model.train()
+        p3, p2, p1 = model(*args)
+        sl1 = lambda p: F.smooth_l1_loss(p[mask], gt[mask], reduction="mean")
+        loss = 0.5 * sl1(p1) + 0.7 * sl1(p2) + sl1(p3)  # utils/losses.py:7-15
+        loss.backward()
+        sd = dict(model.named_parameters())
+        grads = {
+            "g_dres0_0_0": sd["dres0.0.0.weight"].grad[:4, :4],
+            "g_classif3_2": sd["classif3.2.weight"].grad,
+            "g_dres4_conv5_0": sd["dres4.conv5.0.weight"].grad[:4, :4],
+            "g_dres2_conv1_0_1_w": sd["dres2.conv1.0.1.weight"].grad,
+            "g_fe_lastconv_2": sd["feature_extraction.lastconv.2.weight"].grad[:, :8, 0, 0],
+            "g_fe_firstconv_0_0": sd["feature_extraction.firstconv.0.0.weight"].grad[:4],
+        }
+        bufs = dict(model.named_buffers())
+        save(f"g4_{variant}", seeds=[400, 401, 402, 403, 404], maxdisp=maxdisp, nkeys=nkeys,
+             keys=np.array(sorted(model.state_dict().keys())), gt=gt, pred_stride=2,
+             pred_eval=pred_eval[..., ::2, ::2], pred3=p3[..., ::2, ::2],
+             pred2=p2[..., ::2, ::2], pred1=p1[..., ::2, ::2], loss=loss,
+             rm_dres0=bufs["dres0.0.1.running_mean"], rv_dres0=bufs["dres0.0.1.running_var"],
+             **grads)
+
+
+# ---------------------------------------------------------------- G6-G8 reprojection
+def g6_apply_disparity():
+    img = seeded((2, 3, 9, 17), 601)
+    disp = seeded((2, 1, 9, 17), 602, -6.0, 6.0)
+    disp[0, 0, 0, :4] = torch.tensor([30.0, -30.0, 16.5, -0.25])  # far out of range
+    disp.requires_grad_()
+    cot = seeded((2, 3, 9, 17), 603)
+    out = ref_reproj.apply_disparity(img, disp)
+    (g,) = torch.autograd.grad(out, disp, cot)
+    save("g6_apply_disparity", img=img, disp=disp, out=out, cot=cot, grad=g)
+
+
+def g7_patch():
+    b, h, w = 2, 12, 20
+    out = {}
+    pat_l = (seeded((b, 1, h, w), 701, 0, 1) < 0.3).float()
+    pat_r = (seeded((b, 1, h, w), 702, 0, 1) < 0.3).float()
+    con_l, con_r = seeded((b, 1, h, w), 703), seeded((b, 1, h, w), 704)
+    disp0 = seeded((b, 1, h, w), 705, 0.0, 6.0)
+    mask = seeded((b, 1, h, w), 706, 0, 1) < 0.7
+    out.update(pat_l=pat_l, pat_r=pat_r, con_l=con_l, con_r=con_r, disp=disp0, mask=mask)
+    for kind, (l, r) in (("pat", (pat_l, pat_r)), ("con", (con_l, con_r))):
+        for ps in (1, 3, 11):
+            for use_mask in (False, True):
+                d = disp0.clone().requires_grad_()
+                loss, vis, m = ref_reproj.get_reproj_error_patch(
+                    l, r, d, mask if use_mask else None, ps)
+                loss.backward()
+                tag = f"{kind}_ps{ps}_{'mask' if use_mask else 'nomask'}"
+                out[tag + "_loss"], out[tag + "_vis"], out[tag + "_m"] = loss, vis, m
+                out[tag + "_grad"] = d.grad
+    # two-channel input (API allows c > 1)
+    l2, r2 = seeded((1, 2, 8, 10), 707), seeded((1, 2, 8, 10), 708)
+    d2 = seeded((1, 1, 8, 10), 709, 0.0, 4.0).requires_grad_()
+    loss, vis, m = ref_reproj.get_reproj_error_patch(l2, r2, d2, None, 3)
+    loss.backward()
+    out.update(c2_l=l2, c2_r=r2, c2_disp=d2, c2_loss=loss, c2_vis=vis, c2_m=m, c2_grad=d2.grad)
+    save("g7_reproj_patch", **out)
+
+    # whole-image variants (API surface a10)
+    img_l, img_r = seeded((2, 3, 16, 24), 711), seeded((2, 3, 16, 24), 712)
+    d = seeded((2, 1, 16, 24), 713, 0.0, 5.0).requires_grad_()
+    mk = seeded((2, 1, 16, 24), 714, 0, 1) < 0.6
+    lo, wo, mo = ref_reproj.get_reprojection_error_old(img_l, img_r, d, mk)
+    (go,) = torch.autograd.grad(lo, d)
+    lo2, wo2, mo2 = ref_reproj.get_reprojection_error_old(img_l, img_r, d, None)
+    tot, stages, parts = ref_reproj.get_reprojection_error_diff_ratio(img_l, img_r, d, mk)
+    (gd,) = torch.autograd.grad(tot, d)
+    save("g7_reproj_image", img_l=img_l, img_r=img_r, disp=d, mask=mk, old_loss=lo,
+         old_warped=wo, old_mask=mo, old_grad=go, old_nomask_loss=lo2, old_nomask_mask=mo2,
+         dr_total=tot, dr_grad=gd, dr_parts=np.array([parts[f"stage{i}"] for i in range(3)]),
+         dr_warped0=stages["stage0"]["warped"], dr_warped2=stages["stage2"]["warped"],
+         dr_mask1=stages["stage1"]["mask"], dr_disp0=stages["stage0"]["pred_disp"])
+
+
+def g8_lcn():
+    img = seeded((2, 1, 12, 20), 801, 0.0, 1.0)
+    img3 = seeded((1, 3, 6, 9), 802, 0.0, 1.0)
+    out = dict(img=img, img3=img3)
+    for k in (3, 9):
+        n, s = ref_reproj.local_contrast_norm(img, k)
+        out[f"k{k}_normed"], out[f"k{k}_std"] = n, s
+    n, s = ref_reproj.local_contrast_norm(img3, 5)
+    out["c3_normed"], out["c3_std"] = n, s
+    save("g8_lcn", **out)
+
+
+# ---------------------------------------------------------------- G9 RAFT 1-D correlation
+def g9_corr():
+    f1 = seeded((1, 16, 6, 20), 901).requires_grad_()
+    f2 = seeded((1, 16, 6, 20), 902).requires_grad_()
+    coords = torch.stack(torch.meshgrid(torch.arange(6), torch.arange(20), indexing="ij")[::-1],
+                         0).float()[None]
+    coords = coords.clone()
+    coords[:, 0] -= seeded((1, 6, 20), 903, 0.0, 9.0)
+    blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+    out = blk(coords)
+    cot = seeded(tuple(out.shape), 904)
+    g1, g2 = torch.autograd.grad(out, (f1, f2), cot)
+    save("g9_corr1d", fmap1=f1, fmap2=f2, coords=coords, out=out, cot=cot, grad1=g1, grad2=g2,
+         **{f"pyr{i}": p for i, p in enumerate(blk.corr_pyramid[:4])})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
+    for fn in (g1_cost_volume, g2_softargmin, g3_blocks, g4_full, g6_apply_disparity, g7_patch,
+               g8_lcn, g9_corr):
+        if not only or fn.__name__.split("_")[0] in only:
+            fn()
