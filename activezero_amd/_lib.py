@@ -1,0 +1,64 @@
+"""ctypes loader of libazhip.so -- the only way the Python host code reaches the
+HIP kernels.  There is NO fallback: if the library is missing or a call fails,
+a RuntimeError is raised (the product path never routes through oracle/ or a
+CPU restatement)."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libazhip.so")
+HEADER = os.path.join(HERE, "..", "include", "azhip.h")
+
+_lib = None
+
+_C = ctypes
+_PTR, _INT, _SIZE = _C.c_void_p, _C.c_int, _C.c_size_t
+
+# name -> argtypes (return type is int unless listed in _RESTYPE)
+_SIGS = {
+    "az_abi_version": [],
+    "az_strerror": [_INT],
+    "az_warp_scatter": [_PTR, _PTR, _PTR, _INT, _INT, _INT, _INT, _INT, _PTR],
+    "az_cost_volume_fwd": [_PTR] * 3 + [_INT] * 5 + [_PTR],
+    "az_cost_volume_bwd": [_PTR] * 3 + [_INT] * 5 + [_PTR],
+    "az_cost_volume_fwd_ndhwc": [_PTR] * 3 + [_INT] * 5 + [_PTR],
+    "az_cost_volume_bwd_ndhwc": [_PTR] * 3 + [_INT] * 5 + [_PTR],
+    "az_softargmin_fwd": [_PTR] * 2 + [_INT] * 4 + [_PTR],
+    "az_softargmin_bwd": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_warp_gather_fwd": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_warp_gather_bwd": [_PTR] * 5 + [_INT] * 4 + [_PTR],
+    "az_patch_reproj_fwd": [_PTR] * 5 + [_INT] * 5 + [_C.c_float, _PTR],
+    "az_patch_reproj_bwd": [_PTR] * 7 + [_INT] * 5 + [_C.c_float, _PTR],
+    "az_patch_reproj_vis": [_PTR] * 3 + [_INT] * 5 + [_C.c_float, _PTR],
+    "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
+}
+_RESTYPE = {"az_strerror": _C.c_char_p}
+
+
+def declared_symbols():
+    """Every function name include/azhip.h declares."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(az_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m activezero_amd.build` "
+                "(there is no non-HIP fallback)")
+        handle = _C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, _INT)
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {lib().az_strerror(code).decode()} ({code})")

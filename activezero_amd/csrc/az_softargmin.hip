@@ -1,0 +1,240 @@
+// K6 -- fused soft-argmin head: trilinear x4 upsample + softmax over D +
+// disparity expectation, reference nets/psmnet/psmnet_3.py:184-215 and
+// nets/psmnet/psmnet_submodule_3.py:80-89.
+//
+// The reference materialises [B,D,H,W] three times per head (401 MB each at
+// 544x960, D=192).  Here a block owns a 4-row x 64-column tile of the output;
+// the (3 x 18 x d) low-resolution logits it touches are staged once in LDS and
+// every thread walks the D axis of its own pixel in registers:
+//   pass A  v_k = bilinear(y,x) of plane k, M = max_D u_D      (softmax shift)
+//   pass B  u_D = lerp_D(v_k, v_k+1);  s += exp(u_D - M);  t += D * exp(u_D - M)
+//   out = t / s
+// align_corners=False with an exact x4 scale gives the fixed phase weights
+// (dst = 4k+r): r0 -> (.375,.625) of (k-1,k), r1 -> (.125,.875), r2 -> (.875,.125)
+// of (k,k+1), r3 -> (.625,.375); border indices clamp (PyTorch
+// area_pixel_compute_source_index + min(i0+1, size-1)).
+// Algorithmic HBM bytes per head: 4*(d*h*w + H*W); the kernel is VALU/exp bound.
+//
+// Backward recomputes the softmax (nothing saved), forms
+//   d out / d u_D = p_D * (D - out)
+// folds the D-lerp back onto the 48 planes, pre-reduces the 4 pixels of an
+// x-quad with wave shuffles, accumulates the tile's (3 x 18 x d) gradient in LDS
+// (ds_add_f32) and flushes it with one global float atomic per LDS cell.
+#include "az_common.h"
+
+#define SA_TY 4
+#define SA_TX 64
+#define SA_LY 3   // low-res rows touched by 4 output rows
+#define SA_LX 18  // low-res cols touched by 64 output cols
+
+__device__ __forceinline__ void sa_load_tile(float *tile, const float *__restrict__ logits,
+                                             int b, int d, int h, int w, int ybase, int xbase) {
+    const int n = d * SA_LY * SA_LX;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int lx = e % SA_LX;
+        const int r = e / SA_LX;
+        const int ly = r % SA_LY, k = r / SA_LY;
+        const int gy = min(max(ybase + ly, 0), h - 1);
+        const int gx = min(max(xbase + lx, 0), w - 1);
+        tile[e] = logits[(((size_t)b * d + k) * h + gy) * w + gx];
+    }
+}
+
+struct SaPix {
+    int ly0, lx0;    // tile-local index of the lower cell; the upper one is +1
+    float wy1, wx1;  // weight of the upper cell (lower gets 1 - w)
+};
+
+// Source cell / weight of PyTorch's linear x4 upsampling (align_corners=False),
+// in UNCLAMPED form: dst = 4q+r reads cells (q-1,q) for r<2 and (q,q+1) for r>=2.
+// Border clamping is applied where the tile is loaded from / flushed to global
+// memory (cell -1 aliases cell 0, cell `size` aliases size-1), which is the same
+// linear map as PyTorch's clamped indices.
+__device__ __forceinline__ void sa_axis(int dst, int base, int &l0, float &lam1) {
+    const int q = dst >> 2, r = dst & 3;
+    l0 = ((r < 2) ? q - 1 : q) - base;
+    lam1 = (r < 2) ? (r == 0 ? 0.625f : 0.875f) : (r == 2 ? 0.125f : 0.375f);
+}
+
+__device__ __forceinline__ float sa_plane(const float *tile, int k, const SaPix &p) {
+    const float *t = tile + k * (SA_LY * SA_LX);
+    const float *c = t + p.ly0 * SA_LX + p.lx0;
+    const float a00 = c[0], a01 = c[1], a10 = c[SA_LX], a11 = c[SA_LX + 1];
+    const float wx0 = 1.f - p.wx1, wy0 = 1.f - p.wy1;
+    return wy0 * (wx0 * a00 + p.wx1 * a01) + p.wy1 * (wx0 * a10 + p.wx1 * a11);
+}
+
+// softmax statistics of one pixel: M (shift), s = sum exp, t = sum D*exp
+__device__ __forceinline__ void sa_stats(const float *tile, int d, const SaPix &p, float &M,
+                                         float &s, float &t) {
+    // exact maximum of the UPSAMPLED logits (what F.softmax subtracts): the plane
+    // values at both ends and, per plane pair, the two outer lerp phases.
+    float v0 = sa_plane(tile, 0, p);
+    M = v0;
+    for (int k = 0; k + 1 < d; ++k) {
+        const float v1 = sa_plane(tile, k + 1, p);
+        M = fmaxf(M, fmaxf((1.f - 0.125f) * v0 + 0.125f * v1, (1.f - 0.875f) * v0 + 0.875f * v1));
+        v0 = v1;
+    }
+    M = fmaxf(M, v0);
+    s = 0.f;
+    t = 0.f;
+    v0 = sa_plane(tile, 0, p);
+    {   // D = 0, 1 -> plane 0 (source index clamped to 0)
+        const float e = expf(v0 - M);
+        s += e + e;
+        t += e;  // 0*e + 1*e
+    }
+    for (int k = 0; k + 1 < d; ++k) {
+        const float v1 = sa_plane(tile, k + 1, p);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float w1 = 0.125f + 0.25f * m;
+            const float u = (1.f - w1) * v0 + w1 * v1;
+            const float e = expf(u - M);
+            s += e;
+            t += (float)(4 * k + 2 + m) * e;
+        }
+        v0 = v1;
+    }
+    {   // D = 4d-2, 4d-1 -> plane d-1 (upper index clamped)
+        const float e = expf(v0 - M);
+        s += e + e;
+        t += (float)(4 * d - 2) * e + (float)(4 * d - 1) * e;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+softargmin_fwd_kernel(float *__restrict__ out, const float *__restrict__ logits, int d, int h,
+                      int w, int tiles_x) {
+    extern __shared__ float tile[];
+    const int H = 4 * h, W = 4 * w;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int b = blockIdx.y;
+    const int ybase = ty * (SA_TY / 4) - 1, xbase = tx * (SA_TX / 4) - 1;
+    sa_load_tile(tile, logits, b, d, h, w, ybase, xbase);
+    __syncthreads();
+    const int Y = ty * SA_TY + (threadIdx.x >> 6), X = tx * SA_TX + (threadIdx.x & 63);
+    if (X >= W || Y >= H) return;
+    SaPix p;
+    sa_axis(Y, ybase, p.ly0, p.wy1);
+    sa_axis(X, xbase, p.lx0, p.wx1);
+    float M, s, t;
+    sa_stats(tile, d, p, M, s, t);
+    out[((size_t)b * H + Y) * W + X] = t / s;
+}
+
+__global__ void __launch_bounds__(256)
+softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gout,
+                      const float *__restrict__ logits, int d, int h, int w, int tiles_x) {
+    extern __shared__ float smem[];
+    float *tile = smem;
+    float *gtile = smem + d * SA_LY * SA_LX;
+    const int H = 4 * h, W = 4 * w;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int b = blockIdx.y;
+    const int ybase = ty * (SA_TY / 4) - 1, xbase = tx * (SA_TX / 4) - 1;
+    const int ncell = d * SA_LY * SA_LX;
+    sa_load_tile(tile, logits, b, d, h, w, ybase, xbase);
+    for (int e = threadIdx.x; e < ncell; e += blockDim.x) gtile[e] = 0.f;
+    __syncthreads();
+    const int Y = ty * SA_TY + (threadIdx.x >> 6), X = tx * SA_TX + (threadIdx.x & 63);
+    const bool live = (X < W) && (Y < H);
+    SaPix p;
+    sa_axis(Y, ybase, p.ly0, p.wy1);  // indices depend on the thread id only: always in-tile
+    sa_axis(X, xbase, p.lx0, p.wx1);
+    float M, s, t;
+    sa_stats(tile, d, p, M, s, t);
+    const float pred = t / s;
+    const float g = live ? gout[((size_t)b * H + Y) * W + X] / s : 0.f;  // g * (1/s)
+
+    // x-quad roles: the 4 pixels X = 4q..4q+3 touch cells q-1, q, q+1.
+    const int r = threadIdx.x & 3;
+    const int cq = (X >> 2) - xbase;  // tile-local column of cell q, in [1,16]
+    const float wx0 = 1.f - p.wx1;
+    const float f_m1 = (r < 2) ? wx0 : 0.f;   // share going to cell q-1
+    const float f_0 = (r < 2) ? p.wx1 : wx0;  // ... to cell q
+    const float f_p1 = (r < 2) ? 0.f : p.wx1; // ... to cell q+1
+
+    float v0 = sa_plane(tile, 0, p);
+    float acc0;  // gradient being collected for plane k
+    {
+        const float e = expf(v0 - M);
+        acc0 = g * e * ((0.f - pred) + (1.f - pred));
+    }
+    for (int k = 0; k < d; ++k) {
+        float acc1 = 0.f;
+        if (k + 1 < d) {
+            const float v1 = sa_plane(tile, k + 1, p);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float w1 = 0.125f + 0.25f * m;
+                const float u = (1.f - w1) * v0 + w1 * v1;
+                const float gu = g * expf(u - M) * ((float)(4 * k + 2 + m) - pred);
+                acc0 += (1.f - w1) * gu;
+                acc1 += w1 * gu;
+            }
+            v0 = v1;
+        } else {
+            const float e = expf(v0 - M);
+            acc0 += g * e * (((float)(4 * d - 2) - pred) + ((float)(4 * d - 1) - pred));
+        }
+        // plane k complete: quad-reduce the three x-cell shares, then 3 lanes add
+        float s_m1 = f_m1 * acc0, s_0 = f_0 * acc0, s_p1 = f_p1 * acc0;
+        s_m1 += __shfl_xor(s_m1, 1); s_m1 += __shfl_xor(s_m1, 2);
+        s_0 += __shfl_xor(s_0, 1);   s_0 += __shfl_xor(s_0, 2);
+        s_p1 += __shfl_xor(s_p1, 1); s_p1 += __shfl_xor(s_p1, 2);
+        // lanes 0,1,2 of the quad add the shares of cells q-1, q, q+1 (two rows each)
+        if (r < 3) {
+            const float val = (r == 0) ? s_m1 : (r == 1 ? s_0 : s_p1);
+            float *gt = gtile + k * (SA_LY * SA_LX) + p.ly0 * SA_LX + (cq - 1 + r);
+            atomicAdd(gt, (1.f - p.wy1) * val);
+            atomicAdd(gt + SA_LX, p.wy1 * val);
+        }
+        acc0 = acc1;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ncell; e += blockDim.x) {
+        const float v = gtile[e];
+        if (v == 0.f) continue;
+        const int lx = e % SA_LX;
+        const int rr = e / SA_LX;
+        const int ly = rr % SA_LY, k = rr / SA_LY;
+        const int gy = min(max(ybase + ly, 0), h - 1);
+        const int gx = min(max(xbase + lx, 0), w - 1);
+        atomicAdd(&glogits[(((size_t)b * d + k) * h + gy) * w + gx], v);
+    }
+}
+
+static int sa_check(int B, int d, int h, int w) {
+    if (!(B > 0 && d > 0 && h > 0 && w > 0)) return AZ_EINVAL;
+    if (B > 65535) return AZ_EUNSUPPORTED;
+    if ((size_t)2 * d * SA_LY * SA_LX * sizeof(float) > 64 * 1024) return AZ_EUNSUPPORTED;
+    return AZ_OK;
+}
+
+extern "C" int az_softargmin_fwd(float *disp_out, const float *logits, int B, int d, int h,
+                                 int w, void *stream) {
+    AZ_REQUIRE_PTR(disp_out); AZ_REQUIRE_PTR(logits);
+    if (int e = sa_check(B, d, h, w)) return e;
+    const int tiles_x = (4 * w + SA_TX - 1) / SA_TX, tiles_y = (4 * h) / SA_TY;
+    hipLaunchKernelGGL(softargmin_fwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256),
+                       (size_t)d * SA_LY * SA_LX * sizeof(float), az_stream(stream), disp_out,
+                       logits, d, h, w, tiles_x);
+    return az_launch_status();
+}
+
+extern "C" int az_softargmin_bwd(float *grad_logits, const float *grad_disp,
+                                 const float *logits, int B, int d, int h, int w,
+                                 void *stream) {
+    AZ_REQUIRE_PTR(grad_logits); AZ_REQUIRE_PTR(grad_disp); AZ_REQUIRE_PTR(logits);
+    if (int e = sa_check(B, d, h, w)) return e;
+    if (hipMemsetAsync(grad_logits, 0, (size_t)B * d * h * w * sizeof(float),
+                       az_stream(stream)) != hipSuccess)
+        return AZ_ELAUNCH;
+    const int tiles_x = (4 * w + SA_TX - 1) / SA_TX, tiles_y = (4 * h) / SA_TY;
+    hipLaunchKernelGGL(softargmin_bwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256),
+                       (size_t)2 * d * SA_LY * SA_LX * sizeof(float), az_stream(stream),
+                       grad_logits, grad_disp, logits, d, h, w, tiles_x);
+    return az_launch_status();
+}

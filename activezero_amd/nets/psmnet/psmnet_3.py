@@ -1,0 +1,123 @@
+"""PSMNet (stacked hourglass) with the MI355X-native hot path, 3-channel input.
+
+Drop-in for the reference module nets/psmnet/psmnet_3.py: same class names
+(`hourglass`, `PSMNet`), constructor arguments, forward signature / return
+convention (`(pred3, pred2, pred1)` in training, `pred3` in eval, each
+[B,1,H,W] fp32) and state-dict keys.  What changes is how forward() computes:
+
+  reference psmnet_3.py:149-163  zeros + 2*D/4 slice copies  -> ops.cost_volume (K3)
+  reference psmnet_3.py:165-179  cuDNN conv3d/BN stack       -> activezero_amd.agg3d (K4/K5)
+  reference psmnet_3.py:184-215  interpolate+softmax+regress -> ops.softargmin (K6, fused)
+
+The module is device-strict: inputs must be on the GPU (the reference
+hard-codes .cuda(); this path has no CPU fallback).
+"""
+import math
+
+from activezero_amd import agg3d, ops
+from activezero_amd.nets.psmnet.psmnet_submodule_3 import *  # noqa: F401,F403
+from activezero_amd.nets.psmnet import psmnet_submodule_3 as _sub
+
+
+def _relu_unit(cin, cout, stride):
+    return nn.Sequential(convbn_3d(cin, cout, kernel_size=3, stride=stride, pad=1),
+                         nn.ReLU(inplace=True))
+
+
+def _up_unit(cin, cout):
+    return nn.Sequential(
+        nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2,
+                           bias=False),
+        nn.BatchNorm3d(cout))
+
+
+class hourglass(nn.Module):
+    def __init__(self, inplanes):
+        super().__init__()
+        c2 = inplanes * 2
+        self.conv1 = _relu_unit(inplanes, c2, 2)
+        self.conv2 = convbn_3d(c2, c2, kernel_size=3, stride=1, pad=1)
+        self.conv3 = _relu_unit(c2, c2, 2)
+        self.conv4 = _relu_unit(c2, c2, 1)
+        self.conv5 = _up_unit(c2, c2)
+        self.conv6 = _up_unit(c2, inplanes)
+
+    def forward(self, x, presqu, postqu):
+        down = agg3d.conv_bn(x, self.conv1[0], relu=True)
+        pre = agg3d.conv_bn(down, self.conv2, relu=True, add=postqu)
+        deep = agg3d.conv_bn(pre, self.conv3[0], relu=True)
+        deep = agg3d.conv_bn(deep, self.conv4[0], relu=True)
+        post = agg3d.deconv_bn(deep, self.conv5, relu=True,
+                               add=pre if presqu is None else presqu)
+        out = agg3d.deconv_bn(post, self.conv6)
+        return out, pre, post
+
+
+def _classifier():
+    return nn.Sequential(convbn_3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True),
+                         nn.Conv3d(32, 1, kernel_size=3, padding=1, stride=1, bias=False))
+
+
+class PSMNet(nn.Module):
+    _feature_module = _sub
+
+    def __init__(self, maxdisp=192):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.feature_extraction = self._feature_module.FeatureExtraction()
+        self.dres0 = nn.Sequential(convbn_3d(64, 32, 3, 1, 1), nn.ReLU(inplace=True),
+                                   convbn_3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True))
+        self.dres1 = nn.Sequential(convbn_3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True),
+                                   convbn_3d(32, 32, 3, 1, 1))
+        self.dres2 = hourglass(32)
+        self.dres3 = hourglass(32)
+        self.dres4 = hourglass(32)
+        self.classif1 = _classifier()
+        self.classif2 = _classifier()
+        self.classif3 = _classifier()
+        self._reference_init()
+
+    def _reference_init(self):
+        # reference psmnet_3.py:123-142
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv3d)):
+                fan = m.out_channels * math.prod(m.kernel_size)
+                m.weight.data.normal_(0, math.sqrt(2.0 / fan))
+            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+            elif isinstance(m, nn.Linear):
+                m.bias.data.zero_()
+
+    # -- hot path ------------------------------------------------------------
+    def _aggregate(self, vol):
+        c0 = agg3d.conv_bn(vol, self.dres0[0], relu=True)
+        c0 = agg3d.conv_bn(c0, self.dres0[2], relu=True)
+        t = agg3d.conv_bn(c0, self.dres1[0], relu=True)
+        c0 = agg3d.conv_bn(t, self.dres1[2], add=c0)
+
+        out1, pre1, post1 = self.dres2(c0, None, None)
+        out1 = agg3d.add(out1, c0)
+        out2, _pre2, post2 = self.dres3(out1, pre1, post1)
+        out2 = agg3d.add(out2, c0)
+        out3, _pre3, _post3 = self.dres4(out2, pre1, post2)
+        out3 = agg3d.add(out3, c0)
+
+        def head(cls, v):
+            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True), cls[2])
+
+        cost1 = head(self.classif1, out1)
+        cost2 = head(self.classif2, out2) + cost1
+        cost3 = head(self.classif3, out3) + cost2
+        return cost1, cost2, cost3
+
+    def _from_features(self, feat_l, feat_r):
+        vol = agg3d.volume_from_features(feat_l, feat_r, self.maxdisp // 4)
+        cost1, cost2, cost3 = self._aggregate(vol)
+        pred3 = ops.softargmin(cost3)
+        if self.training:
+            return pred3, ops.softargmin(cost2), ops.softargmin(cost1)
+        return pred3
+
+    def forward(self, img_L, img_R):
+        return self._from_features(self.feature_extraction(img_L), self.feature_extraction(img_R))

@@ -1,0 +1,120 @@
+"""2-D feature extractor + building blocks of PSMNet (3-channel input).
+
+Mirrors the public names of the reference module
+nets/psmnet/psmnet_submodule_3.py (convbn, conv, convbn_3d, BasicBlock,
+DisparityRegression, FeatureExtraction) and its parameter/buffer names, so
+reference checkpoints load unchanged.  The 2-D ResNet+SPP extractor is the
+"adjacent" stage of SURVEY.md 8f: ordinary PyTorch-ROCm (MIOpen) modules.
+The 3-D blocks built from convbn_3d are executed by activezero_amd.agg3d.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from activezero_amd import ops
+
+__all__ = ["convbn", "conv", "convbn_3d", "BasicBlock", "DisparityRegression",
+           "FeatureExtraction", "torch", "nn", "F"]
+
+
+def _conv2d(cin, cout, k, stride, pad, dilation):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, dilation=dilation,
+                     padding=dilation if dilation > 1 else pad, bias=False)
+
+
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
+    return nn.Sequential(_conv2d(in_planes, out_planes, kernel_size, stride, pad, dilation),
+                         nn.BatchNorm2d(out_planes))
+
+
+def conv(in_planes, out_planes, kernel_size, stride, pad, dilation):
+    return nn.Sequential(_conv2d(in_planes, out_planes, kernel_size, stride, pad, dilation))
+
+
+def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
+    """Parameter container (Conv3d weight + BatchNorm3d affine/running stats) for one
+    3-D conv+BN unit; reference psmnet_submodule_3.py:44-56."""
+    return nn.Sequential(
+        nn.Conv3d(in_planes, out_planes, kernel_size=kernel_size, stride=stride, padding=pad,
+                  bias=False),
+        nn.BatchNorm3d(out_planes))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride, downsample, pad, dilation):
+        super().__init__()
+        self.conv1 = nn.Sequential(convbn(inplanes, planes, 3, stride, pad, dilation),
+                                   nn.ReLU(inplace=True))
+        self.conv2 = convbn(planes, planes, 3, 1, pad, dilation)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        return self.conv2(self.conv1(x)) + shortcut
+
+
+class DisparityRegression(nn.Module):
+    """sum_d d * p[b,d,y,x] (reference psmnet_submodule_3.py:80-89).  Kept for API
+    parity; PSMNet.forward uses the fused soft-argmin kernel instead of
+    softmax + this module."""
+
+    def __init__(self, maxdisp):
+        super().__init__()
+        self.maxdisp = maxdisp
+
+    def forward(self, x):
+        ramp = torch.arange(self.maxdisp, dtype=x.dtype, device=x.device).view(1, -1, 1, 1)
+        return torch.sum(x * ramp, 1, keepdim=True)
+
+
+_SPP_WINDOWS = ((1, 64), (2, 32), (3, 16), (4, 8))
+
+
+class FeatureExtraction(nn.Module):
+    IN_CHANNELS = 3
+
+    def __init__(self):
+        super().__init__()
+        act = lambda: nn.ReLU(inplace=True)
+        self.inplanes = 32
+        self.firstconv = nn.Sequential(
+            convbn(self.IN_CHANNELS, 32, 3, 2, 1, 1), act(),
+            convbn(32, 32, 3, 1, 1, 1), act(),
+            convbn(32, 32, 3, 1, 1, 1), act())
+        self.layer1 = self._make_layer(BasicBlock, 32, 3, 1, 1, 1)
+        self.layer2 = self._make_layer(BasicBlock, 64, 16, 2, 1, 1)
+        self.layer3 = self._make_layer(BasicBlock, 128, 3, 1, 1, 1)
+        self.layer4 = self._make_layer(BasicBlock, 128, 3, 1, 1, 2)
+        for idx, win in _SPP_WINDOWS:
+            setattr(self, f"branch{idx}", nn.Sequential(
+                nn.AvgPool2d((win, win), stride=(win, win)), convbn(128, 32, 1, 1, 0, 1), act()))
+        self.lastconv = nn.Sequential(
+            convbn(320, 128, 3, 1, 1, 1), act(),
+            nn.Conv2d(128, 32, kernel_size=1, padding=0, stride=1, bias=False))
+
+    def _make_layer(self, block, planes, blocks, stride, pad, dilation):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride,
+                          bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample, pad, dilation)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def _trunk(self, x):
+        raw = self.layer2(self.layer1(self.firstconv(x)))
+        skip = self.layer4(self.layer3(raw))
+        size = skip.shape[-2:]
+        pyramid = [F.interpolate(getattr(self, f"branch{i}")(skip), size, mode="bilinear",
+                                 align_corners=True) for i in (4, 3, 2, 1)]
+        return self.lastconv(torch.cat([raw, skip] + pyramid, 1))
+
+    def forward(self, x):
+        """[B,3,H,W] -> [B,32,H/4,W/4]"""
+        return self._trunk(x)

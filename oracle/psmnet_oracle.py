@@ -36,7 +36,7 @@ def build_cost_volume(feat_l, feat_r, ndisp):
     vol = feat_l.new_zeros(b, 2 * c, ndisp, h, w)
     for i in range(ndisp):
         vol[:, :c, i, :, i:] = feat_l[:, :, :, i:]
-        vol[:, c:, i, :, i:] = feat_r[:, :, :, : w - i]
+        vol[:, c:, i, :, i:] = feat_r[:, :, :, : max(w - i, 0)]
     return vol
 
 

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from oracle import psmnet_oracle as po
 from oracle import reprojection_oracle as ro
 from oracle import warp_oracle as wo
-from tests._weights import load_procedural, seeded
+from tests._weights import load_bn_buffers, load_procedural, seeded
 
 T = torch.from_numpy
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -74,7 +74,7 @@ def test_g3_hourglass(golden, mode, skips):
 def test_g4_full_psmnet(golden, variant, nin):
     g = golden("g4_" + variant)
     md = int(g["maxdisp"])
-    model = load_procedural(po.PSMNetOracle(md, in_ch=nin), "g4.")
+    model = load_bn_buffers(load_procedural(po.PSMNetOracle(md, in_ch=nin), "g4."), g)
     assert sorted(model.state_dict().keys()) == list(g["keys"])  # 514 reference keys
     assert len(model.state_dict()) == int(g["nkeys"])
     imgs = [seeded((2, 3, 256, 256), 400 + i, -2.0, 2.0) for i in range(4)]
