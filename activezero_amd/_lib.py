@@ -13,7 +13,7 @@ HEADER = os.path.join(HERE, "..", "include", "azhip.h")
 _lib = None
 
 _C = ctypes
-_PTR, _INT, _SIZE = _C.c_void_p, _C.c_int, _C.c_size_t
+_PTR, _INT, _SIZE, _LL = _C.c_void_p, _C.c_int, _C.c_size_t, _C.c_longlong
 
 # name -> argtypes (return type is int unless listed in _RESTYPE)
 _SIGS = {
@@ -32,8 +32,24 @@ _SIGS = {
     "az_patch_reproj_bwd": [_PTR] * 7 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_patch_reproj_vis": [_PTR] * 3 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
+    "az_conv3d_pack_weights": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _PTR],
+    "az_conv3d_num_tiles": [_INT] * 5,
+    "az_conv3d_fwd": [_PTR] * 7 + [_INT] * 9 + [_PTR],
+    "az_conv3d_fwd_stats": [_PTR] * 6 + [_INT] * 8 + [_PTR],
+    "az_conv3d_wgrad_workspace": [_INT, _INT],
+    "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 10 + [_PTR],
+    "az_conv3d_c1_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
+    "az_conv3d_c1_dgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_conv3d_c1_wgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_bn3d_finalize": [_PTR] * 10 + [_LL, _INT, _C.c_float, _C.c_float, _PTR],
+    "az_bn3d_eval_affine": [_PTR] * 6 + [_C.c_float, _INT, _PTR],
+    "az_bn3d_apply": [_PTR] * 5 + [_INT, _LL, _INT, _PTR],
+    "az_bn3d_bwd_workspace": [_LL, _INT],
+    "az_bn3d_bwd": [_PTR] * 6 + [_LL] + [_PTR] * 6 + [_INT, _LL, _INT, _PTR],
+    "az_add_relu": [_PTR] * 3 + [_INT, _LL, _PTR],
 }
-_RESTYPE = {"az_strerror": _C.c_char_p}
+_RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL,
+            "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL}
 
 
 def declared_symbols():

@@ -1,66 +1,109 @@
 """3-D cost aggregation executor.
 
 PSMNet's hourglass / dres / classif blocks (reference nets/psmnet/psmnet_3.py:11-77,
-87-117, 165-179) are expressed on top of four primitives working on an opaque
+87-117, 165-179) are expressed on top of five primitives working on an opaque
 "volume" handle:
 
-    volume_from_features(feat_l, feat_r, ndisp)        K3
-    conv_bn(vol, unit, relu, add)                      K4 (+BN, +ReLU, +residual)
-    deconv_bn(vol, unit, relu, add)                    K5
-    conv_logits(vol, conv)                             K4 (32 -> 1 classifier)
+    volume_from_features(feat_l, feat_r, ndisp)   K3  concat cost volume
+    conv_bn(vol, unit, relu, add)                 K4  Conv3d + BatchNorm3d (+residual, +ReLU)
+    deconv_bn(vol, unit, relu, add)               K5  ConvTranspose3d + BatchNorm3d (...)
+    conv_logits(vol, conv, add)                   K4  32 -> 1 classifier (+ running cost sum)
+    add(a, b)                                     plain residual sum
 
-`unit` is the nn.Sequential(Conv3d|ConvTranspose3d, BatchNorm3d) parameter
-container whose names match the reference state-dict.
+`unit` is the nn.Sequential(Conv3d|ConvTranspose3d, BatchNorm3d) parameter container
+whose names match the reference state-dict; the modules' own forward() is never
+called.
 
-BACKEND STATUS (round 1): the cost volume (K3) and the soft-argmin head (K6)
-run on the hand-written HIP kernels; conv/deconv/BN of K4/K5 are dispatched to
-`hip` (activezero_amd.conv3d, hand-written MFMA kernels) when that backend is
-enabled and to PyTorch-ROCm's MIOpen operators otherwise.  MIOpen here is the
-"PyTorch-eager" baseline of BASELINE.md, not a CPU fallback; DESIGN.md tracks
-which layers are native.
+Backends (env AZ_AGG3D):
+  hip     (default) hand-written gfx950 kernels, volumes are channels-last [B,D,H,W,C]
+  miopen  PyTorch-ROCm / MIOpen operators on NCDHW tensors: the "PyTorch-eager"
+          baseline of BASELINE.md kept for A/B measurements (bench.py --backend miopen).
+          It is a GPU library path, not a CPU fallback.
+Both return logits as [B, d, h, w].
 """
 import os
 
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import conv3d, ops, profiler
 
-BACKEND = os.environ.get("AZ_AGG3D", "miopen")
+BACKEND = os.environ.get("AZ_AGG3D", "hip")
+
+
+def set_backend(name):
+    global BACKEND
+    if name not in ("hip", "miopen"):
+        raise ValueError(name)
+    BACKEND = name
+
+
+# ------------------------------------------------------------------ hip backend
+def _mode_of(conv):
+    if isinstance(conv, torch.nn.ConvTranspose3d):
+        return conv3d.DECONV_S2
+    return conv3d.CONV_S1 if conv.stride[0] == 1 else conv3d.CONV_S2
 
 
 def volume_from_features(feat_l, feat_r, ndisp):
-    return ops.cost_volume(feat_l, feat_r, ndisp)
-
-
-def _bn(x, bn, training):
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                        training or not bn.track_running_stats, bn.momentum, bn.eps)
+    if BACKEND == "miopen":
+        return ops.cost_volume(feat_l, feat_r, ndisp)
+    # features arrive NCHW from the 2-D extractor; the 3-D kernels want channels-last
+    fl = feat_l.permute(0, 2, 3, 1).contiguous()
+    fr = feat_r.permute(0, 2, 3, 1).contiguous()
+    return ops.cost_volume_ndhwc(fl, fr, ndisp)
 
 
 def conv_bn(vol, unit, relu=False, add=None):
-    cv, bn = unit[0], unit[1]
-    y = F.conv3d(vol, cv.weight, None, cv.stride, cv.padding)
-    y = _bn(y, bn, bn.training)
-    if add is not None:
-        y = y + add
-    return F.relu(y) if relu else y
+    if BACKEND == "miopen":
+        return _miopen_conv_bn(vol, unit, relu, add)
+    return conv3d.conv_bn(vol, unit[0], unit[1], _mode_of(unit[0]), relu, add)
 
 
 def deconv_bn(vol, unit, relu=False, add=None):
-    dc, bn = unit[0], unit[1]
-    y = F.conv_transpose3d(vol, dc.weight, None, dc.stride, dc.padding, dc.output_padding)
-    y = _bn(y, bn, bn.training)
+    if BACKEND == "miopen":
+        return _miopen_deconv_bn(vol, unit, relu, add)
+    return conv3d.conv_bn(vol, unit[0], unit[1], conv3d.DECONV_S2, relu, add)
+
+
+def conv_logits(vol, conv, add=None):
+    if BACKEND == "miopen":
+        y = F.conv3d(vol, conv.weight, None, conv.stride, conv.padding)[:, 0]
+        return y if add is None else y + add
+    return conv3d.conv_logits(vol, conv, add)
+
+
+def add(a, b):
+    if BACKEND == "miopen":
+        return a + b
+    return conv3d.add(a, b)
+
+
+# ------------------------------------------------------------------ miopen backend
+def _bn(x, bn):
+    training = bn.training or not bn.track_running_stats
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training,
+                        bn.momentum, bn.eps)
+
+
+def _miopen_conv_bn(vol, unit, relu, add):
+    cv, bn = unit[0], unit[1]
+    with profiler.scope(f"miopen_conv3d_fwd_{cv.in_channels}_{cv.out_channels}_s{cv.stride[0]}",
+                        flops=2.0 * 27 * cv.in_channels * cv.out_channels * vol.shape[0]
+                        * (vol[0, 0].numel() // cv.stride[0] ** 3)):
+        y = F.conv3d(vol, cv.weight, None, cv.stride, cv.padding)
+    y = _bn(y, bn)
     if add is not None:
         y = y + add
     return F.relu(y) if relu else y
 
 
-def conv_logits(vol, conv):
-    return F.conv3d(vol, conv.weight, None, conv.stride, conv.padding)
-
-
-def add(a, b):
-    return a + b
+def _miopen_deconv_bn(vol, unit, relu, add):
+    dc, bn = unit[0], unit[1]
+    y = F.conv_transpose3d(vol, dc.weight, None, dc.stride, dc.padding, dc.output_padding)
+    y = _bn(y, bn)
+    if add is not None:
+        y = y + add
+    return F.relu(y) if relu else y

@@ -1,0 +1,241 @@
+"""Autograd wrappers of the MFMA 3-D convolution family (include/azhip.h K4/K5).
+
+Volumes are channels-last tensors [B, D, H, W, C] (C in {32, 64}); weights stay in
+PyTorch's native layouts ([Cout,Cin,3,3,3] for Conv3d, [Cin,Cout,3,3,3] for
+ConvTranspose3d) so the reference state-dict loads unchanged -- the kernels read a
+packed copy made per call by az_conv3d_pack_weights (110-442 KB, L2 resident).
+
+Every layer's three passes map onto the same gather kernel (mode 0/1/2 = stride-1
+conv, stride-2 conv, stride-2 transposed conv) with differently packed weights:
+
+    layer                 forward      input gradient            weight gradient
+    Conv3d stride 1       mode 0       mode 0, flipped+swapped   wgrad(dy, x, 1)
+    Conv3d stride 2       mode 1       mode 2, swapped           wgrad(dy, x, 2)
+    ConvTranspose3d s2    mode 2       mode 1, as stored         wgrad(x, dy, 2)
+"""
+import torch
+
+from . import _lib, profiler
+from .ops import _call, _chk, _p, _stream
+
+CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
+
+
+def _dims(x):
+    b, d, h, w, c = x.shape
+    return b, d, h, w, c
+
+
+def _out_dims(mode, d, h, w):
+    if mode == CONV_S1:
+        return d, h, w
+    if mode == CONV_S2:
+        return (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    return 2 * d, 2 * h, 2 * w
+
+
+def _pack(weight, op_cin, op_cout, stride_out, stride_in, flip):
+    w = _chk(weight.detach().contiguous(), "weight")
+    packed = torch.empty(27 * op_cin * op_cout, dtype=torch.float32, device=w.device)
+    _call("az_conv3d_pack_weights", _p(packed), _p(w), op_cin, op_cout, stride_out, stride_in,
+          int(flip), _stream())
+    return packed
+
+
+def _pack_forward(weight, mode):
+    if mode == DECONV_S2:  # [Cin, Cout, 27]
+        cin, cout = weight.shape[0], weight.shape[1]
+        return _pack(weight, cin, cout, 27, cout * 27, False), cin, cout
+    cout, cin = weight.shape[0], weight.shape[1]
+    return _pack(weight, cin, cout, cin * 27, 27, False), cin, cout
+
+
+def _conv_flops(b, vox_out, cin, cout, mode):
+    taps = 27.0 / 8.0 if mode == DECONV_S2 else 27.0
+    return 2.0 * taps * cin * cout * b * vox_out
+
+
+def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=None, relu=False,
+                stats=False, tag="conv3d"):
+    b, d, h, w, c = _dims(x)
+    assert c == cin, (c, cin)
+    if mode == CONV_S2 and (d % 2 or h % 2 or w % 2):
+        raise RuntimeError("stride-2 layers need even D/H/W (as PSMNet's hourglass does)")
+    do, ho, wo = _out_dims(mode, d, h, w)
+    out = x.new_empty(b, do, ho, wo, cout)
+    flops = _conv_flops(b, do * ho * wo, cin, cout, mode)
+    name = f"{tag}_m{mode}_{cin}_{cout}"
+    if stats:
+        ntiles = _lib.lib().az_conv3d_num_tiles(mode, b, d, h, w)
+        part = x.new_empty(ntiles, cout, 2)
+        cnt = x.new_empty(ntiles)
+        with profiler.scope(name, flops=flops):
+            _call("az_conv3d_fwd_stats", _p(out), _p(part), _p(cnt), _p(x), None, _p(packed), mode, 0,
+                  b, cin, cout, d, h, w, _stream())
+        return out, part, cnt, ntiles
+    with profiler.scope(name, flops=flops):
+        _call("az_conv3d_fwd", _p(out), _p(x), None, _p(packed), _p(scale), _p(shift), _p(residual),
+              int(relu), mode, 0, b, cin, cout, d, h, w, _stream())
+    return out
+
+
+def _wgrad(coarse, fine, stride, cm, cn, tag):
+    b, dc, hc, wc, _ = _dims(coarse)
+    _, df, hf, wf, _ = _dims(fine)
+    gw = coarse.new_empty(cm, cn, 3, 3, 3)
+    ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
+    ws = coarse.new_empty(ws_bytes // 4)
+    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc):
+        _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, b, cm, cn,
+              dc, hc, wc, df, hf, wf, _stream())
+    return gw
+
+
+class _ConvBN(torch.autograd.Function):
+    """y = relu?( BN(conv(x, weight)) + residual ), one autograd node per convbn_3d unit."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, want_grad):
+        x = _chk(x, "x")
+        if residual is not None:
+            residual = _chk(residual, "residual")
+        training = bn.training or not bn.track_running_stats
+        eps = float(bn.eps)
+        with torch.cuda.device(x.device):
+            packed, cin, cout = _pack_forward(weight, mode)
+            scale, shift = x.new_empty(cout), x.new_empty(cout)
+            if not training:
+                _call("az_bn3d_eval_affine", _p(scale), _p(shift), _p(gamma.detach()), _p(beta.detach()),
+                      _p(bn.running_mean), _p(bn.running_var), eps, cout, _stream())
+                if want_grad and any(ctx.needs_input_grad):
+                    raise NotImplementedError(
+                        "eval-mode BatchNorm backward is not implemented on the HIP path; "
+                        "run validation under torch.no_grad() as the reference does")
+                return _run_gather(x, packed, mode, cin, cout, scale, shift, residual, relu)
+            raw, part, cnt, ntiles = _run_gather(x, packed, mode, cin, cout, stats=True)
+            mean, invstd = x.new_empty(cout), x.new_empty(cout)
+            track = bn.track_running_stats and bn.running_mean is not None
+            momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+            _call("az_bn3d_finalize", _p(mean), _p(invstd), _p(scale), _p(shift),
+                  _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
+                  _p(part), _p(cnt), _p(gamma.detach()), _p(beta.detach()), ntiles, cout, eps,
+                  momentum, _stream())
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+            y = torch.empty_like(raw)
+            nvox = raw.numel() // cout
+            with profiler.scope(f"bn3d_apply_{cout}", bytes=4.0 * raw.numel() * (3 if residual is not None else 2),
+                                bound="hbm"):
+                _call("az_bn3d_apply", _p(y), _p(raw), _p(scale), _p(shift), _p(residual), int(relu),
+                      nvox, cout, _stream())
+        ctx.save_for_backward(x, weight, gamma, raw, y if relu else None, mean, invstd)
+        ctx.cfg = (mode, relu, residual is not None, cin, cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, gamma, raw, y, mean, invstd = ctx.saved_tensors
+        mode, relu, has_res, cin, cout = ctx.cfg
+        gy = _chk(gy.contiguous(), "grad_y")
+        nvox = raw.numel() // cout
+        with torch.cuda.device(gy.device):
+            lib = _lib.lib()
+            dx_raw = torch.empty_like(raw)
+            dz = torch.empty_like(raw) if (has_res and relu) else None
+            dgamma, dbeta = gy.new_empty(cout), gy.new_empty(cout)
+            coef = gy.new_empty(cout, 3)
+            ws_bytes = lib.az_bn3d_bwd_workspace(nvox, cout)
+            ws = gy.new_empty(ws_bytes // 4)
+            with profiler.scope(f"bn3d_bwd_{cout}", bytes=4.0 * raw.numel() * (7 if relu else 5), bound="hbm"):
+                _call("az_bn3d_bwd", _p(dx_raw), _p(dz), _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes,
+                      _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), int(relu), nvox,
+                      cout, _stream())
+            g_res = (dz if relu else gy) if has_res else None
+            gx = gw = None
+            if ctx.needs_input_grad[0]:
+                if mode == CONV_S1:    # flipped taps, channels swapped
+                    pk = _pack(weight, cout, cin, 27, cin * 27, True)
+                    gx = _run_gather(dx_raw, pk, CONV_S1, cout, cin, tag="dgrad")
+                elif mode == CONV_S2:  # transposed conv of dy with W[co][ci][k]
+                    pk = _pack(weight, cout, cin, 27, cin * 27, False)
+                    gx = _run_gather(dx_raw, pk, DECONV_S2, cout, cin, tag="dgrad")
+                else:                  # stride-2 conv of dy with Wt[ci][co][k]
+                    pk = _pack(weight, cout, cin, cout * 27, 27, False)
+                    gx = _run_gather(dx_raw, pk, CONV_S2, cout, cin, tag="dgrad")
+            if ctx.needs_input_grad[1]:
+                if mode == DECONV_S2:
+                    gw = _wgrad(x, dx_raw, 2, cin, cout, "deconv")
+                else:
+                    gw = _wgrad(dx_raw, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv")
+        return gx, gw, dgamma, dbeta, g_res, None, None, None, None
+
+
+def conv_bn(x, conv, bn, mode, relu=False, residual=None):
+    return _ConvBN.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, mode, relu,
+                         torch.is_grad_enabled())
+
+
+class _ConvLogits(torch.autograd.Function):
+    """logits = Conv3d(32 -> 1)(x) + addend  (classifN[2] and the running cost sums)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, addend):
+        x = _chk(x, "x")
+        w = _chk(weight.detach().contiguous(), "weight")
+        b, d, h, wd, c = _dims(x)
+        if c != 32 or tuple(w.shape) != (1, 32, 3, 3, 3):
+            raise RuntimeError("classifier conv expects 32 -> 1 channels, 3x3x3")
+        if addend is not None:
+            addend = _chk(addend.contiguous(), "addend")
+        out = x.new_empty(b, d, h, wd)
+        with torch.cuda.device(x.device):
+            with profiler.scope("conv3d_c1_fwd", bytes=4.0 * (x.numel() + out.numel()), bound="hbm"):
+                _call("az_conv3d_c1_fwd", _p(out), _p(x), _p(w), _p(addend), b, d, h, wd, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_add = addend is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _chk(g.contiguous(), "grad_logits")
+        b, d, h, wd, _ = _dims(x)
+        gx = gw = None
+        with torch.cuda.device(g.device):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                with profiler.scope("conv3d_c1_dgrad", bytes=4.0 * (x.numel() + g.numel()), bound="hbm"):
+                    _call("az_conv3d_c1_dgrad", _p(gx), _p(g), _p(w), b, d, h, wd, _stream())
+            if ctx.needs_input_grad[1]:
+                gw = torch.empty_like(w)
+                with profiler.scope("conv3d_c1_wgrad", bytes=4.0 * (x.numel() + g.numel()), bound="hbm"):
+                    _call("az_conv3d_c1_wgrad", _p(gw), _p(x), _p(g), b, d, h, wd, _stream())
+        return gx, gw, (g if ctx.has_add else None)
+
+
+def conv_logits(x, conv, addend=None):
+    return _ConvLogits.apply(x, conv.weight, addend)
+
+
+class _AddRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "a"), _chk(b, "b")
+        y = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            _call("az_add_relu", _p(y), _p(a), _p(b), 0, a.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _AddRelu.apply(a, b)
+
+
+def conv_plain(x, weight, mode):
+    """Bare convolution (no BN), forward only -- used by parity tests and tools."""
+    packed, cin, cout = _pack_forward(weight, mode)
+    return _run_gather(_chk(x, "x"), packed, mode, cin, cout)

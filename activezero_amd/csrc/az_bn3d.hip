@@ -1,0 +1,326 @@
+// BatchNorm3d around the MFMA convolutions (reference
+// nets/psmnet/psmnet_submodule_3.py:44-56: Conv3d -> BatchNorm3d, train-mode batch
+// statistics per GPU, no SyncBN; psmnet_3.py adds ReLU / residual sums after it).
+//
+// Train forward:  conv epilogue writes raw x and per-tile (count, sum, centred M2)
+//   -> az_bn3d_finalize merges the partials per channel with Chan's parallel
+//      formula in fp64 (deterministic, no cancellation), updates the running stats
+//      and emits scale = gamma*invstd, shift = beta - mean*scale
+//   -> az_bn3d_apply: y = relu?(x*scale + shift (+residual)), one HBM pass.
+// Eval forward: az_bn3d_eval_affine folds running stats into (scale, shift), which
+//   the conv epilogue applies directly (no extra pass).
+// Train backward (dy -> dx_raw, dgamma, dbeta, dresidual):
+//   az_bn3d_bwd_reduce: per-block partials of sum(dz), sum(dz*xhat), dz = dy*[y>0]
+//   az_bn3d_bwd_finalize: fp64 merge -> dgamma, dbeta, and the two per-channel
+//      coefficients of the apply pass
+//   az_bn3d_bwd_apply: dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); optional dz out.
+#include "az_common.h"
+
+__global__ void __launch_bounds__(256)
+bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
+                   float *__restrict__ scale, float *__restrict__ shift,
+                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                   const float *__restrict__ part, const float *__restrict__ cnt,
+                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                   long long ntiles, int C, float eps, float momentum) {
+    const int c = blockIdx.x;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (long long t = threadIdx.x; t < ntiles; t += 256) {
+        const double nt = cnt[t];
+        if (nt <= 0.0) continue;
+        const double st = part[(t * C + c) * 2 + 0], m2t = part[(t * C + c) * 2 + 1];
+        const double mt = st / nt;
+        const double tot = n + nt, delta = mt - mean;
+        mean += delta * nt / tot;
+        m2 += m2t + delta * delta * n * nt / tot;
+        n = tot;
+    }
+    __shared__ double sn[256], sm[256], s2[256];
+    sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double na = sn[threadIdx.x], nb = sn[threadIdx.x + o];
+            const double tot = na + nb;
+            if (tot > 0.0) {
+                const double delta = sm[threadIdx.x + o] - sm[threadIdx.x];
+                sm[threadIdx.x] += delta * nb / tot;
+                s2[threadIdx.x] += s2[threadIdx.x + o] + delta * delta * na * nb / tot;
+                sn[threadIdx.x] = tot;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double N = sn[0], mu = sm[0], var = s2[0] / N;
+        const double istd = 1.0 / sqrt(var + (double)eps);
+        mean_out[c] = (float)mu;
+        invstd_out[c] = (float)istd;
+        const float sc = gamma[c] * (float)istd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mu * sc;
+        if (running_mean) {
+            const double unbiased = N > 1.0 ? s2[0] / (N - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_affine_kernel(float *scale, float *shift, const float *gamma,
+                                      const float *beta, const float *rm, const float *rv,
+                                      float eps, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
+                const float *__restrict__ scale, const float *__restrict__ shift,
+                const float4 *__restrict__ res, int relu, long long total4) {
+    constexpr int C4 = C / 4;
+    __shared__ float4 ssc[C4], ssh[C4];
+    if (threadIdx.x < C4) {
+        ssc[threadIdx.x] = reinterpret_cast<const float4 *>(scale)[threadIdx.x];
+        ssh[threadIdx.x] = reinterpret_cast<const float4 *>(shift)[threadIdx.x];
+    }
+    __syncthreads();
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
+        const int c4 = (int)(i % C4);
+        const float4 v = x[i], sc = ssc[c4], sh = ssh[c4];
+        float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z,
+                               v.w * sc.w + sh.w);
+        if (res) {
+            const float4 r = res[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        y[i] = o;
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------------
+// partial[block][C][2]: sum(dz), sum(dz * xhat) over the block's voxels
+template <int C>
+__global__ void __launch_bounds__(256)
+bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
+                     const float *__restrict__ y, const float *__restrict__ x,
+                     const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                     long long nvox) {
+    // thread t owns channel quad (t % C4) and voxel lane (t / C4); C4 divides 256
+    constexpr int C4 = C / 4, VPB = 256 / C4;
+    const int c4 = threadIdx.x % C4, vl = threadIdx.x / C4;
+    const float4 mu = reinterpret_cast<const float4 *>(mean)[c4];
+    const float4 is = reinterpret_cast<const float4 *>(invstd)[c4];
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        const size_t i = (size_t)v * C4 + c4;
+        float4 g = reinterpret_cast<const float4 *>(dy)[i];
+        if (relu) {
+            const float4 yy = reinterpret_cast<const float4 *>(y)[i];
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        const float4 xx = reinterpret_cast<const float4 *>(x)[i];
+        s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+        s2.x += g.x * ((xx.x - mu.x) * is.x); s2.y += g.y * ((xx.y - mu.y) * is.y);
+        s2.z += g.z * ((xx.z - mu.z) * is.z); s2.w += g.w * ((xx.w - mu.w) * is.w);
+    }
+    __shared__ float4 r1[256], r2[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
+    __syncthreads();
+    if (vl == 0) {
+        for (int k = 1; k < VPB; ++k) {
+            const float4 a = r1[k * C4 + c4], b = r2[k * C4 + c4];
+            s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+            s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+        }
+        float *p = partial + ((size_t)blockIdx.x * C + c4 * 4) * 2;
+        p[0] = s1.x; p[1] = s2.x; p[2] = s1.y; p[3] = s2.y;
+        p[4] = s1.z; p[5] = s2.z; p[6] = s1.w; p[7] = s2.w;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_bwd_finalize_kernel(float *__restrict__ dgamma, float *__restrict__ dbeta,
+                       float *__restrict__ coef, const float *__restrict__ partial,
+                       const float *__restrict__ gamma, const float *__restrict__ invstd,
+                       int nblocks, int C, double nvox) {
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int t = threadIdx.x; t < nblocks; t += 256) {
+        a += partial[((size_t)t * C + c) * 2 + 0];
+        b += partial[((size_t)t * C + c) * 2 + 1];
+    }
+    __shared__ double sa[256], sb[256];
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sa[threadIdx.x] += sa[threadIdx.x + o];
+            sb[threadIdx.x] += sb[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        dbeta[c] = (float)sa[0];
+        dgamma[c] = (float)sb[0];
+        // dx = k0 * (dz - k1 - xhat * k2)
+        coef[c * 3 + 0] = gamma[c] * invstd[c];
+        coef[c * 3 + 1] = (float)(sa[0] / nvox);
+        coef[c * 3 + 2] = (float)(sb[0] / nvox);
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
+                    const float4 *__restrict__ dy, const float4 *__restrict__ y,
+                    const float4 *__restrict__ x, const float *__restrict__ mean,
+                    const float *__restrict__ invstd, const float *__restrict__ coef, int relu,
+                    long long total4) {
+    constexpr int C4 = C / 4;
+    __shared__ float smu[C], sis[C], k0[C], k1[C], k2[C];
+    if (threadIdx.x < C) {
+        smu[threadIdx.x] = mean[threadIdx.x];
+        sis[threadIdx.x] = invstd[threadIdx.x];
+        k0[threadIdx.x] = coef[threadIdx.x * 3 + 0];
+        k1[threadIdx.x] = coef[threadIdx.x * 3 + 1];
+        k2[threadIdx.x] = coef[threadIdx.x * 3 + 2];
+    }
+    __syncthreads();
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
+        const int c = (int)(i % C4) * 4;
+        float4 g = dy[i];
+        if (relu) {
+            const float4 yy = y[i];
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (dz_out) dz_out[i] = g;
+        const float4 xx = x[i];
+        float4 o;
+        o.x = k0[c + 0] * (g.x - k1[c + 0] - (xx.x - smu[c + 0]) * sis[c + 0] * k2[c + 0]);
+        o.y = k0[c + 1] * (g.y - k1[c + 1] - (xx.y - smu[c + 1]) * sis[c + 1] * k2[c + 1]);
+        o.z = k0[c + 2] * (g.z - k1[c + 2] - (xx.z - smu[c + 2]) * sis[c + 2] * k2[c + 2]);
+        o.w = k0[c + 3] * (g.w - k1[c + 3] - (xx.w - smu[c + 3]) * sis[c + 3] * k2[c + 3]);
+        dx[i] = o;
+    }
+}
+
+// y = relu?(a + b) and its masked backward, for the plain residual sums of psmnet_3.py
+__global__ void __launch_bounds__(256)
+add_relu_kernel(float4 *__restrict__ y, const float4 *__restrict__ a,
+                const float4 *__restrict__ b, int relu, long long total4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
+        const float4 p = a[i], q = b[i];
+        float4 o = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        y[i] = o;
+    }
+}
+
+#define BN_GRID(total) az_grid_for((total), 256)
+
+extern "C" int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
+                                float *running_mean, float *running_var, const float *partials,
+                                const float *counts, const float *gamma, const float *beta,
+                                long long ntiles, int C, float eps, float momentum,
+                                void *stream) {
+    AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
+    AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta);
+    AZ_REQUIRE(ntiles > 0 && C > 0);
+    if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, az_stream(stream), mean, invstd,
+                       scale, shift, running_mean, running_var, partials, counts, gamma, beta,
+                       ntiles, C, eps, momentum);
+    return az_launch_status();
+}
+
+extern "C" int az_bn3d_eval_affine(float *scale, float *shift, const float *gamma,
+                                   const float *beta, const float *running_mean,
+                                   const float *running_var, float eps, int C, void *stream) {
+    AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta);
+    AZ_REQUIRE_PTR(running_mean); AZ_REQUIRE_PTR(running_var);
+    AZ_REQUIRE(C > 0);
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, az_stream(stream),
+                       scale, shift, gamma, beta, running_mean, running_var, eps, C);
+    return az_launch_status();
+}
+
+extern "C" int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shift,
+                             const float *residual, int relu, long long nvox, int C,
+                             void *stream) {
+    AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
+    AZ_REQUIRE(nvox > 0);
+    const long long total4 = nvox * C / 4;
+    const float4 *r4 = reinterpret_cast<const float4 *>(residual);
+    if (C == 32)
+        hipLaunchKernelGGL(bn_apply_kernel<32>, dim3(BN_GRID(total4)), dim3(256), 0, az_stream(stream),
+                           (float4 *)y, (const float4 *)x, scale, shift, r4, relu, total4);
+    else if (C == 64)
+        hipLaunchKernelGGL(bn_apply_kernel<64>, dim3(BN_GRID(total4)), dim3(256), 0, az_stream(stream),
+                           (float4 *)y, (const float4 *)x, scale, shift, r4, relu, total4);
+    else
+        return AZ_EUNSUPPORTED;
+    return az_launch_status();
+}
+
+extern "C" long long az_bn3d_bwd_workspace(long long nvox, int C) {
+    if (nvox <= 0 || (C != 32 && C != 64)) return AZ_EINVAL;
+    const int vpb = 256 / (C / 4);
+    const long long blocks = az_grid_for((nvox + vpb - 1) / vpb * 256, 256);
+    return blocks * C * 2 * (long long)sizeof(float);
+}
+
+extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
+                           float *workspace, long long workspace_bytes, const float *dy,
+                           const float *y, const float *x, const float *mean,
+                           const float *invstd, const float *gamma, int relu, long long nvox,
+                           int C, void *stream) {
+    AZ_REQUIRE_PTR(dx); AZ_REQUIRE_PTR(dgamma); AZ_REQUIRE_PTR(dbeta); AZ_REQUIRE_PTR(coef);
+    AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(dy); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(mean);
+    AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(gamma);
+    if (relu) AZ_REQUIRE_PTR(y);
+    const long long need = az_bn3d_bwd_workspace(nvox, C);
+    if (need < 0) return (int)need;
+    if (workspace_bytes < need) return AZ_EWORKSPACE;
+    const int blocks = (int)(need / (C * 2 * sizeof(float)));
+    const long long total4 = nvox * C / 4;
+    hipStream_t s = az_stream(stream);
+    if (C == 32) {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
+                           x, mean, invstd, relu, nvox);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
+                           x, mean, invstd, relu, nvox);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef,
+                       workspace, gamma, invstd, blocks, C, (double)nvox);
+    if (C == 32)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<32>, dim3(BN_GRID(total4)), dim3(256), 0, s,
+                           (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
+                           (const float4 *)x, mean, invstd, coef, relu, total4);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<64>, dim3(BN_GRID(total4)), dim3(256), 0, s,
+                           (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
+                           (const float4 *)x, mean, invstd, coef, relu, total4);
+    return az_launch_status();
+}
+
+extern "C" int az_add_relu(float *y, const float *a, const float *b, int relu, long long n,
+                           void *stream) {
+    AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(a); AZ_REQUIRE_PTR(b);
+    AZ_REQUIRE(n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(add_relu_kernel, dim3(BN_GRID(n / 4)), dim3(256), 0, az_stream(stream),
+                       (float4 *)y, (const float4 *)a, (const float4 *)b, relu, n / 4);
+    return az_launch_status();
+}

@@ -1,0 +1,348 @@
+// K4/K5 -- 3x3x3 convolution family of the PSMNet cost aggregation on fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 157 TFLOP/s dense peak).
+// Reference call sites: nets/psmnet/psmnet_submodule_3.py:44-56 (convbn_3d),
+// nets/psmnet/psmnet_3.py:15-58 (hourglass convs / ConvTranspose3d), :87-117.
+//
+// One kernel template, three index maps (all pad 1, kernel 3):
+//   MODE 0  stride-1 conv            in = o - 1 + k
+//   MODE 1  stride-2 conv            in = 2o - 1 + k
+//   MODE 2  stride-2 TRANSPOSED conv o = 2i - 1 + k, run as 8 output-parity phases:
+//           parity 0 -> tap k=1 (i = t), parity 1 -> taps k=2 (i = t), k=0 (i = t+1)
+// Forward, input-gradient and transposed variants of every layer reduce to these
+// maps with re-packed weights (az_conv3d_pack_weights).
+//
+// Layout: activations are channels-last NDHWC, so one voxel is 32/64 contiguous
+// floats.  Implicit GEMM: M = 32 output voxels (a 4x8 patch), N = 32 output
+// channels, K = 27 taps x Cin.  ONE 64-lane wavefront (= one workgroup, no
+// barriers) owns a 4x16 (MODE 1: 4x8) output patch for all Cout:
+//   * per (input plane, 32-channel chunk) it stages the zero-padded input slab in
+//     its private LDS region, voxel stride 36 dwords (bank-conflict padding);
+//   * per tap, A fragments come from LDS (4 x ds_read_b128 = 16 k-values of the
+//     lane's voxel) and B fragments straight from the L2-resident packed weights
+//     (4 x global_load_dwordx4 = the same 16 k-values of the lane's out-channel);
+//   * 16 MFMAs per (M-tile, N-tile, tap, chunk); accumulators never leave registers.
+// fp32 MFMA is 64 cycles/instruction, so one slab (<= 22 KB) feeds >= 18k cycles of
+// matrix work: the kernel is MFMA-bound by construction; LDS/L2 traffic is noise.
+//
+// Epilogues: (0) y = acc*scale[c] + shift[c] (+residual) (ReLU) -- eval-mode BN folded
+// or plain conv; (1) raw store + per-tile per-channel (sum, centred M2) partials for
+// train-mode BatchNorm (merged with Chan's formula in fp64 by az_bn3d_finalize).
+// SRC 1 synthesises the PSMNet concat cost volume on the fly from the two NHWC
+// feature maps (reference psmnet_3.py:149-163) instead of reading a 64-channel tensor.
+#include "az_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CV_VS 36  // slab voxel stride in dwords
+
+struct ConvArgs {
+    const float *in;    // NDHWC input (coarse tensor for MODE 2); SRC 1: left features NHWC
+    const float *in2;   // SRC 1: right features NHWC
+    const float *wp;    // packed weights
+    float *out;         // NDHWC output
+    const float *scale, *shift, *res;  // EPI 0 (any may be null)
+    float *part;        // EPI 1: [tiles][COUT][2]
+    float *cnt;         // EPI 1: [tiles]
+    int B, Di, Hi, Wi;  // input dims
+    int Do, Ho, Wo;     // output dims
+    int Dt, tiles_y, tiles_x;  // index-space extents (MODE 2: coarse dims / phase tiles)
+    int relu;
+};
+
+template <int CIN, int COUT, int MODE, int EPI, int SRC>
+__global__ void __launch_bounds__(64)
+conv3d_gather_kernel(const ConvArgs a) {
+    constexpr int NCH = CIN / 32, NR = COUT / 32;
+    constexpr int MR = (MODE == 1) ? 1 : 2;
+    constexpr int TY = 4, TX = 8 * MR;
+    constexpr int SY = (MODE == 0) ? TY + 2 : (MODE == 1) ? 2 * TY + 1 : TY + 1;
+    constexpr int SX = (MODE == 0) ? TX + 2 : (MODE == 1) ? 2 * TX + 1 : TX + 1;
+    __shared__ __attribute__((aligned(16))) float slab[SY * SX * CV_VS];
+
+    const int lane = threadIdx.x;
+    int bid = blockIdx.x;
+    const int tile_id = bid;
+    const int tix = bid % a.tiles_x; bid /= a.tiles_x;
+    const int tiy = bid % a.tiles_y; bid /= a.tiles_y;
+    int pd = 0, ph = 0, pw = 0;
+    if (MODE == 2) {
+        const int phase = bid & 7; bid >>= 3;
+        pd = phase >> 2; ph = (phase >> 1) & 1; pw = phase & 1;
+    }
+    const int td = bid % a.Dt;
+    const int b = bid / a.Dt;
+    const int ty0 = tiy * TY, tx0 = tix * TX;  // tile origin in index space
+    // input coordinates of slab voxel (0,0)
+    const int ih0 = (MODE == 0) ? ty0 - 1 : (MODE == 1) ? 2 * ty0 - 1 : ty0;
+    const int iw0 = (MODE == 0) ? tx0 - 1 : (MODE == 1) ? 2 * tx0 - 1 : tx0;
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    const int nd = (MODE == 2) ? 1 + pd : 3;
+    const int nh = (MODE == 2) ? 1 + ph : 3;
+    const int nw = (MODE == 2) ? 1 + pw : 3;
+    const int row = lane & 31, half = lane >> 5;
+    const int rty = row >> 3, rtx = row & 7;
+    const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
+
+    for (int sd = 0; sd < nd; ++sd) {
+        const int kd = (MODE == 2) ? (pd ? 2 - 2 * sd : 1) : sd;
+        const int id = (MODE == 0) ? td - 1 + sd : (MODE == 1) ? 2 * td - 1 + sd
+                                                               : td + (pd ? sd : 0);
+        if (id < 0 || id >= a.Di) continue;  // wave-uniform: a zero-padding plane
+        for (int cc = 0; cc < NCH; ++cc) {
+            __syncthreads();  // previous slab fully consumed (single-wave group: fence only)
+            // ---- stage the slab: SY*SX voxels x 8 float4 ---------------------------
+            for (int q = lane; q < SY * SX * 8; q += 64) {
+                const int v = q >> 3, part = q & 7;
+                const int sy = v / SX, sx = v - sy * SX;
+                const int ih = ih0 + sy, iw = iw0 + sx;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
+                    if (SRC == 0) {
+                        const size_t vox = (((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw;
+                        val = *reinterpret_cast<const float4 *>(a.in + vox * CIN + cc * 32 + part * 4);
+                    } else if (iw >= id) {  // concat cost volume: plane id = disparity index
+                        const size_t rowb = ((size_t)b * a.Hi + ih) * a.Wi;
+                        const float *src = (cc == 0) ? a.in + (rowb + iw) * 32
+                                                     : a.in2 + (rowb + iw - id) * 32;
+                        val = *reinterpret_cast<const float4 *>(src + part * 4);
+                    }
+                }
+                *reinterpret_cast<float4 *>(&slab[v * CV_VS + part * 4]) = val;
+            }
+            __syncthreads();
+            // ---- taps of this plane / chunk -------------------------------------------
+            for (int sh = 0; sh < nh; ++sh) {
+                const int kh = (MODE == 2) ? (ph ? 2 - 2 * sh : 1) : sh;
+                const int eh = (MODE == 2) ? (ph ? sh : 0) : sh;
+                for (int sw = 0; sw < nw; ++sw) {
+                    const int kw = (MODE == 2) ? (pw ? 2 - 2 * sw : 1) : sw;
+                    const int ew = (MODE == 2) ? (pw ? sw : 0) : sw;
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+                    float4 bq[NR][4];
+#pragma unroll
+                    for (int n = 0; n < NR; ++n)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            bq[n][j] = wp4[((((size_t)tap * NCH + cc) * NR + n) * 4 + j) * 64 + lane];
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        const int sy = ((MODE == 1) ? 2 * rty : rty) + eh;
+                        const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew;
+                        const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
+                        float4 aq[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
+#pragma unroll
+                        for (int n = 0; n < NR; ++n)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bq[n][j].x, acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bq[n][j].y, acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bq[n][j].z, acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bq[n][j].w, acc[m][n], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------
+    // C/D map of 32x32 MFMA: column (out channel) = lane & 31, row (voxel) =
+    // (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    const int od = (MODE == 2) ? 2 * td + pd : td;
+    // output voxel of accumulator register r of M-tile m: returns validity + element base
+    auto voxel = [&](int m, int r, size_t &base) -> bool {
+        const int vrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int ty = ty0 + (vrow >> 3), tx = tx0 + (vrow & 7) + 8 * m;
+        const int oh = (MODE == 2) ? 2 * ty + ph : ty;
+        const int ow = (MODE == 2) ? 2 * tx + pw : tx;
+        base = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * COUT;
+        return (oh < a.Ho) && (ow < a.Wo);
+    };
+    if (EPI == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                size_t base;
+                if (!voxel(m, r, base)) continue;
+#pragma unroll
+                for (int n = 0; n < NR; ++n) {
+                    const int co = n * 32 + row;
+                    float y = acc[m][n][r];
+                    if (a.scale) y *= a.scale[co];
+                    if (a.shift) y += a.shift[co];
+                    if (a.res) y += a.res[base + co];
+                    if (a.relu) y = fmaxf(y, 0.f);
+                    a.out[base + co] = y;
+                }
+            }
+    } else {
+        int nvalid = 0;
+        unsigned okmask = 0;  // bit (m*16 + r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                size_t base;
+                const bool ok = voxel(m, r, base);
+                if (ok) {
+                    okmask |= 1u << (m * 16 + r);
+                    nvalid++;
+#pragma unroll
+                    for (int n = 0; n < NR; ++n) a.out[base + n * 32 + row] = acc[m][n][r];
+                }
+            }
+        const int ntot = nvalid + __shfl_xor(nvalid, 32);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += ((okmask >> (m * 16 + r)) & 1u) ? acc[m][n][r] : 0.f;
+            s += __shfl_xor(s, 32);
+            const float mean = s / (float)max(ntot, 1);
+            float m2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dlt = acc[m][n][r] - mean;
+                    m2 += ((okmask >> (m * 16 + r)) & 1u) ? dlt * dlt : 0.f;
+                }
+            m2 += __shfl_xor(m2, 32);
+            if (half == 0) {
+                const int co = n * 32 + row;
+                a.part[((size_t)tile_id * COUT + co) * 2 + 0] = s;
+                a.part[((size_t)tile_id * COUT + co) * 2 + 1] = m2;
+            }
+        }
+        if (lane == 0) a.cnt[tile_id] = (float)ntot;
+    }
+}
+
+// ---- weight packing -----------------------------------------------------------------
+// packed[((tap*NCH + cc)*NR + n)*1024 + j*256 + lane*4 + e] =
+//     src[(n*32 + (lane&31))*sn + (cc*32 + 16*(lane>>5) + 4*j + e)*sk + (flip ? 26-tap : tap)]
+__global__ void __launch_bounds__(256)
+conv3d_pack_kernel(float *__restrict__ dst, const float *__restrict__ src, int cin, int cout,
+                   long long sn, long long sk, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 3, lane = (idx >> 2) & 63, j = (idx >> 8) & 3;
+    int r = idx >> 10;
+    const int nr = cout / 32, nch = cin / 32;
+    const int n = r % nr; r /= nr;
+    const int cc = r % nch;
+    const int tap = r / nch;
+    const int co = n * 32 + (lane & 31);
+    const int ci = cc * 32 + 16 * (lane >> 5) + 4 * j + e;
+    dst[idx] = src[co * sn + ci * sk + (flip ? 26 - tap : tap)];
+}
+
+template <int CIN, int COUT, int MODE, int EPI, int SRC>
+static int launch_conv(const ConvArgs &a, hipStream_t s) {
+    long long blocks = (long long)a.B * a.Dt * a.tiles_y * a.tiles_x * (MODE == 2 ? 8 : 1);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
+    hipLaunchKernelGGL((conv3d_gather_kernel<CIN, COUT, MODE, EPI, SRC>), dim3((unsigned)blocks),
+                       dim3(64), 0, s, a);
+    return az_launch_status();
+}
+
+template <int MODE, int EPI>
+static int dispatch_channels(const ConvArgs &a, int cin, int cout, int src, hipStream_t s) {
+    if (src == 1) {
+        if (MODE != 0 || cin != 64) return AZ_EUNSUPPORTED;
+        if (cout == 32) return launch_conv<64, 32, 0, EPI, 1>(a, s);
+        return AZ_EUNSUPPORTED;
+    }
+    if (cin == 32 && cout == 32) return launch_conv<32, 32, MODE, EPI, 0>(a, s);
+    if (cin == 64 && cout == 32) return launch_conv<64, 32, MODE, EPI, 0>(a, s);
+    if (cin == 32 && cout == 64) return launch_conv<32, 64, MODE, EPI, 0>(a, s);
+    if (cin == 64 && cout == 64) return launch_conv<64, 64, MODE, EPI, 0>(a, s);
+    return AZ_EUNSUPPORTED;
+}
+
+static void conv_out_dims(int mode, int Di, int Hi, int Wi, int &Do, int &Ho, int &Wo) {
+    if (mode == 0) { Do = Di; Ho = Hi; Wo = Wi; }
+    else if (mode == 1) { Do = (Di - 1) / 2 + 1; Ho = (Hi - 1) / 2 + 1; Wo = (Wi - 1) / 2 + 1; }
+    else { Do = 2 * Di; Ho = 2 * Hi; Wo = 2 * Wi; }
+}
+
+static int conv_tiles(int mode, int Di, int Hi, int Wi, int &Dt, int &ty, int &tx) {
+    int Do, Ho, Wo;
+    conv_out_dims(mode, Di, Hi, Wi, Do, Ho, Wo);
+    const int TX = (mode == 1) ? 8 : 16;
+    if (mode == 2) { Dt = Di; ty = (Hi + 3) / 4; tx = (Wi + TX - 1) / TX; }
+    else { Dt = Do; ty = (Ho + 3) / 4; tx = (Wo + TX - 1) / TX; }
+    return 0;
+}
+
+extern "C" long long az_conv3d_num_tiles(int mode, int B, int Di, int Hi, int Wi) {
+    if (mode < 0 || mode > 2 || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return AZ_EINVAL;
+    int Dt, ty, tx;
+    conv_tiles(mode, Di, Hi, Wi, Dt, ty, tx);
+    return (long long)B * Dt * ty * tx * (mode == 2 ? 8 : 1);
+}
+
+extern "C" int az_conv3d_pack_weights(float *packed, const float *w, int cin, int cout,
+                                      long long stride_out, long long stride_in, int flip,
+                                      void *stream) {
+    AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w);
+    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0) return AZ_EUNSUPPORTED;
+    const int total = 27 * cin * cout;
+    hipLaunchKernelGGL(conv3d_pack_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                       az_stream(stream), packed, w, cin, cout, stride_out, stride_in, flip, total);
+    return az_launch_status();
+}
+
+static int conv_common(ConvArgs &a, int mode, int B, int cin, int Di, int Hi, int Wi, int src) {
+    if (mode < 0 || mode > 2 || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return AZ_EINVAL;
+    a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
+    conv_out_dims(mode, Di, Hi, Wi, a.Do, a.Ho, a.Wo);
+    conv_tiles(mode, Di, Hi, Wi, a.Dt, a.tiles_y, a.tiles_x);
+    (void)cin; (void)src;
+    return AZ_OK;
+}
+
+extern "C" int az_conv3d_fwd(float *out, const float *in, const float *in2,
+                             const float *packed_w, const float *scale, const float *shift,
+                             const float *residual, int relu, int mode, int src, int B, int cin,
+                             int cout, int Di, int Hi, int Wi, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w);
+    if (src == 1) AZ_REQUIRE_PTR(in2);
+    ConvArgs a{};
+    if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, src)) return e;
+    a.in = in; a.in2 = in2; a.wp = packed_w; a.out = out;
+    a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu;
+    hipStream_t s = az_stream(stream);
+    if (mode == 0) return dispatch_channels<0, 0>(a, cin, cout, src, s);
+    if (mode == 1) return dispatch_channels<1, 0>(a, cin, cout, src, s);
+    return dispatch_channels<2, 0>(a, cin, cout, src, s);
+}
+
+extern "C" int az_conv3d_fwd_stats(float *out, float *partials, float *counts, const float *in,
+                                   const float *in2, const float *packed_w, int mode, int src,
+                                   int B, int cin, int cout, int Di, int Hi, int Wi,
+                                   void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w);
+    AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts);
+    if (src == 1) AZ_REQUIRE_PTR(in2);
+    ConvArgs a{};
+    if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, src)) return e;
+    a.in = in; a.in2 = in2; a.wp = packed_w; a.out = out; a.part = partials; a.cnt = counts;
+    hipStream_t s = az_stream(stream);
+    if (mode == 0) return dispatch_channels<0, 1>(a, cin, cout, src, s);
+    if (mode == 1) return dispatch_channels<1, 1>(a, cin, cout, src, s);
+    return dispatch_channels<2, 1>(a, cin, cout, src, s);
+}

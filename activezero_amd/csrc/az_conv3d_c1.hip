@@ -1,0 +1,204 @@
+// The 32 -> 1 classifier convolutions of PSMNet (reference
+// nets/psmnet/psmnet_3.py:103-117, :177-179: classifN[2] = Conv3d(32,1,3,pad 1) and the
+// running sums cost2 = classif2(out2) + cost1, cost3 = classif3(out3) + cost2).
+//
+// N = 1 is not MFMA-shaped (and fp32 MFMA runs at the VALU rate anyway): these are
+// VALU kernels, 2*27*32 flops per voxel against 128 B of input -> HBM/LDS bound.
+//   fwd   : block = 8x32 output voxels of one (b, d) plane; per kd the 10x34x32ch
+//           input slab is staged in LDS (voxel stride 36 dwords), weights are
+//           wave-uniform scalar loads.  Optional fused "+ previous cost".
+//   dgrad : gin[v][c] = sum_k gout[v+1-k] * w[c][k]; 8 lanes per voxel (one channel
+//           quad each) -> every voxel's 128 B is written coalesced; the 3x10x34 gout
+//           halo tile lives in LDS, the lane's 108 weights in registers.
+//   wgrad : gw[c][k] = sum_v in[v][c] * gout[v+1-k]; same mapping, 108 register
+//           accumulators per lane, LDS reduction per block, 864 float atomics per block.
+#include "az_common.h"
+
+#define C1_TH 8
+#define C1_TW 32
+#define C1_VS 36
+
+__global__ void __launch_bounds__(256)
+c1_fwd_kernel(float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
+              const float *__restrict__ addend, int D, int H, int W, int tiles_x) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];  // (TH+2)*(TW+2)*36
+    const int tx0 = (blockIdx.x % tiles_x) * C1_TW, ty0 = (blockIdx.x / tiles_x) * C1_TH;
+    const int od = blockIdx.y, b = blockIdx.z;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
+    float acc = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int id = od - 1 + kd;
+        if (id < 0 || id >= D) continue;  // block-uniform
+        __syncthreads();
+        for (int q = threadIdx.x; q < SY * SX * 8; q += 256) {
+            const int v = q >> 3, part = q & 7;
+            const int sy = v / SX, sx = v - sy * SX;
+            const int ih = ty0 - 1 + sy, iw = tx0 - 1 + sx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                val = *reinterpret_cast<const float4 *>(
+                    in + ((((size_t)b * D + id) * H + ih) * W + iw) * 32 + part * 4);
+            *reinterpret_cast<float4 *>(&slab[v * C1_VS + part * 4]) = val;
+        }
+        __syncthreads();
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+                const float *ap = &slab[((ly + kh) * SX + lx + kw) * C1_VS];
+                const int tap = (kd * 3 + kh) * 3 + kw;
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(ap + 4 * c4);
+                    // w is [1][32][27]: element (ci, tap) at ci*27 + tap (wave-uniform)
+                    acc += x.x * w[(4 * c4 + 0) * 27 + tap];
+                    acc += x.y * w[(4 * c4 + 1) * 27 + tap];
+                    acc += x.z * w[(4 * c4 + 2) * 27 + tap];
+                    acc += x.w * w[(4 * c4 + 3) * 27 + tap];
+                }
+            }
+    }
+    const int oh = ty0 + ly, ow = tx0 + lx;
+    if (oh < H && ow < W) {
+        const size_t o = (((size_t)b * D + od) * H + oh) * W + ow;
+        out[o] = addend ? acc + addend[o] : acc;
+    }
+}
+
+// shared by dgrad / wgrad: stage gout[b][od-1..od+1][ty0-1..][tx0-1..] (zero padded)
+__device__ __forceinline__ void c1_load_gtile(float *gt, const float *__restrict__ gout, int b,
+                                              int od, int ty0, int tx0, int D, int H, int W) {
+    constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
+    for (int q = threadIdx.x; q < 3 * SY * SX; q += 256) {
+        const int sx = q % SX;
+        const int r = q / SX;
+        const int sy = r % SY, sd = r / SY;
+        const int gd = od - 1 + sd, gh = ty0 - 1 + sy, gw = tx0 - 1 + sx;
+        gt[q] = (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                    ? gout[(((size_t)b * D + gd) * H + gh) * W + gw] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+c1_dgrad_kernel(float *__restrict__ gin, const float *__restrict__ gout,
+                const float *__restrict__ w, int D, int H, int W, int tiles_x) {
+    constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
+    __shared__ float gt[3 * SY * SX];
+    const int tx0 = (blockIdx.x % tiles_x) * C1_TW, ty0 = (blockIdx.x / tiles_x) * C1_TH;
+    const int od = blockIdx.y, b = blockIdx.z;
+    c1_load_gtile(gt, gout, b, od, ty0, tx0, D, H, W);
+    const int quad = threadIdx.x & 7, vl = threadIdx.x >> 3;  // 32 voxels per pass
+    float wr[4][27];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) wr[c][t] = w[(quad * 4 + c) * 27 + t];
+    __syncthreads();
+    for (int p = 0; p < C1_TH; ++p) {  // one tile row (32 voxels) per pass
+        const int ly = p, lx = vl;
+        const int oh = ty0 + ly, ow = tx0 + lx;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // gin[v] += gout[v + 1 - k] * w[k]; tile-local index of v+1-k is (+1) shifted
+                    const float g = gt[((2 - kd) * SY + (ly + 2 - kh)) * SX + lx + 2 - kw];
+                    const int t = (kd * 3 + kh) * 3 + kw;
+                    acc.x += g * wr[0][t]; acc.y += g * wr[1][t];
+                    acc.z += g * wr[2][t]; acc.w += g * wr[3][t];
+                }
+        if (oh < H && ow < W)
+            *reinterpret_cast<float4 *>(gin + ((((size_t)b * D + od) * H + oh) * W + ow) * 32 + quad * 4) = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
+                const float *__restrict__ gout, int D, int H, int W, int tiles_x) {
+    constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
+    __shared__ float gt[3 * SY * SX];
+    __shared__ float red[864];
+    const int tx0 = (blockIdx.x % tiles_x) * C1_TW, ty0 = (blockIdx.x / tiles_x) * C1_TH;
+    const int od = blockIdx.y, b = blockIdx.z;
+    c1_load_gtile(gt, gout, b, od, ty0, tx0, D, H, W);
+    for (int q = threadIdx.x; q < 864; q += 256) red[q] = 0.f;
+    const int quad = threadIdx.x & 7, vl = threadIdx.x >> 3;
+    float acc[4][27];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc[c][t] = 0.f;
+    __syncthreads();
+    for (int p = 0; p < C1_TH; ++p) {
+        const int ly = p, lx = vl;
+        const int ih = ty0 + ly, iw = tx0 + lx;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ih < H && iw < W)
+            x = *reinterpret_cast<const float4 *>(in + ((((size_t)b * D + od) * H + ih) * W + iw) * 32 + quad * 4);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // out[o] = sum_k in[o - 1 + k] w[k]  =>  gw[k] += in[v] * gout[v + 1 - k]
+                    const float g = gt[((2 - kd) * SY + (ly + 2 - kh)) * SX + lx + 2 - kw];
+                    const int t = (kd * 3 + kh) * 3 + kw;
+                    acc[0][t] += x.x * g; acc[1][t] += x.y * g;
+                    acc[2][t] += x.z * g; acc[3][t] += x.w * g;
+                }
+    }
+    // reduce the 32 voxel-lanes that share a channel quad: lanes with equal (lane & 7);
+    // xor-shuffle over lane bits 3..5 inside the wave, then LDS atomics across the 4 waves.
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            float v = acc[c][t];
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if ((threadIdx.x & 63) < 8) atomicAdd(&red[(quad * 4 + c) * 27 + t], v);
+        }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 864; q += 256) atomicAdd(&gw[q], red[q]);
+}
+
+static int c1_check(int B, int D, int H, int W) {
+    if (!(B > 0 && D > 0 && H > 0 && W > 0)) return AZ_EINVAL;
+    if (B > 65535 || D > 65535) return AZ_EUNSUPPORTED;
+    return AZ_OK;
+}
+
+extern "C" int az_conv3d_c1_fwd(float *logits, const float *in, const float *w,
+                                const float *addend, int B, int D, int H, int W, void *stream) {
+    AZ_REQUIRE_PTR(logits); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(w);
+    if (int e = c1_check(B, D, H, W)) return e;
+    const int tiles_x = (W + C1_TW - 1) / C1_TW, tiles_y = (H + C1_TH - 1) / C1_TH;
+    const size_t lds = (size_t)(C1_TH + 2) * (C1_TW + 2) * C1_VS * sizeof(float);
+    hipLaunchKernelGGL(c1_fwd_kernel, dim3(tiles_x * tiles_y, D, B), dim3(256), lds,
+                       az_stream(stream), logits, in, w, addend, D, H, W, tiles_x);
+    return az_launch_status();
+}
+
+extern "C" int az_conv3d_c1_dgrad(float *grad_in, const float *grad_logits, const float *w,
+                                  int B, int D, int H, int W, void *stream) {
+    AZ_REQUIRE_PTR(grad_in); AZ_REQUIRE_PTR(grad_logits); AZ_REQUIRE_PTR(w);
+    if (int e = c1_check(B, D, H, W)) return e;
+    const int tiles_x = (W + C1_TW - 1) / C1_TW, tiles_y = (H + C1_TH - 1) / C1_TH;
+    hipLaunchKernelGGL(c1_dgrad_kernel, dim3(tiles_x * tiles_y, D, B), dim3(256), 0,
+                       az_stream(stream), grad_in, grad_logits, w, D, H, W, tiles_x);
+    return az_launch_status();
+}
+
+extern "C" int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *grad_logits,
+                                  int B, int D, int H, int W, void *stream) {
+    AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(grad_logits);
+    if (int e = c1_check(B, D, H, W)) return e;
+    if (hipMemsetAsync(grad_w, 0, 864 * sizeof(float), az_stream(stream)) != hipSuccess)
+        return AZ_ELAUNCH;
+    const int tiles_x = (W + C1_TW - 1) / C1_TW, tiles_y = (H + C1_TH - 1) / C1_TH;
+    hipLaunchKernelGGL(c1_wgrad_kernel, dim3(tiles_x * tiles_y, D, B), dim3(256), 0,
+                       az_stream(stream), grad_w, in, grad_logits, D, H, W, tiles_x);
+    return az_launch_status();
+}

@@ -1,0 +1,173 @@
+// Weight gradients of the 3x3x3 conv / transposed-conv layers on fp32 MFMA.
+//
+// Every layer's weight gradient has the form
+//   G[m][n][k] = sum_pos coarse[pos][m] * fine[S*pos - 1 + k][n],   k = (kd,kh,kw)
+// with (coarse, fine) = (grad_out, input) for Conv3d (G = dW[co][ci][k]) and
+// (coarse, fine) = (input, grad_out) for ConvTranspose3d stride 2 (G = dW[ci][co][k],
+// reference psmnet_3.py:34-58) -- both are PyTorch's native weight layouts.
+//
+// GEMM view: M = 32 coarse channels, N = 32 fine channels, K = positions, one
+// 32x32 accumulator per tap.  A wavefront (= workgroup) keeps the 9 taps of ONE kd
+// (144 accumulator registers) and walks a strided list of (b, plane, row-segment,
+// w-chunk) work items; per coarse row it stages the coarse chunk and the three fine
+// rows in its private LDS region and feeds v_mfma_f32_32x32x2_f32 with one dword of
+// each per lane (lane = channel, the two K slices = two neighbouring positions).
+// Only when its list is exhausted does it add the 9x32x32 block into the
+// tap-major workspace with float atomics (128-B segments), so atomics are ~1e-4 of
+// the flops.  az_conv3d_wgrad_unpack transposes [k][m][n] -> [m][n][k].
+#include "az_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgArgs {
+    const float *coarse, *fine;
+    float *ws;  // [27][CM][CN]
+    int B, Dc, Hc, Wc, Df, Hf, Wf;
+    int hseg_rows, nhseg, nwchunk;
+    long long nitems;
+    int waves_per_combo;
+};
+
+template <int CM, int CN, int S>
+__global__ void __launch_bounds__(64)
+conv3d_wgrad_kernel(const WgArgs a) {
+    constexpr int WCH = (S == 1) ? 32 : 16;  // coarse positions per chunk
+    constexpr int FW = S * (WCH - 1) + 3;    // fine positions per staged row
+    constexpr int MT = CM / 32, NT = CN / 32, NCOMBO = 3 * MT * NT;
+    __shared__ float sa[WCH * 32];
+    __shared__ float sf[3 * FW * 32];
+
+    const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
+    int combo = blockIdx.x % NCOMBO;
+    const int widx = blockIdx.x / NCOMBO;
+    const int nt = combo % NT; combo /= NT;
+    const int mt = combo % MT;
+    const int kd = combo / MT;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    for (long long item = widx; item < a.nitems; item += a.waves_per_combo) {
+        long long r = item;
+        const int wc = (int)(r % a.nwchunk); r /= a.nwchunk;
+        const int hs = (int)(r % a.nhseg); r /= a.nhseg;
+        const int cd = (int)(r % a.Dc);
+        const int b = (int)(r / a.Dc);
+        const int fd = S * cd - 1 + kd;
+        if (fd < 0 || fd >= a.Df) continue;
+        const int cw0 = wc * WCH, fw0 = S * cw0 - 1;
+        const int h_end = min((hs + 1) * a.hseg_rows, a.Hc);
+        for (int ch = hs * a.hseg_rows; ch < h_end; ++ch) {
+            __syncthreads();
+            // coarse chunk: WCH positions x 32 channels of M-tile mt
+            for (int q = lane; q < WCH * 8; q += 64) {
+                const int pos = q >> 3, part = q & 7;
+                const int cw = cw0 + pos;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cw < a.Wc)
+                    v = *reinterpret_cast<const float4 *>(
+                        a.coarse + ((((size_t)b * a.Dc + cd) * a.Hc + ch) * a.Wc + cw) * CM + mt * 32 + part * 4);
+                *reinterpret_cast<float4 *>(&sa[pos * 32 + part * 4]) = v;
+            }
+            // three fine rows x FW positions x 32 channels of N-tile nt
+            for (int q = lane; q < 3 * FW * 8; q += 64) {
+                const int part = q & 7;
+                const int p = q >> 3;
+                const int kh = p / FW, lw = p - kh * FW;
+                const int fh = S * ch - 1 + kh, fw = fw0 + lw;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf)
+                    v = *reinterpret_cast<const float4 *>(
+                        a.fine + ((((size_t)b * a.Df + fd) * a.Hf + fh) * a.Wf + fw) * CN + nt * 32 + part * 4);
+                *reinterpret_cast<float4 *>(&sf[p * 32 + part * 4]) = v;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int q = 0; q < WCH / 2; ++q) {
+                const int pos = 2 * q + half;
+                const float av = sa[pos * 32 + row];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float bv = sf[(kh * FW + S * pos + kw) * 32 + row];
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * 3 + kw], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // D[i][j]: i = coarse channel (row map), j = fine channel (lane & 31)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tap = kd * 9 + t;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int m = mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+            atomicAdd(&a.ws[((size_t)tap * CM + m) * CN + nt * 32 + row], acc[t][rg]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int cm, int cn) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // over [m][n][27]
+    if (idx >= cm * cn * 27) return;
+    const int tap = idx % 27, mn = idx / 27;
+    dst[idx] = ws[(size_t)tap * cm * cn + mn];
+}
+
+template <int CM, int CN, int S>
+static int launch_wgrad(WgArgs a, hipStream_t s) {
+    constexpr int WCH = (S == 1) ? 32 : 16;
+    constexpr int NCOMBO = 3 * (CM / 32) * (CN / 32);
+    a.nwchunk = (a.Wc + WCH - 1) / WCH;
+    // rows per segment: aim at >= 4 items per wave with ~2048 resident waves
+    const int target_waves = 256 * 8;
+    a.waves_per_combo = max(1, target_waves / NCOMBO);
+    const long long base_items = (long long)a.B * a.Dc * a.nwchunk;
+    int nhseg = (int)((4LL * a.waves_per_combo + base_items - 1) / base_items);
+    nhseg = max(1, min(nhseg, a.Hc));
+    a.hseg_rows = (a.Hc + nhseg - 1) / nhseg;
+    a.nhseg = (a.Hc + a.hseg_rows - 1) / a.hseg_rows;
+    a.nitems = base_items * a.nhseg;
+    if (a.nitems < a.waves_per_combo) a.waves_per_combo = (int)a.nitems;
+    hipLaunchKernelGGL((conv3d_wgrad_kernel<CM, CN, S>), dim3(a.waves_per_combo * NCOMBO), dim3(64),
+                       0, s, a);
+    return az_launch_status();
+}
+
+extern "C" long long az_conv3d_wgrad_workspace(int cm, int cn) {
+    if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32) return AZ_EINVAL;
+    return 27LL * cm * cn * (long long)sizeof(float);
+}
+
+extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
+                               const float *coarse, const float *fine, int stride, int B, int cm,
+                               int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf,
+                               void *stream) {
+    AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(coarse); AZ_REQUIRE_PTR(fine);
+    AZ_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Df > 0 && Hf > 0 && Wf > 0);
+    AZ_REQUIRE(stride == 1 || stride == 2);
+    const long long need = az_conv3d_wgrad_workspace(cm, cn);
+    if (need < 0) return AZ_EUNSUPPORTED;
+    if (workspace_bytes < need) return AZ_EWORKSPACE;
+    hipStream_t s = az_stream(stream);
+    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
+    WgArgs a{};
+    a.coarse = coarse; a.fine = fine; a.ws = workspace;
+    a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;
+    int rc = AZ_EUNSUPPORTED;
+#define WG_CASE(M, N)                                                           \
+    if (cm == M && cn == N)                                                     \
+        rc = (stride == 1) ? launch_wgrad<M, N, 1>(a, s) : launch_wgrad<M, N, 2>(a, s);
+    WG_CASE(32, 32) WG_CASE(32, 64) WG_CASE(64, 32) WG_CASE(64, 64)
+#undef WG_CASE
+    if (rc != AZ_OK) return rc;
+    const int total = cm * cn * 27;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w,
+                       workspace, cm, cn);
+    return az_launch_status();
+}

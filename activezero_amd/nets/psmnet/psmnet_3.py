@@ -103,12 +103,12 @@ class PSMNet(nn.Module):
         out3, _pre3, _post3 = self.dres4(out2, pre1, post2)
         out3 = agg3d.add(out3, c0)
 
-        def head(cls, v):
-            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True), cls[2])
+        def head(cls, v, running):
+            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True), cls[2], running)
 
-        cost1 = head(self.classif1, out1)
-        cost2 = head(self.classif2, out2) + cost1
-        cost3 = head(self.classif3, out3) + cost2
+        cost1 = head(self.classif1, out1, None)
+        cost2 = head(self.classif2, out2, cost1)
+        cost3 = head(self.classif3, out3, cost2)
         return cost1, cost2, cost3
 
     def _from_features(self, feat_l, feat_r):

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on BASELINE.json's metric:
+
+    stereo pairs/sec (540x960, D=192) fwd+bwd     [configs[1]: batch 4 per GPU,
+    PSMNet, supervised disparity loss only, Adam step included]
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; N>1 shards pairs across ranks (data parallel, RCCL gradient
+all-reduce through DistributedDataParallel), weak scaling: batch 4 per GPU.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+
+Synthetic data: rand images, ImageNet-normalised, 540 rows padded
+to 544 on top as test.py does; smooth ground-truth disparity in (5,185); weights
+from the reference init rule under manual_seed(1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+H_IMG, W_IMG, H_PAD, MAXDISP = 540, 960, 544, 192
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="pairs per GPU (config 2: 4)")
+    ap.add_argument("--height", type=int, default=H_IMG)
+    ap.add_argument("--width", type=int, default=W_IMG)
+    ap.add_argument("--maxdisp", type=int, default=MAXDISP)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", choices=["full", "crop"], default="full")
+    return ap.parse_args()
+
+
+def synth_batch(b, h_img, w_img, maxdisp, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
+    pad = (-h_img) % 32  # 540 -> 544 (hourglass needs H/4 divisible by 4; test.py:137-146)
+
+    def image():
+        x = (torch.rand(b, 3, h_img, w_img, device=device, generator=g) - mean) / std
+        return F.pad(x, (0, 0, pad, 0)).contiguous()
+
+    low = torch.randn(b, 1, (h_img + pad) // 16, w_img // 16, device=device, generator=g)
+    low = F.avg_pool2d(F.pad(low, (1, 1, 1, 1), mode="replicate"), 3, 1)
+    gt = 5.0 + (maxdisp - 12.0) * torch.sigmoid(
+        F.interpolate(low, size=(h_img + pad, w_img), mode="bilinear", align_corners=False))
+    gt[:, :, :pad] = 0.0  # padded rows carry no ground truth
+    return image(), image(), gt.contiguous()
+
+
+def disp_loss(preds, gt, maxdisp):
+    """utils/losses.py:7-15 psmnet_disp with the train.py:272 mask, written without
+    boolean-index compaction (no host sync)."""
+    mask = ((gt < maxdisp) & (gt > 0)).to(gt.dtype)
+    n = mask.sum()
+    p3, p2, p1 = preds
+    sl1 = lambda p: (F.smooth_l1_loss(p, gt, reduction="none") * mask).sum() / n
+    return 0.5 * sl1(p1) + 0.7 * sl1(p2) + sl1(p3)
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference's eager op sequence) timed on this
+    box's host cores on a bounded sample of the same workload: ONE pair, fwd+bwd."""
+    from oracle import psmnet_oracle as po
+
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    if args.cpu_sample == "full":
+        h, w, md = args.height, args.width, args.maxdisp
+        sample = f"1 pair {h}x{w} (padded to {h + (-h) % 32}), D={md}, fwd+bwd+loss, 1 step"
+    else:
+        h, w, md = 256, 512, args.maxdisp
+        sample = f"1 pair 256x512 crop, D={md}, fwd+bwd+loss, 1 step (NOT full size)"
+    torch.manual_seed(1)
+    model = po.PSMNetOracle(md, 3).train()
+    il, ir, gt = synth_batch(1, h, w, md, "cpu", 99)
+    t0 = time.perf_counter()
+    preds = model(il, ir)
+    loss = po.psmnet_disp_loss(preds, gt, po.disparity_mask(gt, md))
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": sample, "seconds": dt}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://")  # RCCL on ROCm
+
+    from activezero_amd import agg3d, profiler
+    from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
+
+    torch.manual_seed(1)  # configs/config.py:100
+    model = PSMNet(args.maxdisp).to(device).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[local_rank], bucket_cap_mb=32, gradient_as_bucket_view=True)
+    il, ir, gt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device, 1234 + rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = disp_loss(net(il, ir), gt, args.maxdisp)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profiler.start()  # HIP events around the dominant kernel, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = profiler.stop()
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        out = {
+            "metric": "stereo pairs/sec (540x960, D=192) fwd+bwd",
+            "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: PSMNet 540x960 (padded 544x960) D=192 fwd+bwd+Adam, "
+                                   "supervised disparity loss, batch 4 per GPU",
+                       "global_batch": args.batch * world, "height": args.height,
+                       "width": args.width, "maxdisp": args.maxdisp,
+                       "parallelism": f"dp{world}", "agg3d_backend": agg3d.BACKEND},
+            "loss": float(loss.item()),
+            "roofline": profiler.roofline(prof),
+            "cpu_baseline": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

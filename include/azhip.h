@@ -115,6 +115,78 @@ int az_patch_reproj_vis(float *vis, const float *R, const float *disp, int B, in
 int az_lcn(float *normed, float *stdv, const float *img, int B, int H, int W, int ksize,
            float eps, long long img_batch_stride, void *stream);
 
+/* ---- K4/K5: 3x3x3 convolution family on fp32 MFMA (NDHWC) ---------------------
+ * replaces the cuDNN/ATen calls behind nn.Conv3d / nn.ConvTranspose3d in
+ * nets/psmnet/psmnet_submodule_3.py:44-56 and nets/psmnet/psmnet_3.py:15-58,
+ * 87-117 (forward and, through autograd, their input / weight gradients).
+ * mode: 0 = stride-1 conv, 1 = stride-2 conv, 2 = stride-2 transposed conv
+ *       (kernel 3, padding 1, output_padding 1); channels in {32, 64}.
+ * in: [B,Di,Hi,Wi,cin]; out: [B,Do,Ho,Wo,cout] with (Do,Ho,Wo) = (Di,Hi,Wi),
+ * ((Di-1)/2+1, ...) or (2Di, 2Hi, 2Wi).
+ * src = 1 (mode 0, cin = 64 only): the input is the PSMNet concat cost volume
+ * synthesised on the fly from in = left features [B,Hi,Wi,32] and in2 = right
+ * features (Di = number of disparity planes); otherwise in2 is ignored. */
+
+/* packed[tap][cin/32][cout/32][4][64][4] from any [.][.][27] weight tensor:
+ * element (out-channel n, in-channel k, tap t) is read at
+ * w[n*stride_out + k*stride_in + (flip ? 26-t : t)]. */
+int az_conv3d_pack_weights(float *packed, const float *w, int cin, int cout,
+                           long long stride_out, long long stride_in, int flip, void *stream);
+/* number of wavefront tiles a launch uses = rows of the BN partial buffers */
+long long az_conv3d_num_tiles(int mode, int B, int Di, int Hi, int Wi);
+/* out = relu?( conv(in)*scale[c] + shift[c] + residual ); scale/shift/residual may be
+ * NULL (eval-mode BatchNorm folded into scale/shift, or a plain convolution). */
+int az_conv3d_fwd(float *out, const float *in, const float *in2, const float *packed_w,
+                  const float *scale, const float *shift, const float *residual, int relu,
+                  int mode, int src, int B, int cin, int cout, int Di, int Hi, int Wi,
+                  void *stream);
+/* out = conv(in) (raw) and, per tile and channel, partials[tile][c] = (sum, centred
+ * sum of squares), counts[tile] = valid voxels: the train-mode BatchNorm statistics. */
+int az_conv3d_fwd_stats(float *out, float *partials, float *counts, const float *in,
+                        const float *in2, const float *packed_w, int mode, int src, int B,
+                        int cin, int cout, int Di, int Hi, int Wi, void *stream);
+/* G[m][n][27] = sum_pos coarse[pos][m] * fine[stride*pos - 1 + k][n]: dW of Conv3d with
+ * (coarse, fine) = (grad_out, input), dW of ConvTranspose3d with (input, grad_out). */
+long long az_conv3d_wgrad_workspace(int cm, int cn);
+int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
+                    const float *coarse, const float *fine, int stride, int B, int cm, int cn,
+                    int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream);
+
+/* 32 -> 1 classifier conv (psmnet_3.py:103-117) with the fused running sum
+ * cost_k = classif_k(out_k) + cost_{k-1} (psmnet_3.py:177-179): logits [B,D,H,W] =
+ * conv(in [B,D,H,W,32], w [1,32,3,3,3]) + addend (may be NULL). */
+int az_conv3d_c1_fwd(float *logits, const float *in, const float *w, const float *addend,
+                     int B, int D, int H, int W, void *stream);
+int az_conv3d_c1_dgrad(float *grad_in, const float *grad_logits, const float *w, int B, int D,
+                       int H, int W, void *stream);
+int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *grad_logits, int B, int D,
+                       int H, int W, void *stream);
+
+/* ---- BatchNorm3d pieces around K4/K5 (psmnet_submodule_3.py:55) --------------------
+ * finalize: merge the conv partials (Chan, fp64) -> mean, invstd, scale = gamma*invstd,
+ * shift = beta - mean*scale; running stats updated in place (momentum, unbiased var)
+ * unless running_mean/var are NULL. */
+int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
+                     float *running_mean, float *running_var, const float *partials,
+                     const float *counts, const float *gamma, const float *beta,
+                     long long ntiles, int C, float eps, float momentum, void *stream);
+int az_bn3d_eval_affine(float *scale, float *shift, const float *gamma, const float *beta,
+                        const float *running_mean, const float *running_var, float eps, int C,
+                        void *stream);
+/* y = relu?( x*scale[c] + shift[c] + residual ) over nvox voxels of C channels */
+int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shift,
+                  const float *residual, int relu, long long nvox, int C, void *stream);
+/* backward of y = relu?(bn(x) + residual): dz = dy*[y>0] (or dy), dgamma, dbeta,
+ * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (may be NULL) = dz =
+ * gradient of the residual branch.  coef: [C][3] scratch. */
+long long az_bn3d_bwd_workspace(long long nvox, int C);
+int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
+                float *workspace, long long workspace_bytes, const float *dy, const float *y,
+                const float *x, const float *mean, const float *invstd, const float *gamma,
+                int relu, long long nvox, int C, void *stream);
+/* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175 */
+int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

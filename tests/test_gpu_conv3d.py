@@ -1,0 +1,195 @@
+"""GPU parity: the MFMA conv3d / deconv3d / BatchNorm3d kernels (K4/K5) against the
+oracle's op set (torch CPU conv3d / conv_transpose3d / batch_norm) and the goldens
+produced by the imported reference (g3_*)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from activezero_amd import agg3d, conv3d, ops  # noqa: E402
+from activezero_amd.nets.psmnet import psmnet_3  # noqa: E402
+from oracle import psmnet_oracle as po  # noqa: E402
+from tests._weights import load_procedural, seeded  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def cl(x):  # NCDHW (cpu) -> channels-last on the GPU
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+
+
+def ncdhw(x):  # channels-last (gpu) -> NCDHW cpu
+    return x.detach().permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (32, 64), (64, 64)])
+@pytest.mark.parametrize("dims", [(1, 5, 7, 19), (2, 4, 8, 16), (1, 3, 9, 33)])
+def test_conv_stride1_vs_torch(cin, cout, dims):
+    b, d, h, w = dims
+    x = seeded((b, cin, d, h, w), 1)
+    wt = seeded((cout, cin, 3, 3, 3), 2, -0.2, 0.2)
+    ref = F.conv3d(x, wt, padding=1)
+    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.CONV_S1)
+    close(ncdhw(out), ref, 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (32, 32), (64, 32)])
+@pytest.mark.parametrize("dims", [(1, 4, 6, 10), (2, 6, 8, 20), (1, 2, 10, 34)])
+def test_conv_stride2_vs_torch(cin, cout, dims):
+    b, d, h, w = dims
+    x = seeded((b, cin, d, h, w), 3)
+    wt = seeded((cout, cin, 3, 3, 3), 4, -0.2, 0.2)
+    ref = F.conv3d(x, wt, stride=2, padding=1)
+    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.CONV_S2)
+    close(ncdhw(out), ref, 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (32, 32), (32, 64)])
+@pytest.mark.parametrize("dims", [(1, 2, 3, 5), (2, 3, 4, 17), (1, 1, 5, 9)])
+def test_deconv_stride2_vs_torch(cin, cout, dims):
+    b, d, h, w = dims
+    x = seeded((b, cin, d, h, w), 5)
+    wt = seeded((cin, cout, 3, 3, 3), 6, -0.2, 0.2)
+    ref = F.conv_transpose3d(x, wt, stride=2, padding=1, output_padding=1)
+    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.DECONV_S2)
+    close(ncdhw(out), ref, 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(64, 32, 1), (32, 32, 1), (32, 64, 2), (64, 64, 2), (64, 64, 1)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_convbn3d_golden(golden, cin, cout, stride, mode):
+    g = golden("g3_convbn3d")
+    tag = f"cb{cin}_{cout}_{stride}_{mode}"
+    unit = load_procedural(psmnet_3.convbn_3d(cin, cout, 3, stride, 1), f"g3.cb{cin}_{cout}_{stride}.").to(DEV)
+    unit.train(mode == "train")
+    x = seeded((2, cin, 4, 6, 8), 310 + cin + cout + stride)
+    xg = cl(x).requires_grad_(mode == "train")
+    agg3d.set_backend("hip")
+    if mode == "eval":
+        with torch.no_grad():
+            y = agg3d.conv_bn(xg, unit)
+        close(ncdhw(y), g[tag + "_y"], 1e-4, 2e-5)
+        return
+    y = agg3d.conv_bn(xg, unit)
+    close(ncdhw(y), g[tag + "_y"], 1e-4, 5e-5)
+    ct = seeded(tuple(g[tag + "_y"].shape), 320)
+    y.backward(cl(ct))
+    close(ncdhw(xg.grad), g[tag + "_gx"], 1e-3, 1e-4)
+    close(unit[0].weight.grad[:8, :8], g[tag + "_gw"], 1e-3, 2e-4)
+    close(unit[1].weight.grad, g[tag + "_gg"], 1e-3, 1e-3)
+    close(unit[1].bias.grad, g[tag + "_gb"], 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True), (False, True)])
+def test_convbn_residual_relu_train_vs_oracle(relu, with_res):
+    torch.manual_seed(3)
+    ref_unit = load_procedural(po._cb3(32, 32, 1), "t.cb.")
+    unit = load_procedural(psmnet_3.convbn_3d(32, 32, 3, 1, 1), "t.cb.").to(DEV)
+    x, res = seeded((2, 32, 5, 6, 18), 11), seeded((2, 32, 5, 6, 18), 12)
+    ct = seeded((2, 32, 5, 6, 18), 13)
+    xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
+    yr = ref_unit(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(ct)
+    xg, rg = cl(x).requires_grad_(), cl(res).requires_grad_()
+    y = agg3d.conv_bn(xg, unit, relu=relu, add=rg if with_res else None)
+    close(ncdhw(y), yr, 1e-4, 5e-5)
+    y.backward(cl(ct))
+    close(ncdhw(xg.grad), xr.grad, 1e-3, 1e-4)
+    if with_res:
+        close(ncdhw(rg.grad), rr.grad, 1e-5, 1e-6)
+    close(unit[0].weight.grad, ref_unit[0].weight.grad, 1e-3, 3e-4)
+    close(unit[1].weight.grad, ref_unit[1].weight.grad, 1e-3, 1e-3)
+    close(unit[1].bias.grad, ref_unit[1].bias.grad, 1e-3, 1e-3)
+    close(unit[1].running_mean, ref_unit[1].running_mean, 1e-5, 1e-6)
+    close(unit[1].running_var, ref_unit[1].running_var, 1e-5, 1e-6)
+    assert int(unit[1].num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32)])
+def test_deconvbn_train_vs_oracle(cin, cout):
+    ref_unit = load_procedural(po._up3(cin, cout), "t.up.")
+    unit = load_procedural(psmnet_3._up_unit(cin, cout), "t.up.").to(DEV)
+    x, res = seeded((2, cin, 3, 4, 10), 21), seeded((2, cout, 6, 8, 20), 22)
+    ct = seeded((2, cout, 6, 8, 20), 23)
+    xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
+    yr = F.relu(ref_unit(xr) + rr)
+    yr.backward(ct)
+    xg, rg = cl(x).requires_grad_(), cl(res).requires_grad_()
+    y = agg3d.deconv_bn(xg, unit, relu=True, add=rg)
+    close(ncdhw(y), yr, 1e-4, 5e-5)
+    y.backward(cl(ct))
+    close(ncdhw(xg.grad), xr.grad, 1e-3, 1e-4)
+    close(ncdhw(rg.grad), rr.grad, 1e-5, 1e-6)
+    close(unit[0].weight.grad, ref_unit[0].weight.grad, 1e-3, 3e-4)
+    close(unit[1].weight.grad, ref_unit[1].weight.grad, 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("skips", [False, True])
+def test_hourglass_golden(golden, mode, skips):
+    g = golden("g3_hourglass")
+    hg = load_procedural(psmnet_3.hourglass(32), "g3.hg.").to(DEV)
+    hg.train(mode == "train")
+    x = cl(seeded((1, 32, 8, 8, 12), 301)).requires_grad_(mode == "train")
+    pre, post = cl(seeded((1, 64, 4, 4, 6), 302)), cl(seeded((1, 64, 4, 4, 6), 303))
+    tag = f"{mode}_{'skip' if skips else 'noskip'}"
+    agg3d.set_backend("hip")
+    if mode == "eval":
+        with torch.no_grad():
+            o, p, q = hg(x, pre if skips else None, post if skips else None)
+    else:
+        o, p, q = hg(x, pre if skips else None, post if skips else None)
+    close(ncdhw(o), g[tag + "_out"], 1e-3, 1e-4)
+    close(ncdhw(p), g[tag + "_pre"], 1e-3, 1e-4)
+    close(ncdhw(q), g[tag + "_post"], 1e-3, 1e-4)
+    if mode == "train":
+        ((o * cl(seeded((1, 32, 8, 8, 12), 304))).sum() + p.sum() * 0.25 + q.sum() * 0.5).backward()
+        close(ncdhw(x.grad), g[tag + "_gx"], 2e-3, 2e-4)
+        close(hg.conv1[0][0].weight.grad[:8, :8], g[tag + "_gw_conv1"], 2e-3, 5e-4)
+        close(hg.conv5[0].weight.grad[:8, :8], g[tag + "_gw_conv5"], 2e-3, 5e-4)
+        close(hg.conv6[0].weight.grad[:8, :8], g[tag + "_gw_conv6"], 2e-3, 5e-4)
+        close(hg.conv2[1].weight.grad, g[tag + "_ggamma_conv2"], 2e-3, 2e-3)
+        close(hg.conv6[1].bias.grad, g[tag + "_gbeta_conv6"], 2e-3, 2e-3)
+        close(hg.conv1[0][1].running_mean, g[tag + "_rm_conv1"], 1e-4, 1e-5)
+        close(hg.conv1[0][1].running_var, g[tag + "_rv_conv1"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("dims", [(1, 3, 5, 7), (2, 6, 17, 40), (1, 4, 8, 33)])
+def test_classifier_conv_vs_torch(dims):
+    b, d, h, w = dims
+    x = seeded((b, 32, d, h, w), 31)
+    wt = seeded((1, 32, 3, 3, 3), 32, -0.3, 0.3)
+    addend = seeded((b, d, h, w), 33)
+    ct = seeded((b, d, h, w), 34)
+    xr, wr, ar = x.clone().requires_grad_(), wt.clone().requires_grad_(), addend.clone().requires_grad_()
+    yr = F.conv3d(xr, wr, padding=1)[:, 0] + ar
+    yr.backward(ct)
+    conv = torch.nn.Conv3d(32, 1, 3, padding=1, bias=False).to(DEV)
+    conv.weight.data.copy_(wt)
+    xg, ag = cl(x).requires_grad_(), addend.to(DEV).requires_grad_()
+    y = conv3d.conv_logits(xg, conv, ag)
+    close(y, yr, 1e-4, 2e-5)
+    y.backward(ct.to(DEV))
+    close(ncdhw(xg.grad), xr.grad, 1e-4, 2e-5)
+    close(conv.weight.grad, wr.grad, 1e-3, 2e-4)
+    close(ag.grad, ar.grad, 0, 0)
+    y2 = conv3d.conv_logits(xg, conv, None)
+    close(y2, F.conv3d(x, wt, padding=1)[:, 0], 1e-4, 2e-5)
+
+
+def test_add_and_layout_roundtrip():
+    a, b = seeded((1, 32, 3, 4, 6), 41), seeded((1, 32, 3, 4, 6), 42)
+    y = conv3d.add(cl(a), cl(b))
+    close(ncdhw(y), a + b, 0, 0)
