@@ -29,6 +29,7 @@ import torch.nn.functional as F
 from . import conv3d, ops, profiler
 
 BACKEND = os.environ.get("AZ_AGG3D", "hip")
+FUSE_COST_VOLUME = os.environ.get("AZ_FUSE_COSTVOL", "1") != "0"
 
 
 def set_backend(name):
@@ -51,6 +52,10 @@ def volume_from_features(feat_l, feat_r, ndisp):
     # features arrive NCHW from the 2-D extractor; the 3-D kernels want channels-last
     fl = feat_l.permute(0, 2, 3, 1).contiguous()
     fr = feat_r.permute(0, 2, 3, 1).contiguous()
+    if not torch.is_grad_enabled() and FUSE_COST_VOLUME:
+        # inference: never materialise the 401 MB/pair volume (reference psmnet_3.py:149-163);
+        # dres0[0] builds its operand from the two feature maps in-kernel
+        return conv3d.LazyCostVolume(fl, fr, ndisp)
     return ops.cost_volume_ndhwc(fl, fr, ndisp)
 
 

@@ -55,8 +55,29 @@ def _conv_flops(b, vox_out, cin, cout, mode):
     return 2.0 * taps * cin * cout * b * vox_out
 
 
+class LazyCostVolume:
+    """The PSMNet concat cost volume as a recipe (left/right NHWC features + number of
+    disparity planes) instead of a [B,d,h,w,64] tensor: the first convolution
+    synthesises its operand on the fly (az_conv3d_fwd, src = 1)."""
+
+    def __init__(self, feat_l_nhwc, feat_r_nhwc, ndisp):
+        self.fl, self.fr, self.ndisp = _chk(feat_l_nhwc, "feat_l"), _chk(feat_r_nhwc, "feat_r"), int(ndisp)
+        if self.fl.shape != self.fr.shape or self.fl.shape[-1] != 32:
+            raise RuntimeError("fused cost volume expects two [B,h,w,32] feature maps")
+
+
 def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=None, relu=False,
                 stats=False, tag="conv3d"):
+    if isinstance(x, LazyCostVolume):
+        if stats or mode != CONV_S1 or cin != 64:
+            raise RuntimeError("the fused cost-volume operand is only wired for the eval-mode dres0[0] conv")
+        b, h, w, _ = x.fl.shape
+        d = x.ndisp
+        out = x.fl.new_empty(b, d, h, w, cout)
+        with profiler.scope(f"{tag}_costvol_m0_{cin}_{cout}", flops=_conv_flops(b, d * h * w, cin, cout, mode)):
+            _call("az_conv3d_fwd", _p(out), _p(x.fl), _p(x.fr), _p(packed), _p(scale), _p(shift),
+                  _p(residual), int(relu), mode, 1, b, cin, cout, d, h, w, _stream())
+        return out
     b, d, h, w, c = _dims(x)
     assert c == cin, (c, cin)
     if mode == CONV_S2 and (d % 2 or h % 2 or w % 2):
@@ -96,7 +117,7 @@ class _ConvBN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, want_grad):
-        x = _chk(x, "x")
+        x = _chk(x, "x")  # (LazyCostVolume never reaches autograd: see conv_bn)
         if residual is not None:
             residual = _chk(residual, "residual")
         training = bn.training or not bn.track_running_stats
@@ -171,6 +192,15 @@ class _ConvBN(torch.autograd.Function):
 
 
 def conv_bn(x, conv, bn, mode, relu=False, residual=None):
+    if isinstance(x, LazyCostVolume):  # inference: BN folded, operand synthesised in-kernel
+        if torch.is_grad_enabled() or bn.training:
+            raise RuntimeError("LazyCostVolume is an inference-only operand")
+        with torch.cuda.device(x.fl.device):
+            packed, cin, cout = _pack_forward(conv.weight, mode)
+            scale, shift = x.fl.new_empty(cout), x.fl.new_empty(cout)
+            _call("az_bn3d_eval_affine", _p(scale), _p(shift), _p(bn.weight.detach()), _p(bn.bias.detach()),
+                  _p(bn.running_mean), _p(bn.running_var), float(bn.eps), cout, _stream())
+            return _run_gather(x, packed, mode, cin, cout, scale, shift, residual, relu)
     return _ConvBN.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, mode, relu,
                          torch.is_grad_enabled())
 

@@ -30,3 +30,16 @@ static inline unsigned az_grid_for(long long work_items, int block) {
     if (g > 256LL * 16) g = 256LL * 16;
     return (unsigned)g;
 }
+
+// Branch-free guarded 16-byte load: the address is forced to `safe` (any valid 16-byte
+// location) and the value to zero when !ok.  Written with scalar selects on purpose --
+// a float4 ?: makes hipcc spill through scratch memory and serialise the loads.
+__device__ __forceinline__ float4 az_ld16_or_zero(const float *base, size_t offset, bool ok) {
+    const float4 t = *reinterpret_cast<const float4 *>(base + (ok ? offset : (size_t)0));
+    float4 r;
+    r.x = ok ? t.x : 0.f;
+    r.y = ok ? t.y : 0.f;
+    r.z = ok ? t.z : 0.f;
+    r.w = ok ? t.w : 0.f;
+    return r;
+}

@@ -50,7 +50,7 @@ struct ConvArgs {
 };
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 conv3d_gather_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32, NR = COUT / 32;
     constexpr int MR = (MODE == 1) ? 1 : 2;
@@ -91,66 +91,114 @@ conv3d_gather_kernel(const ConvArgs a) {
     const int rty = row >> 3, rtx = row & 7;
     const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
 
-    for (int sd = 0; sd < nd; ++sd) {
-        const int kd = (MODE == 2) ? (pd ? 2 - 2 * sd : 1) : sd;
-        const int id = (MODE == 0) ? td - 1 + sd : (MODE == 1) ? 2 * td - 1 + sd
-                                                               : td + (pd ? sd : 0);
-        if (id < 0 || id >= a.Di) continue;  // wave-uniform: a zero-padding plane
-        for (int cc = 0; cc < NCH; ++cc) {
-            __syncthreads();  // previous slab fully consumed (single-wave group: fence only)
-            // ---- stage the slab: SY*SX voxels x 8 float4 ---------------------------
-            for (int q = lane; q < SY * SX * 8; q += 64) {
-                const int v = q >> 3, part = q & 7;
-                const int sy = v / SX, sx = v - sy * SX;
-                const int ih = ih0 + sy, iw = iw0 + sx;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi) {
-                    if (SRC == 0) {
-                        const size_t vox = (((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw;
-                        val = *reinterpret_cast<const float4 *>(a.in + vox * CIN + cc * 32 + part * 4);
-                    } else if (iw >= id) {  // concat cost volume: plane id = disparity index
-                        const size_t rowb = ((size_t)b * a.Hi + ih) * a.Wi;
-                        const float *src = (cc == 0) ? a.in + (rowb + iw) * 32
-                                                     : a.in2 + (rowb + iw - id) * 32;
-                        val = *reinterpret_cast<const float4 *>(src + part * 4);
-                    }
-                }
-                *reinterpret_cast<float4 *>(&slab[v * CV_VS + part * 4]) = val;
+    // ---- software pipeline -------------------------------------------------------------
+    // stage = (input plane sd, 32-channel chunk cc).  The slab of stage s+1 is fetched
+    // into registers (branch-free, all loads in flight together) while the MFMAs of
+    // stage s run; weights are fetched one tap ahead.
+    constexpr int NQ = SY * SX * 8;          // float4 pieces of one slab
+    constexpr int NLD = (NQ + 63) / 64;      // pieces per lane
+    constexpr bool BPIPE = (NR == 1);
+    const int NS = nd * NCH;
+    float4 pre[NLD];
+
+    auto plane_of = [&](int sd) -> int {
+        return (MODE == 0) ? td - 1 + sd : (MODE == 1) ? 2 * td - 1 + sd : td + (pd ? sd : 0);
+    };
+    auto issue = [&](int s) {
+        const int sd = s / NCH, cc = s - sd * NCH;
+        const int id = plane_of(sd);
+        const bool pok = id >= 0 && id < a.Di;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int q = lane + 64 * it;
+            const int v = q >> 3, part = q & 7;
+            const int sy = v / SX, sx = v - sy * SX;
+            const int ih = ih0 + sy, iw = iw0 + sx;
+            bool ok = pok && (q < NQ) && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+            if (SRC == 0) {
+                const size_t vox = (((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw;
+                pre[it] = az_ld16_or_zero(a.in, vox * CIN + cc * 32 + part * 4, ok);
+            } else {  // concat cost volume: plane id = disparity index
+                ok = ok && (iw >= id);
+                const size_t rowb = ((size_t)b * a.Hi + ih) * a.Wi;
+                pre[it] = az_ld16_or_zero((cc == 0) ? a.in : a.in2,
+                                          (rowb + iw - (cc == 0 ? 0 : id)) * 32 + part * 4, ok);
             }
-            __syncthreads();
-            // ---- taps of this plane / chunk -------------------------------------------
-            for (int sh = 0; sh < nh; ++sh) {
-                const int kh = (MODE == 2) ? (ph ? 2 - 2 * sh : 1) : sh;
-                const int eh = (MODE == 2) ? (ph ? sh : 0) : sh;
-                for (int sw = 0; sw < nw; ++sw) {
-                    const int kw = (MODE == 2) ? (pw ? 2 - 2 * sw : 1) : sw;
-                    const int ew = (MODE == 2) ? (pw ? sw : 0) : sw;
-                    const int tap = (kd * 3 + kh) * 3 + kw;
-                    float4 bq[NR][4];
+        }
+    };
+    auto commit = [&]() {
 #pragma unroll
-                    for (int n = 0; n < NR; ++n)
+        for (int it = 0; it < NLD; ++it) {
+            const int q = lane + 64 * it;
+            if (q < NQ) *reinterpret_cast<float4 *>(&slab[(q >> 3) * CV_VS + (q & 7) * 4]) = pre[it];
+        }
+    };
+    auto load_b = [&](auto &bq, int tap, int cc) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            bq[n][j] = wp4[((((size_t)tap * NCH + cc) * NR + n) * 4 + j) * 64 + lane];
+        for (int n = 0; n < NR; ++n)
 #pragma unroll
-                    for (int m = 0; m < MR; ++m) {
-                        const int sy = ((MODE == 1) ? 2 * rty : rty) + eh;
-                        const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew;
-                        const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
-                        float4 aq[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
-#pragma unroll
-                        for (int n = 0; n < NR; ++n)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bq[n][j].x, acc[m][n], 0, 0, 0);
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bq[n][j].y, acc[m][n], 0, 0, 0);
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bq[n][j].z, acc[m][n], 0, 0, 0);
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bq[n][j].w, acc[m][n], 0, 0, 0);
-                            }
-                    }
+            for (int j = 0; j < 4; ++j)
+                bq[n][j] = wp4[((((size_t)tap * NCH + cc) * NR + n) * 4 + j) * 64 + lane];
+    };
+    const int ntaps = nh * nw;
+    auto tap_of = [&](int kd, int t, int &eh, int &ew) -> int {
+        const int sh = t / nw, sw = t - sh * nw;
+        const int kh = (MODE == 2) ? (ph ? 2 - 2 * sh : 1) : sh;
+        const int kw = (MODE == 2) ? (pw ? 2 - 2 * sw : 1) : sw;
+        eh = (MODE == 2) ? (ph ? sh : 0) : sh;
+        ew = (MODE == 2) ? (pw ? sw : 0) : sw;
+        return (kd * 3 + kh) * 3 + kw;
+    };
+
+    issue(0);
+    for (int s = 0; s < NS; ++s) {
+        const int sd = s / NCH, cc = s - sd * NCH;
+        const int kd = (MODE == 2) ? (pd ? 2 - 2 * sd : 1) : sd;
+        const int id = plane_of(sd);
+        __syncthreads();  // previous slab fully consumed (single-wave group: fence only)
+        commit();
+        __syncthreads();
+        float4 bq[NR][4];
+        int eh, ew;
+        load_b(bq, tap_of(kd, 0, eh, ew), cc);
+        if (s + 1 < NS) issue(s + 1);
+        if (id < 0 || id >= a.Di) continue;  // wave-uniform: a zero-padding plane
+        for (int t = 0; t < ntaps; ++t) {
+            tap_of(kd, t, eh, ew);
+            // weights one tap ahead when registers allow (NR == 1); with two N-tiles the
+            // second resident wave hides the L2 latency instead
+            float4 bn[BPIPE ? NR : 1][4];
+            if (BPIPE) {
+                if (t + 1 < ntaps) {
+                    int eh2, ew2;
+                    load_b(bn, tap_of(kd, t + 1, eh2, ew2), cc);
                 }
+            } else if (t > 0) {
+                load_b(bq, tap_of(kd, t, eh, ew), cc);
+            }
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const int sy = ((MODE == 1) ? 2 * rty : rty) + eh;
+                const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew;
+                const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
+                float4 aq[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bq[n][j].x, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bq[n][j].y, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bq[n][j].z, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bq[n][j].w, acc[m][n], 0, 0, 0);
+                    }
+            }
+            if (BPIPE && t + 1 < ntaps) {
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bq[n][j] = bn[n][j];
             }
         }
     }

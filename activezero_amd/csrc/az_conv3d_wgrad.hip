@@ -6,6 +6,9 @@
 // (coarse, fine) = (input, grad_out) for ConvTranspose3d stride 2 (G = dW[ci][co][k],
 // reference psmnet_3.py:34-58) -- both are PyTorch's native weight layouts.
 //
+// (Staging is software-pipelined: the next row's operands are fetched branch-free into
+// registers while the current row's 144 MFMAs run; the three fine rows form a rolling
+// window in LDS, slot = row mod 3, so each fine row is fetched once per kd.)
 // GEMM view: M = 32 coarse channels, N = 32 fine channels, K = positions, one
 // 32x32 accumulator per tap.  A wavefront (= workgroup) keeps the 9 taps of ONE kd
 // (144 accumulator registers) and walks a strided list of (b, plane, row-segment,
@@ -29,13 +32,16 @@ struct WgArgs {
 };
 
 template <int CM, int CN, int S>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 conv3d_wgrad_kernel(const WgArgs a) {
     constexpr int WCH = (S == 1) ? 32 : 16;  // coarse positions per chunk
     constexpr int FW = S * (WCH - 1) + 3;    // fine positions per staged row
     constexpr int MT = CM / 32, NT = CN / 32, NCOMBO = 3 * MT * NT;
-    __shared__ float sa[WCH * 32];
-    __shared__ float sf[3 * FW * 32];
+    constexpr int NEW = S;                   // fine rows that enter the 3-row window per step
+    constexpr int NLA = WCH * 8 / 64;        // float4 pieces per lane: coarse row chunk
+    constexpr int NQF = NEW * FW * 8, NLF = (NQF + 63) / 64;  // ... new fine rows
+    __shared__ __attribute__((aligned(16))) float sa[WCH * 32];
+    __shared__ __attribute__((aligned(16))) float sf[3 * FW * 32];  // row fh lives in slot fh mod 3
 
     const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
     int combo = blockIdx.x % NCOMBO;
@@ -50,6 +56,7 @@ conv3d_wgrad_kernel(const WgArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long item = widx; item < a.nitems; item += a.waves_per_combo) {
         long long r = item;
         const int wc = (int)(r % a.nwchunk); r /= a.nwchunk;
@@ -57,45 +64,79 @@ conv3d_wgrad_kernel(const WgArgs a) {
         const int cd = (int)(r % a.Dc);
         const int b = (int)(r / a.Dc);
         const int fd = S * cd - 1 + kd;
-        if (fd < 0 || fd >= a.Df) continue;
+        if (fd < 0 || fd >= a.Df) continue;  // wave-uniform
         const int cw0 = wc * WCH, fw0 = S * cw0 - 1;
-        const int h_end = min((hs + 1) * a.hseg_rows, a.Hc);
-        for (int ch = hs * a.hseg_rows; ch < h_end; ++ch) {
-            __syncthreads();
-            // coarse chunk: WCH positions x 32 channels of M-tile mt
-            for (int q = lane; q < WCH * 8; q += 64) {
-                const int pos = q >> 3, part = q & 7;
+        const int h_beg = hs * a.hseg_rows, h_end = min((hs + 1) * a.hseg_rows, a.Hc);
+        const float *cbase = a.coarse + (((size_t)b * a.Dc + cd) * a.Hc) * a.Wc * CM + mt * 32;
+        const float *fbase = a.fine + (((size_t)b * a.Df + fd) * a.Hf) * a.Wf * CN + nt * 32;
+
+        float4 pa[NLA], pf[NLF];
+        // fetch (branch-free) what step `ch` adds: its coarse row chunk and its NEW newest fine rows
+        auto issue = [&](int ch) {
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                const int q = lane + 64 * it, pos = q >> 3, part = q & 7;
                 const int cw = cw0 + pos;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cw < a.Wc)
-                    v = *reinterpret_cast<const float4 *>(
-                        a.coarse + ((((size_t)b * a.Dc + cd) * a.Hc + ch) * a.Wc + cw) * CM + mt * 32 + part * 4);
-                *reinterpret_cast<float4 *>(&sa[pos * 32 + part * 4]) = v;
+                const bool ok = cw < a.Wc;
+                pa[it] = az_ld16_or_zero(cbase, ((size_t)ch * a.Wc + cw) * CM + part * 4, ok);
             }
-            // three fine rows x FW positions x 32 channels of N-tile nt
-            for (int q = lane; q < 3 * FW * 8; q += 64) {
-                const int part = q & 7;
-                const int p = q >> 3;
-                const int kh = p / FW, lw = p - kh * FW;
-                const int fh = S * ch - 1 + kh, fw = fw0 + lw;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf)
-                    v = *reinterpret_cast<const float4 *>(
-                        a.fine + ((((size_t)b * a.Df + fd) * a.Hf + fh) * a.Wf + fw) * CN + nt * 32 + part * 4);
-                *reinterpret_cast<float4 *>(&sf[p * 32 + part * 4]) = v;
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                const int q = lane + 64 * it, part = q & 7, p = q >> 3;
+                const int rr = p / FW, lw = p - rr * FW;
+                const int fh = S * ch + 2 - NEW + rr, fw = fw0 + lw;
+                const bool ok = (q < NQF) && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
+                pf[it] = az_ld16_or_zero(fbase, ((size_t)fh * a.Wf + fw) * CN + part * 4, ok);
             }
+        };
+        auto commit = [&](int ch) {
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                const int q = lane + 64 * it;
+                *reinterpret_cast<float4 *>(&sa[(q >> 3) * 32 + (q & 7) * 4]) = pa[it];
+            }
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                const int q = lane + 64 * it, part = q & 7, p = q >> 3;
+                const int rr = p / FW, lw = p - rr * FW;
+                const int fh = S * ch + 2 - NEW + rr;
+                const int slot = (fh + 3) % 3;
+                if (q < NQF) *reinterpret_cast<float4 *>(&sf[(slot * FW + lw) * 32 + part * 4]) = pf[it];
+            }
+        };
+
+        __syncthreads();
+        // prologue: the rows of the first window that `issue` does not bring in
+        for (int q = lane; q < (3 - NEW) * FW * 8; q += 64) {
+            const int part = q & 7, p = q >> 3;
+            const int rr = p / FW, lw = p - rr * FW;
+            const int fh = S * h_beg - 1 + rr, fw = fw0 + lw;
+            float4 v = zero4;
+            if (fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf)
+                v = *reinterpret_cast<const float4 *>(fbase + ((size_t)fh * a.Wf + fw) * CN + part * 4);
+            *reinterpret_cast<float4 *>(&sf[(((fh + 3) % 3) * FW + lw) * 32 + part * 4]) = v;
+        }
+        issue(h_beg);
+        for (int ch = h_beg; ch < h_end; ++ch) {
+            __syncthreads();  // MFMAs of the previous row have read their operands
+            commit(ch);
             __syncthreads();
+            if (ch + 1 < h_end) issue(ch + 1);  // in flight under this row's 144 MFMAs
+            const int s0 = (S * ch - 1 + 3) % 3;  // slot of kh = 0; kh = 1, 2 follow cyclically
+            const float *f0 = &sf[s0 * FW * 32 + row];
+            const float *f1 = &sf[((s0 + 1) % 3) * FW * 32 + row];
+            const float *f2 = &sf[((s0 + 2) % 3) * FW * 32 + row];
 #pragma unroll 4
             for (int q = 0; q < WCH / 2; ++q) {
                 const int pos = 2 * q + half;
                 const float av = sa[pos * 32 + row];
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const float bv = sf[(kh * FW + S * pos + kw) * 32 + row];
-                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * 3 + kw], 0, 0, 0);
-                    }
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int o = (S * pos + kw) * 32;
+                    acc[0 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f0[o], acc[0 + kw], 0, 0, 0);
+                    acc[3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f1[o], acc[3 + kw], 0, 0, 0);
+                    acc[6 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f2[o], acc[6 + kw], 0, 0, 0);
+                }
             }
         }
     }

@@ -23,7 +23,6 @@ import sys
 import time
 
 import torch
-import torch.distributed as dist
 import torch.nn.functional as F
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -101,17 +100,16 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    from activezero_amd import dist as azdist
+
+    rank, local_rank, world = azdist.env_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", init_method="env://")  # RCCL on ROCm
+    azdist.init("nccl")  # RCCL on ROCm
 
     from activezero_amd import agg3d, profiler
     from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
@@ -119,11 +117,9 @@ def main():
     torch.manual_seed(1)  # configs/config.py:100
     model = PSMNet(args.maxdisp).to(device).train()
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[local_rank], bucket_cap_mb=32, gradient_as_bucket_view=True)
-    il, ir, gt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device, 1234 + rank)
+    net = azdist.wrap(model, device)
+    il, ir, gt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device,
+                             azdist.rank_seed(1234, rank))
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -132,10 +128,7 @@ def main():
         opt.step()
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    fence = azdist.fence
 
     for _ in range(args.warmup):
         step()
@@ -147,10 +140,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = profiler.stop()
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = t.item()
+    dt = azdist.max_over_ranks(dt, device)
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -172,8 +162,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    azdist.shutdown()
 
 
 if __name__ == "__main__":

@@ -193,3 +193,25 @@ def test_add_and_layout_roundtrip():
     a, b = seeded((1, 32, 3, 4, 6), 41), seeded((1, 32, 3, 4, 6), 42)
     y = conv3d.add(cl(a), cl(b))
     close(ncdhw(y), a + b, 0, 0)
+
+
+def test_fused_cost_volume_conv_equals_materialised():
+    """dres0[0] in eval mode: operand synthesised in-kernel (src=1) vs the materialised
+    NDHWC volume (K3) through the same MFMA kernel -- must agree bit for bit; and both
+    against the oracle's conv on the oracle's volume."""
+    b, h, w, nd = 2, 10, 40, 12
+    fl, fr = seeded((b, 32, h, w), 51), seeded((b, 32, h, w), 52)
+    unit = load_procedural(psmnet_3.convbn_3d(64, 32, 3, 1, 1), "t.d0.").to(DEV).eval()
+    ref_unit = load_procedural(po._cb3(64, 32, 1), "t.d0.").eval()
+    with torch.no_grad():
+        ref = F.relu(ref_unit(po.build_cost_volume(fl, fr, nd)))
+        agg3d.FUSE_COST_VOLUME = True
+        lazy = agg3d.volume_from_features(fl.to(DEV), fr.to(DEV), nd)
+        assert isinstance(lazy, conv3d.LazyCostVolume)
+        y_fused = agg3d.conv_bn(lazy, unit, relu=True)
+        agg3d.FUSE_COST_VOLUME = False
+        vol = agg3d.volume_from_features(fl.to(DEV), fr.to(DEV), nd)
+        y_mat = agg3d.conv_bn(vol, unit, relu=True)
+        agg3d.FUSE_COST_VOLUME = True
+    assert torch.equal(y_fused, y_mat)
+    close(ncdhw(y_fused), ref, 1e-4, 2e-5)
