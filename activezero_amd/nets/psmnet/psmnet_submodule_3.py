@@ -71,6 +71,35 @@ class DisparityRegression(nn.Module):
 
 
 _SPP_WINDOWS = ((1, 64), (2, 32), (3, 16), (4, 8))
+_INTERP_CACHE = {}
+
+
+def _interp_matrix(n_in, n_out, device):
+    """[n_out, n_in] matrix of 1-D linear interpolation with align_corners=True."""
+    key = (n_in, n_out, str(device))
+    m = _INTERP_CACHE.get(key)
+    if m is None:
+        # fp32 source positions exactly as ATen computes them: scale = (in-1)/(out-1), src = scale*dst
+        scale = torch.tensor((n_in - 1) / (n_out - 1) if n_out > 1 else 0.0, dtype=torch.float32)
+        pos = scale * torch.arange(n_out, dtype=torch.float32)
+        i0 = pos.floor().clamp(0, n_in - 1).long()
+        i1 = (i0 + 1).clamp(max=n_in - 1)
+        frac = pos - i0.to(torch.float32)
+        m = torch.zeros(n_out, n_in, dtype=torch.float32)
+        rows = torch.arange(n_out)
+        m[rows, i0] += 1.0 - frac
+        m[rows, i1] += frac
+        m = _INTERP_CACHE[key] = m.to(torch.float32).to(device)
+    return m
+
+
+def upsample_bilinear_ac(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=True) for the tiny SPP maps,
+    written as two dense products out = Wy @ x @ Wx^T.  Same linear map; its backward is
+    two GEMMs as well, instead of ATen's atomics kernel (2.5 ms per call at 136x240)."""
+    wy = _interp_matrix(x.shape[-2], size[0], x.device)
+    wx = _interp_matrix(x.shape[-1], size[1], x.device)
+    return torch.matmul(wy, torch.matmul(x, wx.t()))
 
 
 class FeatureExtraction(nn.Module):
@@ -111,8 +140,7 @@ class FeatureExtraction(nn.Module):
         raw = self.layer2(self.layer1(self.firstconv(x)))
         skip = self.layer4(self.layer3(raw))
         size = skip.shape[-2:]
-        pyramid = [F.interpolate(getattr(self, f"branch{i}")(skip), size, mode="bilinear",
-                                 align_corners=True) for i in (4, 3, 2, 1)]
+        pyramid = [upsample_bilinear_ac(getattr(self, f"branch{i}")(skip), size) for i in (4, 3, 2, 1)]
         return self.lastconv(torch.cat([raw, skip] + pyramid, 1))
 
     def forward(self, x):

@@ -41,7 +41,11 @@ def parse():
     ap.add_argument("--width", type=int, default=W_IMG)
     ap.add_argument("--maxdisp", type=int, default=MAXDISP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", choices=["full", "crop"], default="full")
+    ap.add_argument("--backend", choices=["hip", "miopen"], default=None,
+                    help="3-D aggregation backend (miopen = PyTorch-eager A/B baseline)")
+    ap.add_argument("--fe-channels-last", action="store_true",
+                    help="experiment: run the 2-D feature extractor in channels_last memory format")
+    ap.add_argument("--cpu-sample", choices=["full", "crop"], default="crop")
     return ap.parse_args()
 
 
@@ -75,17 +79,27 @@ def disp_loss(preds, gt, maxdisp):
 
 def cpu_baseline(args):
     """The oracle (CPU restatement of the reference's eager op sequence) timed on this
-    box's host cores on a bounded sample of the same workload: ONE pair, fwd+bwd."""
+    box's host cores on a BOUNDED sample of the same workload: one pair, fwd+loss+bwd, on
+    the reference's own training crop (256x512, configs/config.py:9-10) at the full D=192,
+    scaled to the metric's 544x960 pairs by the pixel ratio (every stage of the path is
+    linear in H*W).  A full-size pair takes > 6 min on 16 cores, too long for a default run
+    (use --cpu-sample full to time it anyway)."""
     from oracle import psmnet_oracle as po
 
-    cores = len(os.sched_getaffinity(0))
+    # the GPU box exposes every host CPU (256) but one GPU's share is 16 cores; more
+    # threads than that only oversubscribes the node (measured: 425 s instead of ~10 s)
+    cores = int(os.environ.get("AZ_CPU_THREADS", min(16, len(os.sched_getaffinity(0)))))
     torch.set_num_threads(cores)
+    md = args.maxdisp
+    hp = args.height + (-args.height) % 32
     if args.cpu_sample == "full":
-        h, w, md = args.height, args.width, args.maxdisp
-        sample = f"1 pair {h}x{w} (padded to {h + (-h) % 32}), D={md}, fwd+bwd+loss, 1 step"
+        h, w, scale = args.height, args.width, 1.0
+        sample = f"1 pair {h}x{w} (padded to {hp}), D={md}, fwd+loss+bwd, 1 step, unscaled"
     else:
-        h, w, md = 256, 512, args.maxdisp
-        sample = f"1 pair 256x512 crop, D={md}, fwd+bwd+loss, 1 step (NOT full size)"
+        h, w = 256, 512
+        scale = (hp * args.width) / float(h * w)
+        sample = (f"1 pair 256x512 crop, D={md}, fwd+loss+bwd, 1 step; seconds x {scale:.3f} "
+                  f"(= {hp}x{args.width} / 256x512 pixels) -> pairs/s at full size")
     torch.manual_seed(1)
     model = po.PSMNetOracle(md, 3).train()
     il, ir, gt = synth_batch(1, h, w, md, "cpu", 99)
@@ -94,8 +108,8 @@ def cpu_baseline(args):
     loss = po.psmnet_disp_loss(preds, gt, po.disparity_mask(gt, md))
     loss.backward()
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": sample, "seconds": dt}
+    return {"value": 1.0 / (dt * scale), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": sample, "sample_seconds": dt}
 
 
 def main():
@@ -114,12 +128,18 @@ def main():
     from activezero_amd import agg3d, profiler
     from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
 
+    if args.backend:
+        agg3d.set_backend(args.backend)
     torch.manual_seed(1)  # configs/config.py:100
     model = PSMNet(args.maxdisp).to(device).train()
+    if args.fe_channels_last:
+        model.feature_extraction.to(memory_format=torch.channels_last)
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
     net = azdist.wrap(model, device)
     il, ir, gt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device,
                              azdist.rank_seed(1234, rank))
+    if args.fe_channels_last:
+        il, ir = (t.contiguous(memory_format=torch.channels_last) for t in (il, ir))
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -130,9 +150,15 @@ def main():
 
     fence = azdist.fence
 
+    def note(msg):  # progress on stderr (the JSON line is the only stdout output)
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model ready, {args.warmup} warm-up steps")
     for _ in range(args.warmup):
         step()
     fence()
+    note(f"timing {args.steps} steps")
     profiler.start()  # HIP events around the dominant kernel, on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,6 +186,7 @@ def main():
             "cpu_baseline": None,
         }
         if not args.no_cpu_baseline and world == 1:
+            note(f"{1e3 * dt / args.steps:.1f} ms/step; timing the CPU baseline sample ({args.cpu_sample})")
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     azdist.shutdown()
