@@ -12,5 +12,6 @@ class PSMNet(_p3.PSMNet):
     _feature_module = _sub6
 
     def forward(self, img_L, img_R, img_L_transformed, img_R_transformed):
-        return self._from_features(self.feature_extraction(img_L, img_L_transformed),
-                                   self.feature_extraction(img_R, img_R_transformed))
+        n = self._nhwc
+        return self._from_features(self.feature_extraction(n(img_L), n(img_L_transformed)),
+                                   self.feature_extraction(n(img_R), n(img_R_transformed)))

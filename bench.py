@@ -43,8 +43,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["hip", "miopen"], default=None,
                     help="3-D aggregation backend (miopen = PyTorch-eager A/B baseline)")
-    ap.add_argument("--fe-channels-last", action="store_true",
-                    help="experiment: run the 2-D feature extractor in channels_last memory format")
     ap.add_argument("--cpu-sample", choices=["full", "crop"], default="crop")
     return ap.parse_args()
 
@@ -132,14 +130,10 @@ def main():
         agg3d.set_backend(args.backend)
     torch.manual_seed(1)  # configs/config.py:100
     model = PSMNet(args.maxdisp).to(device).train()
-    if args.fe_channels_last:
-        model.feature_extraction.to(memory_format=torch.channels_last)
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
     net = azdist.wrap(model, device)
     il, ir, gt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device,
                              azdist.rank_seed(1234, rank))
-    if args.fe_channels_last:
-        il, ir = (t.contiguous(memory_format=torch.channels_last) for t in (il, ir))
 
     def step():
         opt.zero_grad(set_to_none=True)
