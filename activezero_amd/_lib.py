@@ -47,6 +47,12 @@ _SIGS = {
     "az_bn3d_bwd_workspace": [_LL, _INT],
     "az_bn3d_bwd": [_PTR] * 6 + [_LL] + [_PTR] * 6 + [_INT, _LL, _INT, _PTR],
     "az_add_relu": [_PTR] * 3 + [_INT, _LL, _PTR],
+    "az_corr1d_volume": [_PTR] * 3 + [_INT] * 5 + [_PTR],
+    "az_corr1d_volume_bwd": [_PTR] * 5 + [_INT] * 5 + [_PTR],
+    "az_corr1d_pool": [_PTR, _PTR, _LL, _INT, _PTR],
+    "az_corr1d_pool_bwd": [_PTR, _PTR, _LL, _INT, _PTR],
+    "az_corr1d_lookup_fwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
+    "az_corr1d_lookup_bwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
 }
 _RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL}

@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--backend", choices=["hip", "miopen"], default=None,
                     help="3-D aggregation backend (miopen = PyTorch-eager A/B baseline)")
     ap.add_argument("--cpu-sample", choices=["full", "crop"], default="crop")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --single-device)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -119,9 +123,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    azdist.init("nccl")  # RCCL on ROCm
+    azdist.init(args.dist_backend)  # "nccl" = RCCL on ROCm
 
     from activezero_amd import agg3d, profiler
     from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
@@ -176,6 +182,7 @@ def main():
                        "width": args.width, "maxdisp": args.maxdisp,
                        "parallelism": f"dp{world}", "agg3d_backend": agg3d.BACKEND},
             "loss": float(loss.item()),
+            "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
             "roofline": profiler.roofline(prof),
             "cpu_baseline": None,
         }

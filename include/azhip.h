@@ -187,6 +187,30 @@ int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *co
 /* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175 */
 int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, void *stream);
 
+/* ---- K10/K11: RAFT-Stereo 1-D correlation (secondary path) -----------------------
+ * replaces nets/raft/corr.py:115-161 (CorrBlock1D: einsum all-pairs correlation /
+ * sqrt(C), avg_pool pyramid over the last axis, 2r+1-tap linear lookup through
+ * nets/raft/raft_utils.py:68-82 bilinear_sampler, align_corners=True, zero padding).
+ * f1: [B,C,H,W1], f2: [B,C,H,W2] (NCHW); corr: [B,H,W1,W2]. */
+int az_corr1d_volume(float *corr, const float *f1, const float *f2, int B, int C, int H, int W1,
+                     int W2, void *stream);
+/* grad_f1 / grad_f2 may be NULL */
+int az_corr1d_volume_bwd(float *grad_f1, float *grad_f2, const float *grad_corr, const float *f1,
+                         const float *f2, int B, int C, int H, int W1, int W2, void *stream);
+/* one pyramid step: dst[rows][Wsrc/2] = mean of neighbouring pairs of src[rows][Wsrc] */
+int az_corr1d_pool(float *dst, const float *src, long long rows, int Wsrc, void *stream);
+int az_corr1d_pool_bwd(float *grad_src, const float *grad_dst, long long rows, int Wsrc,
+                       void *stream);
+/* out[b, ch_offset + k, h, w1] = lerp(pyr_level[b,h,w1,:], coords[b,0,h,w1] / 2^level + k - radius),
+ * k = 0..2*radius; out is [B,ch_total,H,W1]; coords is [B,2,H,W1] (channel 0 used). */
+int az_corr1d_lookup_fwd(float *out, const float *pyr_level, const float *coords, int B, int H,
+                         int W1, int W_level, int radius, int level, int ch_offset, int ch_total,
+                         void *stream);
+/* grad_pyr_level [B,H,W1,W_level] is overwritten (zero-filled first) */
+int az_corr1d_lookup_bwd(float *grad_pyr_level, const float *grad_out, const float *coords, int B,
+                         int H, int W1, int W_level, int radius, int level, int ch_offset,
+                         int ch_total, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
