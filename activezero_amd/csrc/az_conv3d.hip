@@ -29,11 +29,14 @@
 // train-mode BatchNorm (merged with Chan's formula in fp64 by az_bn3d_finalize).
 // SRC 1 synthesises the PSMNet concat cost volume on the fly from the two NHWC
 // feature maps (reference psmnet_3.py:149-163) instead of reading a 64-channel tensor.
+#include <stdlib.h>
+
 #include "az_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CV_VS 36  // slab voxel stride in dwords
+#define CV_BAND 4 // tile rows per band of the block -> tile order
 
 struct ConvArgs {
     const float *in;    // NDHWC input (coarse tensor for MODE 2); SRC 1: left features NHWC
@@ -47,6 +50,7 @@ struct ConvArgs {
     int Do, Ho, Wo;     // output dims
     int Dt, tiles_y, tiles_x;  // index-space extents (MODE 2: coarse dims / phase tiles)
     int relu;
+    int map_mode;  // block->tile map: 0 linear, 1 XCD-chunked linear, 2 XCD-chunked + banded
 };
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC>
@@ -60,17 +64,44 @@ conv3d_gather_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float slab[SY * SX * CV_VS];
 
     const int lane = threadIdx.x;
-    int bid = blockIdx.x;
-    const int tile_id = bid;
-    const int tix = bid % a.tiles_x; bid /= a.tiles_x;
-    const int tiy = bid % a.tiles_y; bid /= a.tiles_y;
+    // ---- block -> tile map -------------------------------------------------------------
+    // (1) XCD-aware: blocks b and b+8 share an XCD (and its 4 MB L2); hand every XCD one
+    //     contiguous chunk of the linear tile order instead of every 8th tile.
+    // (2) banded order inside the chunk: x fastest, then CV_BAND tile rows, then the depth
+    //     index, then the band -- so the three output planes that read one input plane
+    //     (and the row halos inside a band) are processed back to back and hit in L2.
+    // Pure performance choice; any map that is a bijection onto the tile set is correct.
+    int lin = blockIdx.x;
+    if (a.map_mode >= 1) {
+        const int nblk = gridDim.x, xcd = blockIdx.x & 7, q8 = nblk >> 3, r8 = nblk & 7;
+        lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    }
     int pd = 0, ph = 0, pw = 0;
     if (MODE == 2) {
-        const int phase = bid & 7; bid >>= 3;
+        const int phase = lin & 7; lin >>= 3;
         pd = phase >> 2; ph = (phase >> 1) & 1; pw = phase & 1;
     }
-    const int td = bid % a.Dt;
-    const int b = bid / a.Dt;
+    const int tix = lin % a.tiles_x; lin /= a.tiles_x;
+    int tiy, td, b;
+    if (a.map_mode >= 2) {
+        // lin indexes (b, band, d, row-in-band); the last band may have fewer rows
+        const int per_b = a.Dt * a.tiles_y;
+        b = lin / per_b;
+        int l = lin - b * per_b;
+        const int full = (a.tiles_y / CV_BAND) * CV_BAND * a.Dt;  // blocks in the complete bands
+        int band, rows;
+        if (l < full) { band = l / (CV_BAND * a.Dt); l -= band * CV_BAND * a.Dt; rows = CV_BAND; }
+        else { band = a.tiles_y / CV_BAND; l -= full; rows = a.tiles_y - band * CV_BAND; }
+        td = l / rows;
+        tiy = band * CV_BAND + (l - td * rows);
+    } else {
+        tiy = lin % a.tiles_y; lin /= a.tiles_y;
+        td = lin % a.Dt;
+        b = lin / a.Dt;
+    }
+    // canonical tile id (rows of the BatchNorm partial buffers)
+    const int tile_id = ((((b * a.Dt + td) * a.tiles_y + tiy) * a.tiles_x + tix) << (MODE == 2 ? 3 : 0)) +
+                        (MODE == 2 ? (pd * 4 + ph * 2 + pw) : 0);
     const int ty0 = tiy * TY, tx0 = tix * TX;  // tile origin in index space
     // input coordinates of slab voxel (0,0)
     const int ih0 = (MODE == 0) ? ty0 - 1 : (MODE == 1) ? 2 * ty0 - 1 : ty0;
@@ -354,9 +385,20 @@ extern "C" int az_conv3d_pack_weights(float *packed, const float *w, int cin, in
     return az_launch_status();
 }
 
+static int conv_map_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("AZ_CONV_MAP");
+        mode = e ? atoi(e) : 2;
+        if (mode < 0 || mode > 3) mode = 2;
+    }
+    return mode;
+}
+
 static int conv_common(ConvArgs &a, int mode, int B, int cin, int Di, int Hi, int Wi, int src) {
     if (mode < 0 || mode > 2 || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return AZ_EINVAL;
     a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi;
+    a.map_mode = conv_map_mode();
     conv_out_dims(mode, Di, Hi, Wi, a.Do, a.Ho, a.Wo);
     conv_tiles(mode, Di, Hi, Wi, a.Dt, a.tiles_y, a.tiles_x);
     (void)cin; (void)src;

@@ -44,8 +44,11 @@ conv3d_wgrad_kernel(const WgArgs a) {
     __shared__ __attribute__((aligned(16))) float sf[3 * FW * 32];  // row fh lives in slot fh mod 3
 
     const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
-    int combo = blockIdx.x % NCOMBO;
-    const int widx = blockIdx.x / NCOMBO;
+    // blocks b and b+8 share an XCD: the NCOMBO waves that walk the SAME work list (same
+    // coarse rows, neighbouring fine planes) are given ids 8 apart so they share one L2.
+    const int grp = blockIdx.x / (8 * NCOMBO), rem = blockIdx.x % (8 * NCOMBO);
+    int combo = rem >> 3;
+    const int widx = grp * 8 + (rem & 7);
     const int nt = combo % NT; combo /= NT;
     const int mt = combo % MT;
     const int kd = combo / MT;
@@ -167,14 +170,14 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
     a.nwchunk = (a.Wc + WCH - 1) / WCH;
     // rows per segment: aim at >= 4 items per wave with ~2048 resident waves
     const int target_waves = 256 * 8;
-    a.waves_per_combo = max(1, target_waves / NCOMBO);
+    a.waves_per_combo = max(8, (target_waves / NCOMBO) & ~7);  // multiple of 8 (XCD grouping)
     const long long base_items = (long long)a.B * a.Dc * a.nwchunk;
     int nhseg = (int)((4LL * a.waves_per_combo + base_items - 1) / base_items);
     nhseg = max(1, min(nhseg, a.Hc));
     a.hseg_rows = (a.Hc + nhseg - 1) / nhseg;
     a.nhseg = (a.Hc + a.hseg_rows - 1) / a.hseg_rows;
     a.nitems = base_items * a.nhseg;
-    if (a.nitems < a.waves_per_combo) a.waves_per_combo = (int)a.nitems;
+    if (a.nitems < a.waves_per_combo) a.waves_per_combo = (int)((a.nitems + 7) & ~7LL);
     hipLaunchKernelGGL((conv3d_wgrad_kernel<CM, CN, S>), dim3(a.waves_per_combo * NCOMBO), dim3(64),
                        0, s, a);
     return az_launch_status();

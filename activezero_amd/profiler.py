@@ -53,7 +53,31 @@ def stop():
     return out
 
 
-def roofline(prof):
+# profiler scope name -> kernel symbol in the rocprofv3 PMC summary
+_PMC_NAMES = {"conv3d_m0_32_32": "conv3d_gather_kernel<32, 32, 0, 1, 0>",
+              "dgrad_m0_32_32": "conv3d_gather_kernel<32, 32, 0, 0, 0>",
+              "conv_wgrad_s1_32_32": "conv3d_wgrad_kernel<32, 32, 1>"}
+
+
+def pmc_traffic(scope_name, per_launch_work, pmc_json):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (tools/kernel_probe.py + tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes,
+    unit-calibrated on a pure streaming kernel).  Only returned when the probe ran the same
+    launch shape (same algorithmic flops per launch); otherwise None."""
+    import json
+    import os
+
+    if not os.path.exists(pmc_json) or scope_name not in _PMC_NAMES:
+        return None
+    data = json.load(open(pmc_json))
+    k = data["kernels"].get(_PMC_NAMES[scope_name])
+    probe_flops = 2.0 * 27 * 32 * 32 * data["tensor_bytes"] / (4 * 32)
+    if not k or abs(probe_flops - per_launch_work) > 1e-6 * probe_flops:
+        return None
+    return k["hbm_bytes"]
+
+
+def roofline(prof, pmc_json=None):
     """roofline object for the kernel with the largest total time in the timed region."""
     if not prof:
         return None
@@ -62,7 +86,9 @@ def roofline(prof):
     work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
     achieved = work / (r["avg_ms"] * 1e-3)
     return {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak, "unit": unit,
-            "frac": achieved / peak, "traffic": None, "avg_launch_ms": r["avg_ms"],
+            "frac": achieved / peak,
+            "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
+            "avg_launch_ms": r["avg_ms"],
             "launches_timed": r["launches"],
             "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
             "others": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]}

@@ -176,14 +176,15 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: PSMNet 540x960 (padded 544x960) D=192 fwd+bwd+Adam, "
-                                   "supervised disparity loss, batch 4 per GPU",
+            "config": {"workload": f"configs[1]: PSMNet {args.height}x{args.width} (padded to "
+                                   f"{args.height + (-args.height) % 32} rows) D={args.maxdisp} fwd+bwd+Adam, "
+                                   f"supervised disparity loss, batch {args.batch} per GPU",
                        "global_batch": args.batch * world, "height": args.height,
                        "width": args.width, "maxdisp": args.maxdisp,
                        "parallelism": f"dp{world}", "agg3d_backend": agg3d.BACKEND},
             "loss": float(loss.item()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
-            "roofline": profiler.roofline(prof),
+            "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "pmc_traffic_b4.json")),
             "cpu_baseline": None,
         }
         if not args.no_cpu_baseline and world == 1:

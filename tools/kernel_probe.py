@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Launch the dominant kernels of the path alone, at bench.py's shapes (B=4, V0 =
+48x136x240, 32 channels), so that rocprofv3 PMC passes can price their HBM traffic:
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir> -o fetch -- python3 tools/kernel_probe.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir> -o write -- python3 tools/kernel_probe.py
+    python tools/pmc_summary.py <dir> --out profiles/<name>
+
+bn_apply (pure float4 streaming, exactly 1 read + 1 write of the tensor) is the
+calibration kernel for the gfx950 FETCH_SIZE/WRITE_SIZE unit corrections
+(MI355X_MICROARCH.md "HBM"): its byte counts are known a priori.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from activezero_amd import conv3d  # noqa: E402
+from activezero_amd.ops import _call, _p, _stream  # noqa: E402
+
+B, D, H, W, C = int(os.environ.get("AZ_PROBE_B", 4)), 48, 136, 240, 32
+REPS = 3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x = torch.randn(B, D, H, W, C, device=dev)
+    g = torch.randn(B, D, H, W, C, device=dev)
+    w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
+    scale, shift = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    for _ in range(REPS):
+        # calibration: y = x*scale + shift  (reads x once, writes y once)
+        _call("az_bn3d_apply", _p(y), _p(x), _p(scale), _p(shift), None, 0, x.numel() // C, C, _stream())
+        pk, cin, cout = conv3d._pack_forward(w, conv3d.CONV_S1)
+        conv3d._run_gather(x, pk, conv3d.CONV_S1, cin, cout, stats=True)        # forward + BN partials
+        conv3d._run_gather(g, conv3d._pack(w, C, C, 27, C * 27, True), conv3d.CONV_S1, C, C, tag="dgrad")
+        conv3d._wgrad(g, x, 1, C, C, "conv")
+        torch.cuda.synchronize()
+    print("probe done", x.numel() * 4 / 1e6, "MB per tensor")
+
+
+if __name__ == "__main__":
+    main()
