@@ -88,7 +88,7 @@ def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=Non
     name = f"{tag}_m{mode}_{cin}_{cout}"
     if stats:
         ntiles = _lib.lib().az_conv3d_num_tiles(mode, b, d, h, w)
-        part = x.new_empty(ntiles, cout, 2)
+        part = x.new_empty(cout, ntiles, 2)
         cnt = x.new_empty(ntiles)
         with profiler.scope(name, flops=flops):
             _call("az_conv3d_fwd_stats", _p(out), _p(part), _p(cnt), _p(x), None, _p(packed), mode, 0,

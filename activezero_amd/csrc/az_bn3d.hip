@@ -28,7 +28,8 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
     for (long long t = threadIdx.x; t < ntiles; t += 256) {
         const double nt = cnt[t];
         if (nt <= 0.0) continue;
-        const double st = part[(t * C + c) * 2 + 0], m2t = part[(t * C + c) * 2 + 1];
+        const float2 pr = *reinterpret_cast<const float2 *>(&part[((long long)c * ntiles + t) * 2]);
+        const double st = pr.x, m2t = pr.y;
         const double mt = st / nt;
         const double tot = n + nt, delta = mt - mean;
         mean += delta * nt / tot;

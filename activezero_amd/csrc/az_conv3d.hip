@@ -44,7 +44,8 @@ struct ConvArgs {
     const float *wp;    // packed weights
     float *out;         // NDHWC output
     const float *scale, *shift, *res;  // EPI 0 (any may be null)
-    float *part;        // EPI 1: [tiles][COUT][2]
+    float *part;        // EPI 1: [COUT][tiles][2] (channel-major: finalize reads it coalesced)
+    long long ntiles;
     float *cnt;         // EPI 1: [tiles]
     int B, Di, Hi, Wi;  // input dims
     int Do, Ho, Wo;     // output dims
@@ -302,8 +303,7 @@ conv3d_gather_kernel(const ConvArgs a) {
             m2 += __shfl_xor(m2, 32);
             if (half == 0) {
                 const int co = n * 32 + row;
-                a.part[((size_t)tile_id * COUT + co) * 2 + 0] = s;
-                a.part[((size_t)tile_id * COUT + co) * 2 + 1] = m2;
+                *reinterpret_cast<float2 *>(&a.part[((size_t)co * a.ntiles + tile_id) * 2]) = make_float2(s, m2);
             }
         }
         if (lane == 0) a.cnt[tile_id] = (float)ntot;
@@ -431,6 +431,7 @@ extern "C" int az_conv3d_fwd_stats(float *out, float *partials, float *counts, c
     ConvArgs a{};
     if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, src)) return e;
     a.in = in; a.in2 = in2; a.wp = packed_w; a.out = out; a.part = partials; a.cnt = counts;
+    a.ntiles = az_conv3d_num_tiles(mode, B, Di, Hi, Wi);
     hipStream_t s = az_stream(stream);
     if (mode == 0) return dispatch_channels<0, 1>(a, cin, cout, src, s);
     if (mode == 1) return dispatch_channels<1, 1>(a, cin, cout, src, s);

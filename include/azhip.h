@@ -140,7 +140,7 @@ int az_conv3d_fwd(float *out, const float *in, const float *in2, const float *pa
                   const float *scale, const float *shift, const float *residual, int relu,
                   int mode, int src, int B, int cin, int cout, int Di, int Hi, int Wi,
                   void *stream);
-/* out = conv(in) (raw) and, per tile and channel, partials[tile][c] = (sum, centred
+/* out = conv(in) (raw) and, per channel and tile, partials[c][tile] = (sum, centred
  * sum of squares), counts[tile] = valid voxels: the train-mode BatchNorm statistics. */
 int az_conv3d_fwd_stats(float *out, float *partials, float *counts, const float *in,
                         const float *in2, const float *packed_w, int mode, int src, int B,
