@@ -140,22 +140,38 @@ conv3d_gather_kernel(const ConvArgs a) {
         const int sd = s / NCH, cc = s - sd * NCH;
         const int id = plane_of(sd);
         const bool pok = id >= 0 && id < a.Di;
+        const int idc = min(max(id, 0), a.Di - 1);
+        bool okv[NLD];
+        // pass 1: every load is issued unconditionally from a clamped (always valid)
+        // address, so all NLD requests are in flight together ...
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int q = lane + 64 * it;
             const int v = q >> 3, part = q & 7;
             const int sy = v / SX, sx = v - sy * SX;
             const int ih = ih0 + sy, iw = iw0 + sx;
-            bool ok = pok && (q < NQ) && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+            const int ihc = min(max(ih, 0), a.Hi - 1), iwc = min(max(iw, 0), a.Wi - 1);
+            bool ok = pok && (q < NQ) && ih == ihc && iw == iwc;
+            const float *src;
             if (SRC == 0) {
-                const size_t vox = (((size_t)b * a.Di + id) * a.Hi + ih) * a.Wi + iw;
-                pre[it] = az_ld16_or_zero(a.in, vox * CIN + cc * 32 + part * 4, ok);
+                const size_t vox = (((size_t)b * a.Di + idc) * a.Hi + ihc) * a.Wi + iwc;
+                src = a.in + vox * CIN + cc * 32 + part * 4;
             } else {  // concat cost volume: plane id = disparity index
                 ok = ok && (iw >= id);
-                const size_t rowb = ((size_t)b * a.Hi + ih) * a.Wi;
-                pre[it] = az_ld16_or_zero((cc == 0) ? a.in : a.in2,
-                                          (rowb + iw - (cc == 0 ? 0 : id)) * 32 + part * 4, ok);
+                const size_t rowb = ((size_t)b * a.Hi + ihc) * a.Wi;
+                const int iwr = (cc == 0) ? iwc : max(iwc - idc, 0);
+                src = ((cc == 0) ? a.in : a.in2) + (rowb + iwr) * 32 + part * 4;
             }
+            pre[it] = *reinterpret_cast<const float4 *>(src);
+            okv[it] = ok;
+        }
+        // pass 2: ... and padding is applied afterwards with scalar selects
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            pre[it].x = okv[it] ? pre[it].x : 0.f;
+            pre[it].y = okv[it] ? pre[it].y : 0.f;
+            pre[it].z = okv[it] ? pre[it].z : 0.f;
+            pre[it].w = okv[it] ? pre[it].w : 0.f;
         }
     };
     auto commit = [&]() {
@@ -195,37 +211,49 @@ conv3d_gather_kernel(const ConvArgs a) {
         load_b(bq, tap_of(kd, 0, eh, ew), cc);
         if (s + 1 < NS) issue(s + 1);
         if (id < 0 || id >= a.Di) continue;  // wave-uniform: a zero-padding plane
+        auto load_a = [&](float4 (&aq)[4], int m, int eh_, int ew_) {
+            const int sy = ((MODE == 1) ? 2 * rty : rty) + eh_;
+            const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew_;
+            const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
+        };
+        auto mfma16 = [&](f32x16 (&c)[NR], const float4 (&aq)[4], const float4 (&bw)[NR][4]) {
+#pragma unroll
+            for (int n = 0; n < NR; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bw[n][j].x, c[n], 0, 0, 0);
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bw[n][j].y, c[n], 0, 0, 0);
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bw[n][j].z, c[n], 0, 0, 0);
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
+                }
+        };
+        // A fragments are read one MFMA block (16*NR instructions) ahead of their use:
+        // tile 1's while tile 0 multiplies, the next tap's tile 0 while tile 1 multiplies.
+        float4 a0[4], a1[4];
+        load_a(a0, 0, eh, ew);
         for (int t = 0; t < ntaps; ++t) {
             tap_of(kd, t, eh, ew);
+            if (MR == 2) load_a(a1, 1, eh, ew);
             // weights one tap ahead when registers allow (NR == 1); with two N-tiles the
             // second resident wave hides the L2 latency instead
             float4 bn[BPIPE ? NR : 1][4];
-            if (BPIPE) {
-                if (t + 1 < ntaps) {
-                    int eh2, ew2;
-                    load_b(bn, tap_of(kd, t + 1, eh2, ew2), cc);
-                }
-            } else if (t > 0) {
-                load_b(bq, tap_of(kd, t, eh, ew), cc);
+            int eh2 = 0, ew2 = 0;
+            if (t + 1 < ntaps) {
+                const int tap2 = tap_of(kd, t + 1, eh2, ew2);
+                if (BPIPE) load_b(bn, tap2, cc);
             }
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                const int sy = ((MODE == 1) ? 2 * rty : rty) + eh;
-                const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew;
-                const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
-                float4 aq[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
-#pragma unroll
-                for (int n = 0; n < NR; ++n)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bq[n][j].x, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bq[n][j].y, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bq[n][j].z, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bq[n][j].w, acc[m][n], 0, 0, 0);
-                    }
-            }
+            if (!BPIPE && t > 0) load_b(bq, tap_of(kd, t, eh, ew), cc);
+            // hipcc otherwise sinks the LDS reads next to their consumers (register pressure)
+            // and every MFMA quad then waits on a just-issued ds_read: pin the written order
+            __builtin_amdgcn_sched_barrier(0);
+            mfma16(acc[0], a0, bq);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < ntaps) load_a(a0, 0, eh2, ew2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MR == 2) mfma16(acc[MR - 1], a1, bq);
+            __builtin_amdgcn_sched_barrier(0);
             if (BPIPE && t + 1 < ntaps) {
 #pragma unroll
                 for (int n = 0; n < NR; ++n)

@@ -76,20 +76,34 @@ conv3d_wgrad_kernel(const WgArgs a) {
         float4 pa[NLA], pf[NLF];
         // fetch (branch-free) what step `ch` adds: its coarse row chunk and its NEW newest fine rows
         auto issue = [&](int ch) {
+            bool oka[NLA], okf[NLF];
+            // all loads first, from clamped (always valid) addresses; padding by select after
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it, pos = q >> 3, part = q & 7;
                 const int cw = cw0 + pos;
-                const bool ok = cw < a.Wc;
-                pa[it] = az_ld16_or_zero(cbase, ((size_t)ch * a.Wc + cw) * CM + part * 4, ok);
+                oka[it] = cw < a.Wc;
+                pa[it] = *reinterpret_cast<const float4 *>(
+                    cbase + ((size_t)ch * a.Wc + min(cw, a.Wc - 1)) * CM + part * 4);
             }
 #pragma unroll
             for (int it = 0; it < NLF; ++it) {
                 const int q = lane + 64 * it, part = q & 7, p = q >> 3;
-                const int rr = p / FW, lw = p - rr * FW;
+                const int rr = min(p / FW, NEW - 1), lw = p - (p / FW) * FW;
                 const int fh = S * ch + 2 - NEW + rr, fw = fw0 + lw;
-                const bool ok = (q < NQF) && fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf;
-                pf[it] = az_ld16_or_zero(fbase, ((size_t)fh * a.Wf + fw) * CN + part * 4, ok);
+                const int fhc = min(max(fh, 0), a.Hf - 1), fwc = min(max(fw, 0), a.Wf - 1);
+                okf[it] = (q < NQF) && fh == fhc && fw == fwc;
+                pf[it] = *reinterpret_cast<const float4 *>(fbase + ((size_t)fhc * a.Wf + fwc) * CN + part * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                pa[it].x = oka[it] ? pa[it].x : 0.f; pa[it].y = oka[it] ? pa[it].y : 0.f;
+                pa[it].z = oka[it] ? pa[it].z : 0.f; pa[it].w = oka[it] ? pa[it].w : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                pf[it].x = okf[it] ? pf[it].x : 0.f; pf[it].y = okf[it] ? pf[it].y : 0.f;
+                pf[it].z = okf[it] ? pf[it].z : 0.f; pf[it].w = okf[it] ? pf[it].w : 0.f;
             }
         };
         auto commit = [&](int ch) {
