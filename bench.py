@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--backend", choices=["hip", "miopen"], default=None,
                     help="3-D aggregation backend (miopen = PyTorch-eager A/B baseline)")
     ap.add_argument("--cpu-sample", choices=["full", "crop"], default="crop")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="do not set torch.backends.cudnn.benchmark (the reference sets it, train.py:38)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --single-device)")
     ap.add_argument("--single-device", action="store_true",
@@ -134,6 +136,9 @@ def main():
 
     if args.backend:
         agg3d.set_backend(args.backend)
+    # the reference enables cudnn.benchmark (train.py:38); on ROCm this is MIOpen's
+    # exhaustive find for the adjacent 2-D convolutions (paid once, during warm-up)
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
     torch.manual_seed(1)  # configs/config.py:100
     model = PSMNet(args.maxdisp).to(device).train()
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
