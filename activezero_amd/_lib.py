@@ -32,10 +32,11 @@ _SIGS = {
     "az_patch_reproj_bwd": [_PTR] * 7 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_patch_reproj_vis": [_PTR] * 3 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
-    "az_conv3d_pack_weights": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _PTR],
+    "az_conv3d_packed_floats": [_INT, _INT, _INT],
+    "az_conv3d_pack_weights": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
     "az_conv3d_num_tiles": [_INT] * 5,
-    "az_conv3d_fwd": [_PTR] * 7 + [_INT] * 9 + [_PTR],
-    "az_conv3d_fwd_stats": [_PTR] * 6 + [_INT] * 8 + [_PTR],
+    "az_conv3d_fwd": [_PTR] * 7 + [_INT] * 10 + [_PTR],
+    "az_conv3d_fwd_stats": [_PTR] * 6 + [_INT] * 9 + [_PTR],
     "az_conv3d_wgrad_workspace": [_INT, _INT],
     "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 10 + [_PTR],
     "az_conv3d_c1_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
@@ -54,7 +55,7 @@ _SIGS = {
     "az_corr1d_lookup_fwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
     "az_corr1d_lookup_bwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
 }
-_RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL,
+_RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_packed_floats": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL}
 
 

@@ -13,12 +13,25 @@ conv, stride-2 conv, stride-2 transposed conv) with differently packed weights:
     Conv3d stride 2       mode 1       mode 2, swapped           wgrad(dy, x, 2)
     ConvTranspose3d s2    mode 2       mode 1, as stored         wgrad(x, dy, 2)
 """
+import os
+
 import torch
 
 from . import _lib, profiler
 from .ops import _call, _chk, _p, _stream
 
 CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
+FP32, BF16X6 = 0, 1
+# arithmetic of the gather kernels (forward, input gradients, transposed convs):
+#   fp32   -- v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chain (157 TFLOP/s peak)
+#   bf16x6 -- exact 3-way bf16 split of both operands, six bf16 MFMAs per product, fp32
+#             accumulate: fp32-class accuracy (measured ~1e-7 relative) at 2.7x the rate
+PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[os.environ.get("AZ_CONV_PRECISION", "bf16x6")]
+
+
+def set_precision(name):
+    global PRECISION
+    PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[name]
 
 
 def _dims(x):
@@ -36,9 +49,10 @@ def _out_dims(mode, d, h, w):
 
 def _pack(weight, op_cin, op_cout, stride_out, stride_in, flip):
     w = _chk(weight.detach().contiguous(), "weight")
-    packed = torch.empty(27 * op_cin * op_cout, dtype=torch.float32, device=w.device)
+    n = _lib.lib().az_conv3d_packed_floats(op_cin, op_cout, PRECISION)
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
     _call("az_conv3d_pack_weights", _p(packed), _p(w), op_cin, op_cout, stride_out, stride_in,
-          int(flip), _stream())
+          int(flip), PRECISION, _stream())
     return packed
 
 
@@ -76,7 +90,7 @@ def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=Non
         out = x.fl.new_empty(b, d, h, w, cout)
         with profiler.scope(f"{tag}_costvol_m0_{cin}_{cout}", flops=_conv_flops(b, d * h * w, cin, cout, mode)):
             _call("az_conv3d_fwd", _p(out), _p(x.fl), _p(x.fr), _p(packed), _p(scale), _p(shift),
-                  _p(residual), int(relu), mode, 1, b, cin, cout, d, h, w, _stream())
+                  _p(residual), int(relu), mode, 1, PRECISION, b, cin, cout, d, h, w, _stream())
         return out
     b, d, h, w, c = _dims(x)
     assert c == cin, (c, cin)
@@ -92,11 +106,11 @@ def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=Non
         cnt = x.new_empty(ntiles)
         with profiler.scope(name, flops=flops):
             _call("az_conv3d_fwd_stats", _p(out), _p(part), _p(cnt), _p(x), None, _p(packed), mode, 0,
-                  b, cin, cout, d, h, w, _stream())
+                  PRECISION, b, cin, cout, d, h, w, _stream())
         return out, part, cnt, ntiles
     with profiler.scope(name, flops=flops):
         _call("az_conv3d_fwd", _p(out), _p(x), None, _p(packed), _p(scale), _p(shift), _p(residual),
-              int(relu), mode, 0, b, cin, cout, d, h, w, _stream())
+              int(relu), mode, 0, PRECISION, b, cin, cout, d, h, w, _stream())
     return out
 
 

@@ -37,6 +37,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CV_VS 36  // slab voxel stride in dwords
 #define CV_BAND 4 // tile rows per band of the block -> tile order
+#define X6_VS 52  // PREC 1 slab voxel stride in dwords
+#ifndef X6_BPIPE_PREC
+#define X6_BPIPE_PREC 0  // weight prefetch one tap ahead only in the fp32 path (registers)
+#endif
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvArgs {
     const float *in;    // NDHWC input (coarse tensor for MODE 2); SRC 1: left features NHWC
@@ -54,7 +60,7 @@ struct ConvArgs {
     int map_mode;  // block->tile map: 0 linear, 1 XCD-chunked linear, 2 XCD-chunked + banded
 };
 
-template <int CIN, int COUT, int MODE, int EPI, int SRC>
+template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
 __global__ void __launch_bounds__(64, 2)
 conv3d_gather_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32, NR = COUT / 32;
@@ -62,7 +68,10 @@ conv3d_gather_kernel(const ConvArgs a) {
     constexpr int TY = 4, TX = 8 * MR;
     constexpr int SY = (MODE == 0) ? TY + 2 : (MODE == 1) ? 2 * TY + 1 : TY + 1;
     constexpr int SX = (MODE == 0) ? TX + 2 : (MODE == 1) ? 2 * TX + 1 : TX + 1;
-    __shared__ __attribute__((aligned(16))) float slab[SY * SX * CV_VS];
+    // PREC 0: fp32 slab, 36 dwords per voxel.  PREC 1: three bf16 planes (hi, mid, lo) of 32
+    // channels each, 52 dwords per voxel (3 x 64 B + 16 B bank padding).
+    constexpr int VS = (PREC == 0) ? CV_VS : X6_VS;
+    __shared__ __attribute__((aligned(16))) float slab[SY * SX * VS];
 
     const int lane = threadIdx.x;
     // ---- block -> tile map -------------------------------------------------------------
@@ -129,7 +138,7 @@ conv3d_gather_kernel(const ConvArgs a) {
     // stage s run; weights are fetched one tap ahead.
     constexpr int NQ = SY * SX * 8;          // float4 pieces of one slab
     constexpr int NLD = (NQ + 63) / 64;      // pieces per lane
-    constexpr bool BPIPE = (NR == 1);
+    constexpr bool BPIPE = (NR == 1) && (PREC == X6_BPIPE_PREC);
     const int NS = nd * NCH;
     float4 pre[NLD];
 
@@ -143,27 +152,31 @@ conv3d_gather_kernel(const ConvArgs a) {
         const int idc = min(max(id, 0), a.Di - 1);
         bool okv[NLD];
         // pass 1: every load is issued unconditionally from a clamped (always valid)
-        // address, so all NLD requests are in flight together ...
+        // address, so all NLD requests are in flight together.  Address = wave-uniform
+        // 64-bit plane base + 32-bit per-lane offset; a wave-instruction covers 8 slab
+        // voxels, so (sy, sx) advance by 8 voxels per iteration without divisions.
+        const float *plane0 = (SRC == 0)
+            ? a.in + (((size_t)b * a.Di + idc) * a.Hi) * a.Wi * CIN + cc * 32
+            : ((cc == 0) ? a.in : a.in2) + ((size_t)b * a.Hi) * a.Wi * 32;
+        const int part4 = (lane & 7) * 4;
+        int sy = (lane >> 3) / SX, sx = (lane >> 3) - sy * SX;
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
-            const int q = lane + 64 * it;
-            const int v = q >> 3, part = q & 7;
-            const int sy = v / SX, sx = v - sy * SX;
             const int ih = ih0 + sy, iw = iw0 + sx;
             const int ihc = min(max(ih, 0), a.Hi - 1), iwc = min(max(iw, 0), a.Wi - 1);
-            bool ok = pok && (q < NQ) && ih == ihc && iw == iwc;
-            const float *src;
+            bool ok = pok && (lane + 64 * it < NQ) && ih == ihc && iw == iwc;
+            unsigned off;
             if (SRC == 0) {
-                const size_t vox = (((size_t)b * a.Di + idc) * a.Hi + ihc) * a.Wi + iwc;
-                src = a.in + vox * CIN + cc * 32 + part * 4;
+                off = (unsigned)(ihc * a.Wi + iwc) * CIN + part4;
             } else {  // concat cost volume: plane id = disparity index
                 ok = ok && (iw >= id);
-                const size_t rowb = ((size_t)b * a.Hi + ihc) * a.Wi;
                 const int iwr = (cc == 0) ? iwc : max(iwc - idc, 0);
-                src = ((cc == 0) ? a.in : a.in2) + (rowb + iwr) * 32 + part * 4;
+                off = (unsigned)(ihc * a.Wi + iwr) * 32 + part4;
             }
-            pre[it] = *reinterpret_cast<const float4 *>(src);
+            pre[it] = *reinterpret_cast<const float4 *>(plane0 + off);
             okv[it] = ok;
+            sx += 8;
+            if (sx >= SX) { sx -= SX; ++sy; }
         }
         // pass 2: ... and padding is applied afterwards with scalar selects
 #pragma unroll
@@ -178,15 +191,36 @@ conv3d_gather_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int q = lane + 64 * it;
-            if (q < NQ) *reinterpret_cast<float4 *>(&slab[(q >> 3) * CV_VS + (q & 7) * 4]) = pre[it];
+            if (PREC == 0) {
+                if (q < NQ) *reinterpret_cast<float4 *>(&slab[(q >> 3) * CV_VS + (q & 7) * 4]) = pre[it];
+            } else if (q < NQ) {
+                // exact 3-way split x = hi + mid + lo into bf16 by truncation (8+8+8 significand bits)
+                const float xs[4] = {pre[it].x, pre[it].y, pre[it].z, pre[it].w};
+                unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = __float_as_uint(xs[e]) & 0xffff0000u;
+                    const float r1 = xs[e] - __uint_as_float(hi[e]);
+                    mid[e] = __float_as_uint(r1) & 0xffff0000u;
+                    const float r2 = r1 - __uint_as_float(mid[e]);
+                    lo[e] = __float_as_uint(r2) & 0xffff0000u;
+                }
+                unsigned *dst = reinterpret_cast<unsigned *>(slab) + (q >> 3) * X6_VS + (q & 7) * 2;
+                *reinterpret_cast<uint2 *>(dst) = make_uint2((hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]);
+                *reinterpret_cast<uint2 *>(dst + 16) = make_uint2((mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]);
+                *reinterpret_cast<uint2 *>(dst + 32) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+            }
         }
     };
+    // 16-byte operand pieces per (tile, tap, chunk): fp32 -> 4 (k = 16*half + 4j..4j+3);
+    // bf16x6 -> 6 = 3 split parts x 2 K16 blocks (k = 16*kb + 8*half + 0..7), index p*2 + kb
+    constexpr int NF = (PREC == 0) ? 4 : 6;
     auto load_b = [&](auto &bq, int tap, int cc) {
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bq[n][j] = wp4[((((size_t)tap * NCH + cc) * NR + n) * 4 + j) * 64 + lane];
+            for (int j = 0; j < NF; ++j)
+                bq[n][j] = wp4[((((size_t)tap * NCH + cc) * NR + n) * NF + j) * 64 + lane];
     };
     const int ntaps = nh * nw;
     auto tap_of = [&](int kd, int t, int &eh, int &ew) -> int {
@@ -206,39 +240,60 @@ conv3d_gather_kernel(const ConvArgs a) {
         __syncthreads();  // previous slab fully consumed (single-wave group: fence only)
         commit();
         __syncthreads();
-        float4 bq[NR][4];
+        float4 bq[NR][NF];
         int eh, ew;
         load_b(bq, tap_of(kd, 0, eh, ew), cc);
         if (s + 1 < NS) issue(s + 1);
         if (id < 0 || id >= a.Di) continue;  // wave-uniform: a zero-padding plane
-        auto load_a = [&](float4 (&aq)[4], int m, int eh_, int ew_) {
+        auto load_a = [&](float4 (&aq)[NF], int m, int eh_, int ew_) {
             const int sy = ((MODE == 1) ? 2 * rty : rty) + eh_;
             const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew_;
-            const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
+            if (PREC == 0) {
+                const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
+                for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
+            } else {
+                const float *ap = &slab[(sy * SX + sx) * X6_VS + 4 * half];
+#pragma unroll
+                for (int f = 0; f < 6; ++f)  // part f>>1 at +16 dwords, K16 block f&1 at +8 dwords
+                    aq[f] = *reinterpret_cast<const float4 *>(ap + (f >> 1) * 16 + (f & 1) * 8);
+            }
         };
-        auto mfma16 = [&](f32x16 (&c)[NR], const float4 (&aq)[4], const float4 (&bw)[NR][4]) {
+        auto mfma16 = [&](f32x16 (&c)[NR], const float4 (&aq)[NF], const float4 (&bw)[NR][NF]) {
 #pragma unroll
-            for (int n = 0; n < NR; ++n)
+            for (int n = 0; n < NR; ++n) {
+                if (PREC == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bw[n][j].x, c[n], 0, 0, 0);
-                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bw[n][j].y, c[n], 0, 0, 0);
-                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bw[n][j].z, c[n], 0, 0, 0);
-                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bw[n][j].x, c[n], 0, 0, 0);
+                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bw[n][j].y, c[n], 0, 0, 0);
+                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bw[n][j].z, c[n], 0, 0, 0);
+                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
+                    }
+                } else {
+                    // fp32 product on the bf16 pipe: (ah+am+al)(bh+bm+bl) without the three
+                    // terms below 2^-24: six v_mfma_f32_32x32x16_bf16 per 16-deep K block,
+                    // smallest terms first
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+#define X6(A, B) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
+                        __builtin_bit_cast(bf16x8, aq[(A) * 2 + kb]), __builtin_bit_cast(bf16x8, bw[n][(B) * 2 + kb]), c[n], 0, 0, 0)
+                        X6(2, 0); X6(0, 2); X6(1, 1); X6(1, 0); X6(0, 1); X6(0, 0);
+#undef X6
+                    }
                 }
+            }
         };
         // A fragments are read one MFMA block (16*NR instructions) ahead of their use:
         // tile 1's while tile 0 multiplies, the next tap's tile 0 while tile 1 multiplies.
-        float4 a0[4], a1[4];
+        float4 a0[NF], a1[NF];
         load_a(a0, 0, eh, ew);
         for (int t = 0; t < ntaps; ++t) {
             tap_of(kd, t, eh, ew);
             if (MR == 2) load_a(a1, 1, eh, ew);
             // weights one tap ahead when registers allow (NR == 1); with two N-tiles the
             // second resident wave hides the L2 latency instead
-            float4 bn[BPIPE ? NR : 1][4];
+            float4 bn[BPIPE ? NR : 1][NF];
             int eh2 = 0, ew2 = 0;
             if (t + 1 < ntaps) {
                 const int tap2 = tap_of(kd, t + 1, eh2, ew2);
@@ -258,7 +313,7 @@ conv3d_gather_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < NR; ++n)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bq[n][j] = bn[n][j];
+                    for (int j = 0; j < NF; ++j) bq[n][j] = bn[n][j];
             }
         }
     }
@@ -357,27 +412,69 @@ conv3d_pack_kernel(float *__restrict__ dst, const float *__restrict__ src, int c
     dst[idx] = src[co * sn + ci * sk + (flip ? 26 - tap : tap)];
 }
 
-template <int CIN, int COUT, int MODE, int EPI, int SRC>
+// bf16x6 packing: [tap][cc][n][part(3)][kb(2)][lane(64)][8] bf16, element j of lane =
+// part `p` of src(co = n*32 + (lane&31), ci = cc*32 + 16*kb + 8*(lane>>5) + j, tap)
+__global__ void __launch_bounds__(256)
+conv3d_pack_x6_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, int cin,
+                      int cout, long long sn, long long sk, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    int r = idx >> 9;
+    const int kb = r & 1; r >>= 1;
+    const int p = r % 3; r /= 3;
+    const int nr = cout / 32, nch = cin / 32;
+    const int n = r % nr; r /= nr;
+    const int cc = r % nch;
+    const int tap = r / nch;
+    const int co = n * 32 + (lane & 31);
+    const int ci = cc * 32 + 16 * kb + 8 * (lane >> 5) + j;
+    const float x = src[co * sn + ci * sk + (flip ? 26 - tap : tap)];
+    const unsigned hi = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hi);
+    const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    const unsigned lo = __float_as_uint(r2) & 0xffff0000u;
+    dst[idx] = (unsigned short)((p == 0 ? hi : p == 1 ? mid : lo) >> 16);
+}
+
+template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
 static int launch_conv(const ConvArgs &a, hipStream_t s) {
     long long blocks = (long long)a.B * a.Dt * a.tiles_y * a.tiles_x * (MODE == 2 ? 8 : 1);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3d_gather_kernel<CIN, COUT, MODE, EPI, SRC>), dim3((unsigned)blocks),
-                       dim3(64), 0, s, a);
+    hipLaunchKernelGGL((conv3d_gather_kernel<CIN, COUT, MODE, EPI, SRC, PREC>),
+                       dim3((unsigned)blocks), dim3(64), 0, s, a);
     return az_launch_status();
 }
 
-template <int MODE, int EPI>
+template <int MODE, int EPI, int PREC>
 static int dispatch_channels(const ConvArgs &a, int cin, int cout, int src, hipStream_t s) {
     if (src == 1) {
         if (MODE != 0 || cin != 64) return AZ_EUNSUPPORTED;
-        if (cout == 32) return launch_conv<64, 32, 0, EPI, 1>(a, s);
+        if (cout == 32) return launch_conv<64, 32, 0, EPI, 1, PREC>(a, s);
         return AZ_EUNSUPPORTED;
     }
-    if (cin == 32 && cout == 32) return launch_conv<32, 32, MODE, EPI, 0>(a, s);
-    if (cin == 64 && cout == 32) return launch_conv<64, 32, MODE, EPI, 0>(a, s);
-    if (cin == 32 && cout == 64) return launch_conv<32, 64, MODE, EPI, 0>(a, s);
-    if (cin == 64 && cout == 64) return launch_conv<64, 64, MODE, EPI, 0>(a, s);
+    if (cin == 32 && cout == 32) return launch_conv<32, 32, MODE, EPI, 0, PREC>(a, s);
+    if (cin == 64 && cout == 32) return launch_conv<64, 32, MODE, EPI, 0, PREC>(a, s);
+    if (cin == 32 && cout == 64) return launch_conv<32, 64, MODE, EPI, 0, PREC>(a, s);
+    if (cin == 64 && cout == 64) return launch_conv<64, 64, MODE, EPI, 0, PREC>(a, s);
     return AZ_EUNSUPPORTED;
+}
+
+template <int EPI>
+static int dispatch_mode(const ConvArgs &a, int mode, int precision, int cin, int cout, int src,
+                         hipStream_t s) {
+    if (precision == 0) {
+        if (mode == 0) return dispatch_channels<0, EPI, 0>(a, cin, cout, src, s);
+        if (mode == 1) return dispatch_channels<1, EPI, 0>(a, cin, cout, src, s);
+        return dispatch_channels<2, EPI, 0>(a, cin, cout, src, s);
+    }
+    if (precision == 1) {
+        if (mode == 0) return dispatch_channels<0, EPI, 1>(a, cin, cout, src, s);
+        if (mode == 1) return dispatch_channels<1, EPI, 1>(a, cin, cout, src, s);
+        return dispatch_channels<2, EPI, 1>(a, cin, cout, src, s);
+    }
+    return AZ_EINVAL;
 }
 
 static void conv_out_dims(int mode, int Di, int Hi, int Wi, int &Do, int &Ho, int &Wo) {
@@ -402,14 +499,28 @@ extern "C" long long az_conv3d_num_tiles(int mode, int B, int Di, int Hi, int Wi
     return (long long)B * Dt * ty * tx * (mode == 2 ? 8 : 1);
 }
 
+extern "C" long long az_conv3d_packed_floats(int cin, int cout, int precision) {
+    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || precision < 0 || precision > 1) return AZ_EINVAL;
+    return precision == 0 ? 27LL * cin * cout : 27LL * cin * cout * 3 / 2;
+}
+
 extern "C" int az_conv3d_pack_weights(float *packed, const float *w, int cin, int cout,
                                       long long stride_out, long long stride_in, int flip,
-                                      void *stream) {
+                                      int precision, void *stream) {
     AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w);
     if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0) return AZ_EUNSUPPORTED;
-    const int total = 27 * cin * cout;
-    hipLaunchKernelGGL(conv3d_pack_kernel, dim3((total + 255) / 256), dim3(256), 0,
-                       az_stream(stream), packed, w, cin, cout, stride_out, stride_in, flip, total);
+    if (precision == 0) {
+        const int total = 27 * cin * cout;
+        hipLaunchKernelGGL(conv3d_pack_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                           az_stream(stream), packed, w, cin, cout, stride_out, stride_in, flip, total);
+    } else if (precision == 1) {
+        const int total = 27 * cin * cout * 3;
+        hipLaunchKernelGGL(conv3d_pack_x6_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                           az_stream(stream), reinterpret_cast<unsigned short *>(packed), w, cin, cout,
+                           stride_out, stride_in, flip, total);
+    } else {
+        return AZ_EINVAL;
+    }
     return az_launch_status();
 }
 
@@ -435,24 +546,21 @@ static int conv_common(ConvArgs &a, int mode, int B, int cin, int Di, int Hi, in
 
 extern "C" int az_conv3d_fwd(float *out, const float *in, const float *in2,
                              const float *packed_w, const float *scale, const float *shift,
-                             const float *residual, int relu, int mode, int src, int B, int cin,
-                             int cout, int Di, int Hi, int Wi, void *stream) {
+                             const float *residual, int relu, int mode, int src, int precision,
+                             int B, int cin, int cout, int Di, int Hi, int Wi, void *stream) {
     AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w);
     if (src == 1) AZ_REQUIRE_PTR(in2);
     ConvArgs a{};
     if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, src)) return e;
     a.in = in; a.in2 = in2; a.wp = packed_w; a.out = out;
     a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu;
-    hipStream_t s = az_stream(stream);
-    if (mode == 0) return dispatch_channels<0, 0>(a, cin, cout, src, s);
-    if (mode == 1) return dispatch_channels<1, 0>(a, cin, cout, src, s);
-    return dispatch_channels<2, 0>(a, cin, cout, src, s);
+    return dispatch_mode<0>(a, mode, precision, cin, cout, src, az_stream(stream));
 }
 
 extern "C" int az_conv3d_fwd_stats(float *out, float *partials, float *counts, const float *in,
                                    const float *in2, const float *packed_w, int mode, int src,
-                                   int B, int cin, int cout, int Di, int Hi, int Wi,
-                                   void *stream) {
+                                   int precision, int B, int cin, int cout, int Di, int Hi,
+                                   int Wi, void *stream) {
     AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w);
     AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts);
     if (src == 1) AZ_REQUIRE_PTR(in2);
@@ -460,8 +568,5 @@ extern "C" int az_conv3d_fwd_stats(float *out, float *partials, float *counts, c
     if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, src)) return e;
     a.in = in; a.in2 = in2; a.wp = packed_w; a.out = out; a.part = partials; a.cnt = counts;
     a.ntiles = az_conv3d_num_tiles(mode, B, Di, Hi, Wi);
-    hipStream_t s = az_stream(stream);
-    if (mode == 0) return dispatch_channels<0, 1>(a, cin, cout, src, s);
-    if (mode == 1) return dispatch_channels<1, 1>(a, cin, cout, src, s);
-    return dispatch_channels<2, 1>(a, cin, cout, src, s);
+    return dispatch_mode<1>(a, mode, precision, cin, cout, src, az_stream(stream));
 }

@@ -130,21 +130,29 @@ int az_lcn(float *normed, float *stdv, const float *img, int B, int H, int W, in
 /* packed[tap][cin/32][cout/32][4][64][4] from any [.][.][27] weight tensor:
  * element (out-channel n, in-channel k, tap t) is read at
  * w[n*stride_out + k*stride_in + (flip ? 26-t : t)]. */
+/* precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chain);
+ *            1 = "bf16x6": both operands are split exactly into three bf16 parts and the
+ *                six significant partial products run on v_mfma_f32_32x32x16_bf16 with fp32
+ *                accumulation (error ~1e-7 relative, like fp32; 2.7x the fp32 MFMA rate).
+ * The packed buffer holds az_conv3d_packed_floats(cin, cout, precision) floats. */
+long long az_conv3d_packed_floats(int cin, int cout, int precision);
 int az_conv3d_pack_weights(float *packed, const float *w, int cin, int cout,
-                           long long stride_out, long long stride_in, int flip, void *stream);
+                           long long stride_out, long long stride_in, int flip, int precision,
+                           void *stream);
 /* number of wavefront tiles a launch uses = rows of the BN partial buffers */
 long long az_conv3d_num_tiles(int mode, int B, int Di, int Hi, int Wi);
 /* out = relu?( conv(in)*scale[c] + shift[c] + residual ); scale/shift/residual may be
  * NULL (eval-mode BatchNorm folded into scale/shift, or a plain convolution). */
 int az_conv3d_fwd(float *out, const float *in, const float *in2, const float *packed_w,
                   const float *scale, const float *shift, const float *residual, int relu,
-                  int mode, int src, int B, int cin, int cout, int Di, int Hi, int Wi,
-                  void *stream);
+                  int mode, int src, int precision, int B, int cin, int cout, int Di, int Hi,
+                  int Wi, void *stream);
 /* out = conv(in) (raw) and, per channel and tile, partials[c][tile] = (sum, centred
  * sum of squares), counts[tile] = valid voxels: the train-mode BatchNorm statistics. */
 int az_conv3d_fwd_stats(float *out, float *partials, float *counts, const float *in,
-                        const float *in2, const float *packed_w, int mode, int src, int B,
-                        int cin, int cout, int Di, int Hi, int Wi, void *stream);
+                        const float *in2, const float *packed_w, int mode, int src,
+                        int precision, int B, int cin, int cout, int Di, int Hi, int Wi,
+                        void *stream);
 /* G[m][n][27] = sum_pos coarse[pos][m] * fine[stride*pos - 1 + k][n]: dW of Conv3d with
  * (coarse, fine) = (grad_out, input), dW of ConvTranspose3d with (input, grad_out). */
 long long az_conv3d_wgrad_workspace(int cm, int cn);

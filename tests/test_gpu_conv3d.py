@@ -24,6 +24,14 @@ def ncdhw(x):  # channels-last (gpu) -> NCDHW cpu
     return x.detach().permute(0, 4, 1, 2, 3).contiguous().cpu()
 
 
+@pytest.fixture(autouse=True, params=["bf16x6", "fp32"])
+def conv_precision(request):
+    """every test of this file runs in both arithmetic modes of the gather kernels"""
+    conv3d.set_precision(request.param)
+    yield request.param
+    conv3d.set_precision("bf16x6")
+
+
 def close(a, b, rtol=1e-4, atol=1e-5):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)

@@ -20,7 +20,7 @@ def bench(shape, cin, cout, mode, reps=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 
-print("map", os.environ.get("AZ_CONV_MAP"),
+print("prec", os.environ.get("AZ_CONV_PRECISION"), "map", os.environ.get("AZ_CONV_MAP"),
       "V0 32->32 s1: %.3f ms" % bench((4, 48, 136, 240), 32, 32, 0),
       "| V0 64->32 s1: %.3f" % bench((4, 48, 136, 240), 64, 32, 0),
       "| V1 64->64 s1: %.3f" % bench((4, 24, 68, 120), 64, 64, 0),
