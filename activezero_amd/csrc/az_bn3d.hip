@@ -24,34 +24,42 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
                    const float *__restrict__ gamma, const float *__restrict__ beta,
                    long long ntiles, int C, float eps, float momentum) {
     const int c = blockIdx.x;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (long long t = threadIdx.x; t < ntiles; t += 256) {
-        const double nt = cnt[t];
-        if (nt <= 0.0) continue;
-        const float2 pr = *reinterpret_cast<const float2 *>(&part[((long long)c * ntiles + t) * 2]);
-        const double st = pr.x, m2t = pr.y;
-        const double mt = st / nt;
-        const double tot = n + nt, delta = mt - mean;
-        mean += delta * nt / tot;
-        m2 += m2t + delta * delta * n * nt / tot;
-        n = tot;
-    }
+    // pass 1: N = sum n_t, S = sum s_t  ->  mean
+    // pass 2: M2 = sum [ M2_t + n_t (s_t/n_t - mean)^2 ]   (Chan's merge with the final mean)
     __shared__ double sn[256], sm[256], s2[256];
-    sn[threadIdx.x] = n; sm[threadIdx.x] = mean; s2[threadIdx.x] = m2;
+    const float2 *pc = reinterpret_cast<const float2 *>(part) + (long long)c * ntiles;
+    double n = 0.0, sum = 0.0;
+    for (long long t = threadIdx.x; t < ntiles; t += 256) {
+        n += (double)cnt[t];
+        sum += (double)pc[t].x;
+    }
+    sn[threadIdx.x] = n; sm[threadIdx.x] = sum;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
-            const double na = sn[threadIdx.x], nb = sn[threadIdx.x + o];
-            const double tot = na + nb;
-            if (tot > 0.0) {
-                const double delta = sm[threadIdx.x + o] - sm[threadIdx.x];
-                sm[threadIdx.x] += delta * nb / tot;
-                s2[threadIdx.x] += s2[threadIdx.x + o] + delta * delta * na * nb / tot;
-                sn[threadIdx.x] = tot;
-            }
+            sn[threadIdx.x] += sn[threadIdx.x + o];
+            sm[threadIdx.x] += sm[threadIdx.x + o];
         }
         __syncthreads();
     }
+    const double Ntot = sn[0], mean_all = sm[0] / sn[0];
+    double m2 = 0.0;
+    for (long long t = threadIdx.x; t < ntiles; t += 256) {
+        const float nt = cnt[t];
+        if (nt <= 0.f) continue;
+        const float2 pr = pc[t];
+        const double dlt = (double)pr.x / (double)nt - mean_all;
+        m2 += (double)pr.y + (double)nt * dlt * dlt;
+    }
+    __syncthreads();
+    s2[threadIdx.x] = m2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s2[threadIdx.x] += s2[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sn[0] = Ntot; sm[0] = mean_all; }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const double N = sn[0], mu = sm[0], var = s2[0] / N;
         const double istd = 1.0 / sqrt(var + (double)eps);

@@ -22,6 +22,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// coarse positions per staged chunk (even).  PSMNet's widths are 240 / 120 / 60: 30 and 20
+// divides them exactly (no MFMA on padding positions); the stride-2 kernels keep 16 (a wider
+// chunk spills at the 2-waves/SIMD register budget).
+#define WG_WCH1 30
+#define WG_WCH2 16
+
 struct WgArgs {
     const float *coarse, *fine;
     float *ws;  // [27][CM][CN]
@@ -31,14 +37,15 @@ struct WgArgs {
     int waves_per_combo;
 };
 
+// (stride 2 stages twice the fine rows: it gets the 1-wave/SIMD register budget instead of spilling)
 template <int CM, int CN, int S>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, S == 1 ? 2 : 1)
 conv3d_wgrad_kernel(const WgArgs a) {
-    constexpr int WCH = (S == 1) ? 32 : 16;  // coarse positions per chunk
+    constexpr int WCH = (S == 1) ? WG_WCH1 : WG_WCH2;  // coarse positions per chunk
     constexpr int FW = S * (WCH - 1) + 3;    // fine positions per staged row
     constexpr int MT = CM / 32, NT = CN / 32, NCOMBO = 3 * MT * NT;
     constexpr int NEW = S;                   // fine rows that enter the 3-row window per step
-    constexpr int NLA = WCH * 8 / 64;        // float4 pieces per lane: coarse row chunk
+    constexpr int NQA = WCH * 8, NLA = (NQA + 63) / 64;  // float4 pieces per lane: coarse row chunk
     constexpr int NQF = NEW * FW * 8, NLF = (NQF + 63) / 64;  // ... new fine rows
     __shared__ __attribute__((aligned(16))) float sa[WCH * 32];
     __shared__ __attribute__((aligned(16))) float sf[3 * FW * 32];  // row fh lives in slot fh mod 3
@@ -82,7 +89,7 @@ conv3d_wgrad_kernel(const WgArgs a) {
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it, pos = q >> 3, part = q & 7;
                 const int cw = cw0 + pos;
-                oka[it] = cw < a.Wc;
+                oka[it] = (q < NQA) && cw < a.Wc;
                 pa[it] = *reinterpret_cast<const float4 *>(
                     cbase + ((size_t)ch * a.Wc + min(cw, a.Wc - 1)) * CM + part * 4);
             }
@@ -110,7 +117,7 @@ conv3d_wgrad_kernel(const WgArgs a) {
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it;
-                *reinterpret_cast<float4 *>(&sa[(q >> 3) * 32 + (q & 7) * 4]) = pa[it];
+                if (q < NQA) *reinterpret_cast<float4 *>(&sa[(q >> 3) * 32 + (q & 7) * 4]) = pa[it];
             }
 #pragma unroll
             for (int it = 0; it < NLF; ++it) {
@@ -143,7 +150,7 @@ conv3d_wgrad_kernel(const WgArgs a) {
             const float *f0 = &sf[s0 * FW * 32 + row];
             const float *f1 = &sf[((s0 + 1) % 3) * FW * 32 + row];
             const float *f2 = &sf[((s0 + 2) % 3) * FW * 32 + row];
-#pragma unroll 4
+#pragma unroll 5
             for (int q = 0; q < WCH / 2; ++q) {
                 const int pos = 2 * q + half;
                 const float av = sa[pos * 32 + row];
@@ -179,16 +186,33 @@ wgrad_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int c
 
 template <int CM, int CN, int S>
 static int launch_wgrad(WgArgs a, hipStream_t s) {
-    constexpr int WCH = (S == 1) ? 32 : 16;
+    constexpr int WCH = (S == 1) ? WG_WCH1 : WG_WCH2;
     constexpr int NCOMBO = 3 * (CM / 32) * (CN / 32);
     a.nwchunk = (a.Wc + WCH - 1) / WCH;
-    // rows per segment: aim at >= 4 items per wave with ~2048 resident waves
-    const int target_waves = 256 * 8;
-    a.waves_per_combo = max(8, (target_waves / NCOMBO) & ~7);  // multiple of 8 (XCD grouping)
+    // Static work lists: wave w of a combo takes items w, w + W, w + 2W, ...  The kernel ends
+    // with its most loaded wave, so pick (row segments, waves per combo W) such that the item
+    // count is (nearly) a multiple of W while W * NCOMBO stays close to the ~2048 resident
+    // waves: score = balance * occupancy, >= 4 items per wave to amortise the per-item prologue.
+    const int slots = 256 * 8;
+    const int wmax = max(8, (slots / NCOMBO) & ~7);
     const long long base_items = (long long)a.B * a.Dc * a.nwchunk;
-    int nhseg = (int)((4LL * a.waves_per_combo + base_items - 1) / base_items);
-    nhseg = max(1, min(nhseg, a.Hc));
-    a.hseg_rows = (a.Hc + nhseg - 1) / nhseg;
+    double best = -1.0;
+    int best_w = 8, best_rows = a.Hc;
+    for (int nseg = 1; nseg <= min(a.Hc, 24); ++nseg) {
+        const int rows = (a.Hc + nseg - 1) / nseg;
+        const int segs = (a.Hc + rows - 1) / rows;
+        const long long items = base_items * segs;
+        for (int w = wmax; w >= max(8, wmax / 2); w -= 8) {
+            const long long per = (items + w - 1) / w;
+            if (per < 4 && nseg < min(a.Hc, 24)) continue;
+            const double balance = (double)items / (double)(per * w);
+            const double occ = (double)w / (double)wmax;
+            const double score = balance * (0.5 + 0.5 * occ) - 0.002 * segs;
+            if (score > best) { best = score; best_w = w; best_rows = rows; }
+        }
+    }
+    a.waves_per_combo = best_w;
+    a.hseg_rows = best_rows;
     a.nhseg = (a.Hc + a.hseg_rows - 1) / a.hseg_rows;
     a.nitems = base_items * a.nhseg;
     if (a.nitems < a.waves_per_combo) a.waves_per_combo = (int)((a.nitems + 7) & ~7LL);
