@@ -38,7 +38,7 @@ _SIGS = {
     "az_conv3d_fwd": [_PTR] * 7 + [_INT] * 10 + [_PTR],
     "az_conv3d_fwd_stats": [_PTR] * 6 + [_INT] * 9 + [_PTR],
     "az_conv3d_wgrad_workspace": [_INT, _INT],
-    "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 10 + [_PTR],
+    "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 11 + [_PTR],
     "az_conv3d_c1_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_dgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_wgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],

@@ -29,9 +29,14 @@ FP32, BF16X6 = 0, 1
 PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[os.environ.get("AZ_CONV_PRECISION", "bf16x6")]
 
 
-def set_precision(name):
-    global PRECISION
+WGRAD_PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[os.environ.get("AZ_WGRAD_PRECISION", "bf16x6")]
+
+
+def set_precision(name, wgrad=None):
+    global PRECISION, WGRAD_PRECISION
     PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[name]
+    if wgrad is not None:
+        WGRAD_PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[wgrad]
 
 
 def _dims(x):
@@ -64,6 +69,12 @@ def _pack_forward(weight, mode):
     return _pack(weight, cin, cout, cin * 27, 27, False), cin, cout
 
 
+def _peak(precision):
+    """MFMA roofline of the arithmetic in use, in fp32-equivalent TFLOP/s: the fp32 MFMA dense
+    peak, or the bf16 dense peak divided by the six bf16 MFMAs one fp32 product costs."""
+    return (157.3, "fp32 MFMA") if precision == FP32 else (2500.0 / 6.0, "bf16x6: bf16 MFMA peak / 6")
+
+
 def _conv_flops(b, vox_out, cin, cout, mode):
     taps = 27.0 / 8.0 if mode == DECONV_S2 else 27.0
     return 2.0 * taps * cin * cout * b * vox_out
@@ -88,7 +99,8 @@ def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=Non
         b, h, w, _ = x.fl.shape
         d = x.ndisp
         out = x.fl.new_empty(b, d, h, w, cout)
-        with profiler.scope(f"{tag}_costvol_m0_{cin}_{cout}", flops=_conv_flops(b, d * h * w, cin, cout, mode)):
+        with profiler.scope(f"{tag}_costvol_m0_{cin}_{cout}", flops=_conv_flops(b, d * h * w, cin, cout, mode),
+                            peak=_peak(PRECISION)):
             _call("az_conv3d_fwd", _p(out), _p(x.fl), _p(x.fr), _p(packed), _p(scale), _p(shift),
                   _p(residual), int(relu), mode, 1, PRECISION, b, cin, cout, d, h, w, _stream())
         return out
@@ -104,11 +116,11 @@ def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=Non
         ntiles = _lib.lib().az_conv3d_num_tiles(mode, b, d, h, w)
         part = x.new_empty(cout, ntiles, 2)
         cnt = x.new_empty(ntiles)
-        with profiler.scope(name, flops=flops):
+        with profiler.scope(name, flops=flops, peak=_peak(PRECISION)):
             _call("az_conv3d_fwd_stats", _p(out), _p(part), _p(cnt), _p(x), None, _p(packed), mode, 0,
                   PRECISION, b, cin, cout, d, h, w, _stream())
         return out, part, cnt, ntiles
-    with profiler.scope(name, flops=flops):
+    with profiler.scope(name, flops=flops, peak=_peak(PRECISION)):
         _call("az_conv3d_fwd", _p(out), _p(x), None, _p(packed), _p(scale), _p(shift), _p(residual),
               int(relu), mode, 0, PRECISION, b, cin, cout, d, h, w, _stream())
     return out
@@ -120,9 +132,10 @@ def _wgrad(coarse, fine, stride, cm, cn, tag):
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
     ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
     ws = coarse.new_empty(ws_bytes // 4)
-    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc):
-        _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, b, cm, cn,
-              dc, hc, wc, df, hf, wf, _stream())
+    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
+                        peak=_peak(WGRAD_PRECISION)):
+        _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, WGRAD_PRECISION,
+              b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
     return gw
 
 

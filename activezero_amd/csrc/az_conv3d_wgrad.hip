@@ -176,6 +176,196 @@ conv3d_wgrad_kernel(const WgArgs a) {
     }
 }
 
+
+// ---- bf16x6 variant ------------------------------------------------------------------------
+// Same decomposition, but the products run on v_mfma_f32_32x32x16_bf16 with both operands split
+// exactly into three bf16 parts (hi, mid, lo; six significant partial products, fp32
+// accumulation -- see az_conv3d.hip).  K = 16 POSITIONS per MFMA, so a lane needs 8 consecutive
+// positions of its channel: the staged [position][channel] bf16 tiles are read with
+// ds_read_b64_tr_b16 (the hardware transpose read: per 16-lane group, lane 4q+p gives the
+// address of row q / columns 4p..4p+3 and lane i receives column i of the 4 rows).  Rows are
+// addressed individually, which also covers the stride-2 position map and the kw tap shift.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+#define X6_WCH 16  // coarse positions per chunk = one K16 block
+
+template <int CM, int CN, int S>
+__global__ void __launch_bounds__(64, S == 1 ? 2 : 1)
+conv3d_wgrad_x6_kernel(const WgArgs a) {
+    constexpr int WCH = X6_WCH;
+    constexpr int FW = S * (WCH - 1) + 3;  // fine positions per staged row
+    constexpr int MT = CM / 32, NT = CN / 32, NCOMBO = 3 * MT * NT;
+    constexpr int NEW = S;
+    constexpr int NQA = WCH * 8, NLA = (NQA + 63) / 64;
+    constexpr int NQF = NEW * FW * 8, NLF = (NQF + 63) / 64;
+    // bf16 images, 32 channels (64 B) per position: [part][pos][32]
+    __shared__ __attribute__((aligned(16))) unsigned short sa[3 * WCH * 32];
+    __shared__ __attribute__((aligned(16))) unsigned short sf[3 * 3 * FW * 32];  // [slot][part][pos][32]
+
+    const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
+    const int grp = blockIdx.x / (8 * NCOMBO), rem = blockIdx.x % (8 * NCOMBO);
+    int combo = rem >> 3;
+    const int widx = grp * 8 + (rem & 7);
+    const int nt = combo % NT; combo /= NT;
+    const int mt = combo % MT;
+    const int kd = combo / MT;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // transpose-read geometry of this lane: 16-lane group g = lane>>4 reads columns
+    // 16*(g&1).. of rows 8*(g>>1) + {0..3} and {4..7}; inside the group lane t = 4q+p
+    // supplies the address of row q, columns 4p..4p+3.
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tr_col = 16 * ((lane >> 4) & 1) + 4 * tp;
+    const int tr_row = 8 * (lane >> 5) + tq;  // + 4 for the second read
+
+    auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v) {
+        // exact 3-way bf16 split by truncation; dst_part0 points at 4 channels of part 0
+        const float xs[4] = {v.x, v.y, v.z, v.w};
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = __float_as_uint(xs[e]) & 0xffff0000u;
+            const float r1 = xs[e] - __uint_as_float(hi[e]);
+            mid[e] = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mid[e]);
+            lo[e] = __float_as_uint(r2) & 0xffff0000u;
+        }
+        *reinterpret_cast<uint2 *>(dst_part0) = make_uint2((hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]);
+        *reinterpret_cast<uint2 *>(dst_part0 + part_stride) = make_uint2((mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]);
+        *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+    };
+    // fragment of 8 consecutive K rows (positions) for this lane's column, rows given by rowfn(k)
+    auto frag = [&](const unsigned short *img, int r0, int r1) -> bf16x8 {
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + r0 * 32 + tr_col));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + r1 * 32 + tr_col));
+        s16x8 v;
+        v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+        v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    for (long long item = widx; item < a.nitems; item += a.waves_per_combo) {
+        long long r = item;
+        const int wc = (int)(r % a.nwchunk); r /= a.nwchunk;
+        const int hs = (int)(r % a.nhseg); r /= a.nhseg;
+        const int cd = (int)(r % a.Dc);
+        const int b = (int)(r / a.Dc);
+        const int fd = S * cd - 1 + kd;
+        if (fd < 0 || fd >= a.Df) continue;  // wave-uniform
+        const int cw0 = wc * WCH, fw0 = S * cw0 - 1;
+        const int h_beg = hs * a.hseg_rows, h_end = min((hs + 1) * a.hseg_rows, a.Hc);
+        const float *cbase = a.coarse + (((size_t)b * a.Dc + cd) * a.Hc) * a.Wc * CM + mt * 32;
+        const float *fbase = a.fine + (((size_t)b * a.Df + fd) * a.Hf) * a.Wf * CN + nt * 32;
+
+        float4 pa[NLA], pf[NLF];
+        auto issue = [&](int ch) {
+            bool oka[NLA], okf[NLF];
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                const int q = lane + 64 * it, pos = q >> 3, part = q & 7;
+                const int cw = cw0 + pos;
+                oka[it] = (q < NQA) && cw < a.Wc;
+                pa[it] = *reinterpret_cast<const float4 *>(
+                    cbase + ((size_t)ch * a.Wc + min(cw, a.Wc - 1)) * CM + part * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                const int q = lane + 64 * it, part = q & 7, p = q >> 3;
+                const int rr = min(p / FW, NEW - 1), lw = p - (p / FW) * FW;
+                const int fh = S * ch + 2 - NEW + rr, fw = fw0 + lw;
+                const int fhc = min(max(fh, 0), a.Hf - 1), fwc = min(max(fw, 0), a.Wf - 1);
+                okf[it] = (q < NQF) && fh == fhc && fw == fwc;
+                pf[it] = *reinterpret_cast<const float4 *>(fbase + ((size_t)fhc * a.Wf + fwc) * CN + part * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                pa[it].x = oka[it] ? pa[it].x : 0.f; pa[it].y = oka[it] ? pa[it].y : 0.f;
+                pa[it].z = oka[it] ? pa[it].z : 0.f; pa[it].w = oka[it] ? pa[it].w : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                pf[it].x = okf[it] ? pf[it].x : 0.f; pf[it].y = okf[it] ? pf[it].y : 0.f;
+                pf[it].z = okf[it] ? pf[it].z : 0.f; pf[it].w = okf[it] ? pf[it].w : 0.f;
+            }
+        };
+        auto commit = [&](int ch) {
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                const int q = lane + 64 * it;
+                if (q < NQA) split_store(&sa[(q >> 3) * 32 + (q & 7) * 4], WCH * 32, pa[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                const int q = lane + 64 * it, part = q & 7, p = q >> 3;
+                const int rr = p / FW, lw = p - rr * FW;
+                const int fh = S * ch + 2 - NEW + rr;
+                const int slot = (fh + 3) % 3;
+                if (q < NQF) split_store(&sf[(slot * 3 * FW + lw) * 32 + part * 4], FW * 32, pf[it]);
+            }
+        };
+
+        __syncthreads();
+        // prologue: rows of the first window that `issue` does not bring in
+        for (int q = lane; q < (3 - NEW) * FW * 8; q += 64) {
+            const int part = q & 7, p = q >> 3;
+            const int rr = p / FW, lw = p - rr * FW;
+            const int fh = S * h_beg - 1 + rr, fw = fw0 + lw;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf)
+                v = *reinterpret_cast<const float4 *>(fbase + ((size_t)fh * a.Wf + fw) * CN + part * 4);
+            split_store(&sf[(((fh + 3) % 3) * 3 * FW + lw) * 32 + part * 4], FW * 32, v);
+        }
+        issue(h_beg);
+        for (int ch = h_beg; ch < h_end; ++ch) {
+            __syncthreads();
+            commit(ch);
+            __syncthreads();
+            if (ch + 1 < h_end) issue(ch + 1);
+            const int s0 = (S * ch - 1 + 3) % 3;  // slot of kh = 0
+            // A fragments (coarse): parts hi/mid/lo, K rows = positions 8*(lane>>5) + 0..7
+            bf16x8 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = frag(sa + p * WCH * 32, tr_row, tr_row + 4);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned short *frow = sf + ((s0 + kh) % 3) * 3 * FW * 32;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    bf16x8 bfr[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        bfr[p] = frag(frow + p * FW * 32, S * tr_row + kw, S * (tr_row + 4) + kw);
+                    f32x16 c = acc[kh * 3 + kw];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+                    acc[kh * 3 + kw] = c;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tap = kd * 9 + t;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int m = mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+            atomicAdd(&a.ws[((size_t)tap * CM + m) * CN + nt * 32 + row], acc[t][rg]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int cm, int cn) {
     const int idx = blockIdx.x * 256 + threadIdx.x;  // over [m][n][27]
@@ -184,9 +374,9 @@ wgrad_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int c
     dst[idx] = ws[(size_t)tap * cm * cn + mn];
 }
 
-template <int CM, int CN, int S>
+template <int CM, int CN, int S, int PREC>
 static int launch_wgrad(WgArgs a, hipStream_t s) {
-    constexpr int WCH = (S == 1) ? WG_WCH1 : WG_WCH2;
+    constexpr int WCH = (PREC == 1) ? X6_WCH : (S == 1) ? WG_WCH1 : WG_WCH2;
     constexpr int NCOMBO = 3 * (CM / 32) * (CN / 32);
     a.nwchunk = (a.Wc + WCH - 1) / WCH;
     // Static work lists: wave w of a combo takes items w, w + W, w + 2W, ...  The kernel ends
@@ -216,8 +406,12 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
     a.nhseg = (a.Hc + a.hseg_rows - 1) / a.hseg_rows;
     a.nitems = base_items * a.nhseg;
     if (a.nitems < a.waves_per_combo) a.waves_per_combo = (int)((a.nitems + 7) & ~7LL);
-    hipLaunchKernelGGL((conv3d_wgrad_kernel<CM, CN, S>), dim3(a.waves_per_combo * NCOMBO), dim3(64),
-                       0, s, a);
+    if (PREC == 1)
+        hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CM, CN, S>), dim3(a.waves_per_combo * NCOMBO),
+                           dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<CM, CN, S>), dim3(a.waves_per_combo * NCOMBO),
+                           dim3(64), 0, s, a);
     return az_launch_status();
 }
 
@@ -227,12 +421,13 @@ extern "C" long long az_conv3d_wgrad_workspace(int cm, int cn) {
 }
 
 extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
-                               const float *coarse, const float *fine, int stride, int B, int cm,
-                               int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf,
-                               void *stream) {
+                               const float *coarse, const float *fine, int stride, int precision,
+                               int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf,
+                               int Wf, void *stream) {
     AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(coarse); AZ_REQUIRE_PTR(fine);
     AZ_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Df > 0 && Hf > 0 && Wf > 0);
     AZ_REQUIRE(stride == 1 || stride == 2);
+    AZ_REQUIRE(precision == 0 || precision == 1);
     const long long need = az_conv3d_wgrad_workspace(cm, cn);
     if (need < 0) return AZ_EUNSUPPORTED;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
@@ -242,9 +437,11 @@ extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long worksp
     a.coarse = coarse; a.fine = fine; a.ws = workspace;
     a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;
     int rc = AZ_EUNSUPPORTED;
-#define WG_CASE(M, N)                                                           \
-    if (cm == M && cn == N)                                                     \
-        rc = (stride == 1) ? launch_wgrad<M, N, 1>(a, s) : launch_wgrad<M, N, 2>(a, s);
+#define WG_CASE(M, N)                                                                        \
+    if (cm == M && cn == N)                                                                  \
+        rc = precision == 0                                                                  \
+                 ? ((stride == 1) ? launch_wgrad<M, N, 1, 0>(a, s) : launch_wgrad<M, N, 2, 0>(a, s)) \
+                 : ((stride == 1) ? launch_wgrad<M, N, 1, 1>(a, s) : launch_wgrad<M, N, 2, 1>(a, s));
     WG_CASE(32, 32) WG_CASE(32, 64) WG_CASE(64, 32) WG_CASE(64, 64)
 #undef WG_CASE
     if (rc != AZ_OK) return rc;

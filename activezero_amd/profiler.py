@@ -25,7 +25,7 @@ def start():
 
 
 @contextlib.contextmanager
-def scope(name, flops=0.0, bytes=0.0, bound="mfma"):
+def scope(name, flops=0.0, bytes=0.0, bound="mfma", peak=None):
     if not _active:
         yield
         return
@@ -36,7 +36,7 @@ def scope(name, flops=0.0, bytes=0.0, bound="mfma"):
         yield
     finally:
         b.record()
-        _records.setdefault(name, []).append((a, b, float(flops), float(bytes), bound))
+        _records.setdefault(name, []).append((a, b, float(flops), float(bytes), bound, peak))
 
 
 def stop():
@@ -48,15 +48,16 @@ def stop():
         ms = [a.elapsed_time(b) for a, b, *_ in recs]
         out[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                      "flops": sum(r[2] for r in recs) / len(recs),
-                     "bytes": sum(r[3] for r in recs) / len(recs), "bound": recs[0][4]}
+                     "bytes": sum(r[3] for r in recs) / len(recs), "bound": recs[0][4],
+                     "peak": recs[0][5]}
     _records.clear()
     return out
 
 
 # profiler scope name -> kernel symbol in the rocprofv3 PMC summary
-_PMC_NAMES = {"conv3d_m0_32_32": "conv3d_gather_kernel<32, 32, 0, 1, 0>",
-              "dgrad_m0_32_32": "conv3d_gather_kernel<32, 32, 0, 0, 0>",
-              "conv_wgrad_s1_32_32": "conv3d_wgrad_kernel<32, 32, 1>"}
+_PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_gather_kernel<32, 32, 0, 1, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 1, 0, 0>"),
+              "dgrad_m0_32_32": ("conv3d_gather_kernel<32, 32, 0, 0, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 0, 0, 0>"),
+              "conv_wgrad_s1_32_32": ("conv3d_wgrad_x6_kernel<32, 32, 1>", "conv3d_wgrad_kernel<32, 32, 1>")}
 
 
 def pmc_traffic(scope_name, per_launch_work, pmc_json):
@@ -70,7 +71,9 @@ def pmc_traffic(scope_name, per_launch_work, pmc_json):
     if not os.path.exists(pmc_json) or scope_name not in _PMC_NAMES:
         return None
     data = json.load(open(pmc_json))
-    k = data["kernels"].get(_PMC_NAMES[scope_name])
+    k = None
+    for sym in _PMC_NAMES[scope_name]:
+        k = k or data["kernels"].get(sym)
     probe_flops = 2.0 * 27 * 32 * 32 * data["tensor_bytes"] / (4 * 32)
     if not k or abs(probe_flops - per_launch_work) > 1e-6 * probe_flops:
         return None
@@ -83,9 +86,13 @@ def roofline(prof, pmc_json=None):
         return None
     name, r = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
     peak, unit = PEAK[r["bound"]]
+    peak_basis = "fp32 MFMA dense" if r["bound"] == "mfma" else "HBM3E spec"
+    if r.get("peak"):
+        peak, peak_basis = r["peak"]
     work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
     achieved = work / (r["avg_ms"] * 1e-3)
-    return {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak, "unit": unit,
+    return {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak,
+            "peak_basis": peak_basis, "unit": unit,
             "frac": achieved / peak,
             "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
             "avg_launch_ms": r["avg_ms"],

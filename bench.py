@@ -131,7 +131,7 @@ def main():
     device = torch.device("cuda", local_rank)
     azdist.init(args.dist_backend)  # "nccl" = RCCL on ROCm
 
-    from activezero_amd import agg3d, profiler
+    from activezero_amd import agg3d, conv3d, profiler
     from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
 
     if args.backend:
@@ -186,7 +186,11 @@ def main():
                                    f"supervised disparity loss, batch {args.batch} per GPU",
                        "global_batch": args.batch * world, "height": args.height,
                        "width": args.width, "maxdisp": args.maxdisp,
-                       "parallelism": f"dp{world}", "agg3d_backend": agg3d.BACKEND},
+                       "parallelism": f"dp{world}", "agg3d_backend": agg3d.BACKEND,
+                       "arithmetic": "fp32 results; conv/deconv/dgrad on "
+                                     + ("bf16x6 split MFMA" if conv3d.PRECISION else "fp32 MFMA")
+                                     + ", wgrad on " + ("bf16x6 split MFMA" if conv3d.WGRAD_PRECISION else "fp32 MFMA")
+                                     + ", fp32 accumulation everywhere"},
             "loss": float(loss.item()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
             "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "pmc_traffic_b4.json")),

@@ -157,8 +157,8 @@ int az_conv3d_fwd_stats(float *out, float *partials, float *counts, const float 
  * (coarse, fine) = (grad_out, input), dW of ConvTranspose3d with (input, grad_out). */
 long long az_conv3d_wgrad_workspace(int cm, int cn);
 int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
-                    const float *coarse, const float *fine, int stride, int B, int cm, int cn,
-                    int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream);
+                    const float *coarse, const float *fine, int stride, int precision, int B,
+                    int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream);
 
 /* 32 -> 1 classifier conv (psmnet_3.py:103-117) with the fused running sum
  * cost_k = classif_k(out_k) + cost_{k-1} (psmnet_3.py:177-179): logits [B,D,H,W] =

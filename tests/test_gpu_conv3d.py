@@ -24,12 +24,15 @@ def ncdhw(x):  # channels-last (gpu) -> NCDHW cpu
     return x.detach().permute(0, 4, 1, 2, 3).contiguous().cpu()
 
 
+DEFAULT_WGRAD = {0: "fp32", 1: "bf16x6"}[conv3d.WGRAD_PRECISION]
+
+
 @pytest.fixture(autouse=True, params=["bf16x6", "fp32"])
 def conv_precision(request):
     """every test of this file runs in both arithmetic modes of the gather kernels"""
-    conv3d.set_precision(request.param)
+    conv3d.set_precision(request.param, wgrad=request.param)
     yield request.param
-    conv3d.set_precision("bf16x6")
+    conv3d.set_precision("bf16x6", wgrad=DEFAULT_WGRAD)
 
 
 def close(a, b, rtol=1e-4, atol=1e-5):

@@ -67,3 +67,30 @@ def test_full_model_matches_reference_goldens(golden, variant, mod, nin):
     assert rel_l2(sd["dres4.conv5.0.weight"].grad[:4, :4], g["g_dres4_conv5_0"]) < 2e-2
     assert rel_l2(sd["feature_extraction.firstconv.0.0.weight"].grad[:4], g["g_fe_firstconv_0_0"]) < 5e-2
     close(dict(model.named_buffers())["dres0.0.1.running_var"], g["rv_dres0"], 1e-4, 1e-6)
+
+
+def test_config0_shape_eval_forward_vs_oracle():
+    """BASELINE.json configs[0]: one 256x512 pair, D=64, eval forward -- the reference's own
+    CPU-runnable case.  Weights procedural; BN running stats calibrated once on the oracle
+    (momentum-1 training pass) and copied, so the eval network is well conditioned."""
+    md = 64
+    oracle = load_procedural(po.PSMNetOracle(md, 3), "cfg0.")
+    il, ir = seeded((1, 3, 256, 512), 901, -2.0, 2.0), seeded((1, 3, 256, 512), 902, -2.0, 2.0)
+    bns = [m for m in oracle.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    for m in bns:
+        m.momentum = 1.0
+    oracle.train()
+    with torch.no_grad():
+        # the 64x64 SPP pooling leaves one value per channel at this size: calibrate on a
+        # 2-sample batch (the pair and its mirror) like the golden generator does
+        oracle(torch.cat([il, il.flip(3)]), torch.cat([ir, ir.flip(3)]))
+    oracle.eval()
+    with torch.no_grad():
+        ref = oracle(il, ir)
+    model = psm3.PSMNet(md)
+    model.load_state_dict(oracle.state_dict())
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model(il.to(DEV), ir.to(DEV))
+    assert out.shape == (1, 1, 256, 512)
+    disp_close(out, ref.numpy())
