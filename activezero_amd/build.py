@@ -20,6 +20,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libazhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("AZ_HIPCC_EXTRA", "").split()  # experiments, e.g. -DX6_VARIANT=1
 
 
 def _stale(target, deps):

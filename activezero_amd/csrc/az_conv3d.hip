@@ -38,9 +38,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CV_VS 36  // slab voxel stride in dwords
 #define CV_BAND 4 // tile rows per band of the block -> tile order
 #define X6_VS 52  // PREC 1 slab voxel stride in dwords
-#ifndef X6_BPIPE_PREC
-#define X6_BPIPE_PREC 0  // weight prefetch one tap ahead only in the fp32 path (registers)
-#endif
+// bf16x6 register policy (measured per shape, tools/conv_ab.py): with two N-tiles or the
+// stride-2 map the kernel takes the 1-wave/SIMD budget (512 registers) and prefetches the
+// weights one tap ahead; otherwise 2 waves/SIMD without weight prefetch.
+#define X6_WIDE(COUT, MODE, PREC) ((PREC) == 1 && (((COUT) == 64 && (MODE) != 2) || (MODE) == 1))
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -61,7 +62,7 @@ struct ConvArgs {
 };
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
-__global__ void __launch_bounds__(64, 2)
+__global__ void __launch_bounds__(64, X6_WIDE(COUT, MODE, PREC) ? 1 : 2)
 conv3d_gather_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32, NR = COUT / 32;
     constexpr int MR = (MODE == 1) ? 1 : 2;
@@ -71,7 +72,10 @@ conv3d_gather_kernel(const ConvArgs a) {
     // PREC 0: fp32 slab, 36 dwords per voxel.  PREC 1: three bf16 planes (hi, mid, lo) of 32
     // channels each, 52 dwords per voxel (3 x 64 B + 16 B bank padding).
     constexpr int VS = (PREC == 0) ? CV_VS : X6_VS;
-    __shared__ __attribute__((aligned(16))) float slab[SY * SX * VS];
+    // LDS row pitch of the slab in voxels: SX, or padded (X6_ROWPAD) so that the A-fragment
+    // ds_read_b128 of a 4x8-voxel M-tile is bank-conflict free (rows 24 voxels apart)
+    constexpr int SXP = (X6_WIDE(COUT, MODE, PREC) && MODE == 0) ? 24 : SX;
+    __shared__ __attribute__((aligned(16))) float slab[SY * SXP * VS];
 
     const int lane = threadIdx.x;
     // ---- block -> tile map -------------------------------------------------------------
@@ -138,7 +142,7 @@ conv3d_gather_kernel(const ConvArgs a) {
     // stage s run; weights are fetched one tap ahead.
     constexpr int NQ = SY * SX * 8;          // float4 pieces of one slab
     constexpr int NLD = (NQ + 63) / 64;      // pieces per lane
-    constexpr bool BPIPE = (NR == 1) && (PREC == X6_BPIPE_PREC);
+    constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : X6_WIDE(COUT, MODE, PREC);
     const int NS = nd * NCH;
     float4 pre[NLD];
 
@@ -188,28 +192,23 @@ conv3d_gather_kernel(const ConvArgs a) {
         }
     };
     auto commit = [&]() {
+        int sy = (lane >> 3) / SX, sx = (lane >> 3) - sy * SX;
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int q = lane + 64 * it;
+            const int vox = sy * SXP + sx;
             if (PREC == 0) {
-                if (q < NQ) *reinterpret_cast<float4 *>(&slab[(q >> 3) * CV_VS + (q & 7) * 4]) = pre[it];
+                if (q < NQ) *reinterpret_cast<float4 *>(&slab[vox * CV_VS + (q & 7) * 4]) = pre[it];
             } else if (q < NQ) {
-                // exact 3-way split x = hi + mid + lo into bf16 by truncation (8+8+8 significand bits)
-                const float xs[4] = {pre[it].x, pre[it].y, pre[it].z, pre[it].w};
-                unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    hi[e] = __float_as_uint(xs[e]) & 0xffff0000u;
-                    const float r1 = xs[e] - __uint_as_float(hi[e]);
-                    mid[e] = __float_as_uint(r1) & 0xffff0000u;
-                    const float r2 = r1 - __uint_as_float(mid[e]);
-                    lo[e] = __float_as_uint(r2) & 0xffff0000u;
-                }
-                unsigned *dst = reinterpret_cast<unsigned *>(slab) + (q >> 3) * X6_VS + (q & 7) * 2;
-                *reinterpret_cast<uint2 *>(dst) = make_uint2((hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]);
-                *reinterpret_cast<uint2 *>(dst + 16) = make_uint2((mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]);
-                *reinterpret_cast<uint2 *>(dst + 32) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+                uint2 hi, mid, lo;
+                az_split3_bf16x4(pre[it], hi, mid, lo);
+                unsigned *dst = reinterpret_cast<unsigned *>(slab) + vox * X6_VS + (q & 7) * 2;
+                *reinterpret_cast<uint2 *>(dst) = hi;
+                *reinterpret_cast<uint2 *>(dst + 16) = mid;
+                *reinterpret_cast<uint2 *>(dst + 32) = lo;
             }
+            sx += 8;
+            if (sx >= SX) { sx -= SX; ++sy; }
         }
     };
     // 16-byte operand pieces per (tile, tap, chunk): fp32 -> 4 (k = 16*half + 4j..4j+3);
@@ -249,11 +248,11 @@ conv3d_gather_kernel(const ConvArgs a) {
             const int sy = ((MODE == 1) ? 2 * rty : rty) + eh_;
             const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew_;
             if (PREC == 0) {
-                const float *ap = &slab[(sy * SX + sx) * CV_VS + 16 * half];
+                const float *ap = &slab[(sy * SXP + sx) * CV_VS + 16 * half];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
             } else {
-                const float *ap = &slab[(sy * SX + sx) * X6_VS + 4 * half];
+                const float *ap = &slab[(sy * SXP + sx) * X6_VS + 4 * half];
 #pragma unroll
                 for (int f = 0; f < 6; ++f)  // part f>>1 at +16 dwords, K16 block f&1 at +8 dwords
                     aq[f] = *reinterpret_cast<const float4 *>(ap + (f >> 1) * 16 + (f & 1) * 8);
@@ -288,33 +287,35 @@ conv3d_gather_kernel(const ConvArgs a) {
         // tile 1's while tile 0 multiplies, the next tap's tile 0 while tile 1 multiplies.
         float4 a0[NF], a1[NF];
         load_a(a0, 0, eh, ew);
-        for (int t = 0; t < ntaps; ++t) {
-            tap_of(kd, t, eh, ew);
-            if (MR == 2) load_a(a1, 1, eh, ew);
-            // weights one tap ahead when registers allow (NR == 1); with two N-tiles the
-            // second resident wave hides the L2 latency instead
-            float4 bn[BPIPE ? NR : 1][NF];
-            int eh2 = 0, ew2 = 0;
+        // one tap: `cur` holds this tap's weights, `nxt` receives the next tap's (ping-pong
+        // buffers, so the prefetch costs no register copies)
+        auto tap_body = [&](int t, float4 (&cur)[NR][NF], float4 (&nxt)[NR][NF]) {
+            int eh_, ew_, eh2 = 0, ew2 = 0;
+            const int tap = tap_of(kd, t, eh_, ew_);
+            if (MR == 2) load_a(a1, 1, eh_, ew_);
             if (t + 1 < ntaps) {
                 const int tap2 = tap_of(kd, t + 1, eh2, ew2);
-                if (BPIPE) load_b(bn, tap2, cc);
+                if (BPIPE) load_b(nxt, tap2, cc);
             }
-            if (!BPIPE && t > 0) load_b(bq, tap_of(kd, t, eh, ew), cc);
+            if (!BPIPE && t > 0) load_b(cur, tap, cc);
             // hipcc otherwise sinks the LDS reads next to their consumers (register pressure)
             // and every MFMA quad then waits on a just-issued ds_read: pin the written order
             __builtin_amdgcn_sched_barrier(0);
-            mfma16(acc[0], a0, bq);
+            mfma16(acc[0], a0, cur);
             __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < ntaps) load_a(a0, 0, eh2, ew2);
             __builtin_amdgcn_sched_barrier(0);
-            if (MR == 2) mfma16(acc[MR - 1], a1, bq);
+            if (MR == 2) mfma16(acc[MR - 1], a1, cur);
             __builtin_amdgcn_sched_barrier(0);
-            if (BPIPE && t + 1 < ntaps) {
-#pragma unroll
-                for (int n = 0; n < NR; ++n)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) bq[n][j] = bn[n][j];
+        };
+        if (BPIPE) {
+            float4 bq2[NR][NF];
+            for (int t = 0; t < ntaps; t += 2) {
+                tap_body(t, bq, bq2);
+                if (t + 1 < ntaps) tap_body(t + 1, bq2, bq);
             }
+        } else {
+            for (int t = 0; t < ntaps; ++t) tap_body(t, bq, bq);
         }
     }
 

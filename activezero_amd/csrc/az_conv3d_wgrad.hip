@@ -227,20 +227,12 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
     const int tr_row = 8 * (lane >> 5) + tq;  // + 4 for the second read
 
     auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v) {
-        // exact 3-way bf16 split by truncation; dst_part0 points at 4 channels of part 0
-        const float xs[4] = {v.x, v.y, v.z, v.w};
-        unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            hi[e] = __float_as_uint(xs[e]) & 0xffff0000u;
-            const float r1 = xs[e] - __uint_as_float(hi[e]);
-            mid[e] = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(mid[e]);
-            lo[e] = __float_as_uint(r2) & 0xffff0000u;
-        }
-        *reinterpret_cast<uint2 *>(dst_part0) = make_uint2((hi[0] >> 16) | hi[1], (hi[2] >> 16) | hi[3]);
-        *reinterpret_cast<uint2 *>(dst_part0 + part_stride) = make_uint2((mid[0] >> 16) | mid[1], (mid[2] >> 16) | mid[3]);
-        *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = make_uint2((lo[0] >> 16) | lo[1], (lo[2] >> 16) | lo[3]);
+        // exact 3-way bf16 split; dst_part0 points at 4 channels of part 0
+        uint2 hi, mid, lo;
+        az_split3_bf16x4(v, hi, mid, lo);
+        *reinterpret_cast<uint2 *>(dst_part0) = hi;
+        *reinterpret_cast<uint2 *>(dst_part0 + part_stride) = mid;
+        *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = lo;
     };
     // fragment of 8 consecutive K rows (positions) for this lane's column, rows given by rowfn(k)
     auto frag = [&](const unsigned short *img, int r0, int r1) -> bf16x8 {
