@@ -323,31 +323,40 @@ conv3d_gather_kernel(const ConvArgs a) {
     // C/D map of 32x32 MFMA: column (out channel) = lane & 31, row (voxel) =
     // (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const int od = (MODE == 2) ? 2 * td + pd : td;
-    // output voxel of accumulator register r of M-tile m: returns validity + element base
-    auto voxel = [&](int m, int r, size_t &base) -> bool {
+    // Addresses: wave-uniform 64-bit plane base + 32-bit offsets.  A tile that lies completely
+    // inside the output (every interior tile) takes the branch-free path.
+    const size_t plane_el = (((size_t)b * a.Do + od) * a.Ho) * a.Wo * COUT;
+    float *outp = a.out + plane_el;
+    const float *resp = a.res ? a.res + plane_el : nullptr;
+    const int ohs = (MODE == 2) ? 2 : 1;  // output step per index-space step
+    const int oh_base = (MODE == 2) ? 2 * ty0 + ph : ty0, ow_base = (MODE == 2) ? 2 * tx0 + pw : tx0;
+    const bool full = (oh_base + ohs * (TY - 1) < a.Ho) && (ow_base + ohs * (TX - 1) < a.Wo);
+    // offset (in floats) of accumulator register r of M-tile m, and its validity
+    auto voxel = [&](int m, int r, unsigned &off) -> bool {
         const int vrow = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int ty = ty0 + (vrow >> 3), tx = tx0 + (vrow & 7) + 8 * m;
-        const int oh = (MODE == 2) ? 2 * ty + ph : ty;
-        const int ow = (MODE == 2) ? 2 * tx + pw : tx;
-        base = ((((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow) * COUT;
-        return (oh < a.Ho) && (ow < a.Wo);
+        const int oh = oh_base + ohs * (vrow >> 3), ow = ow_base + ohs * ((vrow & 7) + 8 * m);
+        off = (unsigned)(oh * a.Wo + ow) * COUT + row;
+        return full || ((oh < a.Ho) && (ow < a.Wo));
     };
     if (EPI == 0) {
+        float sc[NR], sf[NR];
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            sc[n] = a.scale ? a.scale[n * 32 + row] : 1.f;
+            sf[n] = a.shift ? a.shift[n * 32 + row] : 0.f;
+        }
 #pragma unroll
         for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                size_t base;
-                if (!voxel(m, r, base)) continue;
+                unsigned off;
+                if (!voxel(m, r, off)) continue;
 #pragma unroll
                 for (int n = 0; n < NR; ++n) {
-                    const int co = n * 32 + row;
-                    float y = acc[m][n][r];
-                    if (a.scale) y *= a.scale[co];
-                    if (a.shift) y += a.shift[co];
-                    if (a.res) y += a.res[base + co];
+                    float y = acc[m][n][r] * sc[n] + sf[n];
+                    if (resp) y += resp[off + n * 32];
                     if (a.relu) y = fmaxf(y, 0.f);
-                    a.out[base + co] = y;
+                    outp[off + n * 32] = y;
                 }
             }
     } else {
@@ -357,33 +366,48 @@ conv3d_gather_kernel(const ConvArgs a) {
         for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                size_t base;
-                const bool ok = voxel(m, r, base);
+                unsigned off;
+                const bool ok = voxel(m, r, off);
                 if (ok) {
                     okmask |= 1u << (m * 16 + r);
                     nvalid++;
 #pragma unroll
-                    for (int n = 0; n < NR; ++n) a.out[base + n * 32 + row] = acc[m][n][r];
+                    for (int n = 0; n < NR; ++n) outp[off + n * 32] = acc[m][n][r];
                 }
             }
         const int ntot = nvalid + __shfl_xor(nvalid, 32);
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
-            float s = 0.f;
+            float s = 0.f, m2 = 0.f;
+            if (full) {  // wave-uniform: no masking
 #pragma unroll
-            for (int m = 0; m < MR; ++m)
+                for (int m = 0; m < MR; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += ((okmask >> (m * 16 + r)) & 1u) ? acc[m][n][r] : 0.f;
-            s += __shfl_xor(s, 32);
-            const float mean = s / (float)max(ntot, 1);
-            float m2 = 0.f;
+                    for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+                s += __shfl_xor(s, 32);
+                const float mean = s / (float)(MR * 32);
 #pragma unroll
-            for (int m = 0; m < MR; ++m)
+                for (int m = 0; m < MR; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float dlt = acc[m][n][r] - mean;
-                    m2 += ((okmask >> (m * 16 + r)) & 1u) ? dlt * dlt : 0.f;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float dlt = acc[m][n][r] - mean;
+                        m2 += dlt * dlt;
+                    }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s += ((okmask >> (m * 16 + r)) & 1u) ? acc[m][n][r] : 0.f;
+                s += __shfl_xor(s, 32);
+                const float mean = s / (float)max(ntot, 1);
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float dlt = acc[m][n][r] - mean;
+                        m2 += ((okmask >> (m * 16 + r)) & 1u) ? dlt * dlt : 0.f;
+                    }
+            }
             m2 += __shfl_xor(m2, 32);
             if (half == 0) {
                 const int co = n * 32 + row;
@@ -392,25 +416,6 @@ conv3d_gather_kernel(const ConvArgs a) {
         }
         if (lane == 0) a.cnt[tile_id] = (float)ntot;
     }
-}
-
-// ---- weight packing -----------------------------------------------------------------
-// packed[((tap*NCH + cc)*NR + n)*1024 + j*256 + lane*4 + e] =
-//     src[(n*32 + (lane&31))*sn + (cc*32 + 16*(lane>>5) + 4*j + e)*sk + (flip ? 26-tap : tap)]
-__global__ void __launch_bounds__(256)
-conv3d_pack_kernel(float *__restrict__ dst, const float *__restrict__ src, int cin, int cout,
-                   long long sn, long long sk, int flip, int total) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int e = idx & 3, lane = (idx >> 2) & 63, j = (idx >> 8) & 3;
-    int r = idx >> 10;
-    const int nr = cout / 32, nch = cin / 32;
-    const int n = r % nr; r /= nr;
-    const int cc = r % nch;
-    const int tap = r / nch;
-    const int co = n * 32 + (lane & 31);
-    const int ci = cc * 32 + 16 * (lane >> 5) + 4 * j + e;
-    dst[idx] = src[co * sn + ci * sk + (flip ? 26 - tap : tap)];
 }
 
 // bf16x6 packing: [tap][cc][n][part(3)][kb(2)][lane(64)][8] bf16, element j of lane =
