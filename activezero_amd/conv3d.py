@@ -296,3 +296,50 @@ def conv_plain(x, weight, mode):
     """Bare convolution (no BN), forward only -- used by parity tests and tools."""
     packed, cin, cout = _pack_forward(weight, mode)
     return _run_gather(_chk(x, "x"), packed, mode, cin, cout)
+
+
+# ----------------------------------------------------------------------------
+# 2-D layers of the adjacent feature extractor on the same kernels (SURVEY.md 8f-1)
+# ----------------------------------------------------------------------------
+class _Lift2d(torch.autograd.Function):
+    """[Cout,Cin,3,3] -> [Cout,Cin,3,3,3] with the 2-D kernel in the centre depth slice.
+    A [B,C,H,W] channels-last image is a [B,1,H,W,C] volume; with D = 1 the kd = 0 / kd = 2
+    planes are zero padding and the gather / wgrad kernels skip them, so a 3x3 stride-1 conv2d
+    costs exactly its own 9 taps."""
+
+    @staticmethod
+    def forward(ctx, w2d):
+        w3 = w2d.new_zeros(*w2d.shape[:2], 3, 3, 3)
+        w3[:, :, 1] = w2d
+        return w3
+
+    @staticmethod
+    def backward(ctx, g3):
+        return g3[:, :, 1].contiguous()
+
+
+def supports_2d(conv):
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.dilation == (1, 1) and conv.padding == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.in_channels in (32, 64) and conv.out_channels in (32, 64))
+
+
+def _as_volume(x):
+    """[B,C,H,W] (any strides) -> contiguous channels-last volume [B,1,H,W,C]; zero-copy when
+    the tensor already is torch.channels_last."""
+    return x.permute(0, 2, 3, 1).contiguous().unsqueeze(1)
+
+
+def _as_image(v):
+    """[B,1,H,W,C] volume -> [B,C,H,W] tensor in channels_last memory format (a view)."""
+    return v.squeeze(1).permute(0, 3, 1, 2)
+
+
+def conv_bn_2d(x, conv, bn, relu=False, residual=None):
+    """relu?(BatchNorm2d(Conv2d 3x3 s1 p1 (x)) + residual) on the MFMA gather kernels."""
+    if not supports_2d(conv):
+        raise RuntimeError("conv_bn_2d: unsupported layer")
+    res = _as_volume(residual) if residual is not None else None
+    y = _ConvBN.apply(_as_volume(x), _Lift2d.apply(conv.weight), bn.weight, bn.bias, res, bn, CONV_S1,
+                      relu, torch.is_grad_enabled())
+    return _as_image(y)

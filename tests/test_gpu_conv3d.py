@@ -226,3 +226,27 @@ def test_fused_cost_volume_conv_equals_materialised():
         agg3d.FUSE_COST_VOLUME = True
     assert torch.equal(y_fused, y_mat)
     close(ncdhw(y_fused), ref, 1e-4, 2e-5)
+
+
+def test_conv_bn_2d_unit_matches_torch_modules():
+    """The opt-in 2-D route (D=1 volumes through the gather kernels) against the plain
+    nn.Conv2d + nn.BatchNorm2d modules it replaces, forward and backward."""
+    from activezero_amd.nets.psmnet import psmnet_submodule_3 as sm
+
+    unit = load_procedural(sm.convbn(64, 64, 3, 1, 1, 1), "t.cb2d.").to(DEV).train()
+    ref = load_procedural(sm.convbn(64, 64, 3, 1, 1, 1), "t.cb2d.").train()
+    x, res = seeded((2, 64, 20, 36), 61), seeded((2, 64, 20, 36), 62)
+    ct = seeded((2, 64, 20, 36), 63)
+    xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
+    yr = F.relu(ref(xr) + rr)
+    yr.backward(ct)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    rg = res.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = conv3d.conv_bn_2d(xg, unit[0], unit[1], relu=True, residual=rg)
+    close(y, yr, 1e-4, 5e-5)
+    y.backward(ct.to(DEV))
+    close(xg.grad, xr.grad, 1e-3, 1e-4)
+    close(rg.grad, rr.grad, 1e-5, 1e-6)
+    close(unit[0].weight.grad, ref[0].weight.grad, 1e-3, 3e-4)
+    close(unit[1].weight.grad, ref[1].weight.grad, 1e-3, 1e-3)
+    close(unit[1].running_var, ref[1].running_var, 1e-5, 1e-6)
