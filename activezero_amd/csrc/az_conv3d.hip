@@ -418,6 +418,25 @@ conv3d_gather_kernel(const ConvArgs a) {
     }
 }
 
+// ---- weight packing -----------------------------------------------------------------
+// packed[((tap*NCH + cc)*NR + n)*1024 + j*256 + lane*4 + e] =
+//     src[(n*32 + (lane&31))*sn + (cc*32 + 16*(lane>>5) + 4*j + e)*sk + (flip ? 26-tap : tap)]
+__global__ void __launch_bounds__(256)
+conv3d_pack_kernel(float *__restrict__ dst, const float *__restrict__ src, int cin, int cout,
+                   long long sn, long long sk, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 3, lane = (idx >> 2) & 63, j = (idx >> 8) & 3;
+    int r = idx >> 10;
+    const int nr = cout / 32, nch = cin / 32;
+    const int n = r % nr; r /= nr;
+    const int cc = r % nch;
+    const int tap = r / nch;
+    const int co = n * 32 + (lane & 31);
+    const int ci = cc * 32 + 16 * (lane >> 5) + 4 * j + e;
+    dst[idx] = src[co * sn + ci * sk + (flip ? 26 - tap : tap)];
+}
+
 // bf16x6 packing: [tap][cc][n][part(3)][kb(2)][lane(64)][8] bf16, element j of lane =
 // part `p` of src(co = n*32 + (lane&31), ci = cc*32 + 16*kb + 8*(lane>>5) + j, tap)
 __global__ void __launch_bounds__(256)
