@@ -42,8 +42,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // stride-2 map the kernel takes the 1-wave/SIMD budget (512 registers) and prefetches the
 // weights one tap ahead; otherwise 2 waves/SIMD without weight prefetch.
 #define X6_WIDE(COUT, MODE, PREC) ((PREC) == 1 && (((COUT) == 64 && (MODE) != 2) || (MODE) == 1))
+// (Tried and dropped: a 3-deep register ring streaming the weights two taps ahead under the
+//  1-wave/SIMD budget for every shape -- 2.76 ms vs 2.2 ms on 32->32: one wave per SIMD cannot
+//  hide its own commit / epilogue phases, and the fully unrolled ring spills into AGPRs.)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Diagnostic build only (-DCV_STAMP): per-phase cycle sums of every wave, added to a global
+// array that nothing else reads (cdna_hip_programming.md, In-kernel stamps).
+#ifdef CV_STAMP
+__device__ unsigned long long cv_stamp_sum[8];
+#define CV_T0() cv_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#define CV_ACC(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long cv_t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); cv_acc[i] += cv_t1 - cv_t0; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CV_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&cv_stamp_sum[i_], cv_acc[i_]); atomicAdd(&cv_stamp_sum[5], 1ull); } } while (0)
+#else
+#define CV_T0()
+#define CV_ACC(i)
+#define CV_FLUSH()
+#endif
 
 struct ConvArgs {
     const float *in;    // NDHWC input (coarse tensor for MODE 2); SRC 1: left features NHWC
@@ -77,6 +93,9 @@ conv3d_gather_kernel(const ConvArgs a) {
     constexpr int SXP = (X6_WIDE(COUT, MODE, PREC) && MODE == 0) ? 24 : SX;
     __shared__ __attribute__((aligned(16))) float slab[SY * SXP * VS];
 
+#ifdef CV_STAMP
+    unsigned long long cv_acc[5] = {0, 0, 0, 0, 0}, cv_t0 = 0;
+#endif
     const int lane = threadIdx.x;
     // ---- block -> tile map -------------------------------------------------------------
     // (1) XCD-aware: blocks b and b+8 share an XCD (and its 4 MB L2); hand every XCD one
@@ -145,6 +164,7 @@ conv3d_gather_kernel(const ConvArgs a) {
     constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : X6_WIDE(COUT, MODE, PREC);
     const int NS = nd * NCH;
     float4 pre[NLD];
+    unsigned okbits = 0;  // bit it: pre[it] holds real data (else zero padding)
 
     auto plane_of = [&](int sd) -> int {
         return (MODE == 0) ? td - 1 + sd : (MODE == 1) ? 2 * td - 1 + sd : td + (pd ? sd : 0);
@@ -154,8 +174,8 @@ conv3d_gather_kernel(const ConvArgs a) {
         const int id = plane_of(sd);
         const bool pok = id >= 0 && id < a.Di;
         const int idc = min(max(id, 0), a.Di - 1);
-        bool okv[NLD];
-        // pass 1: every load is issued unconditionally from a clamped (always valid)
+        okbits = 0;
+        // every load is issued unconditionally from a clamped (always valid)
         // address, so all NLD requests are in flight together.  Address = wave-uniform
         // 64-bit plane base + 32-bit per-lane offset; a wave-instruction covers 8 slab
         // voxels, so (sy, sx) advance by 8 voxels per iteration without divisions.
@@ -178,18 +198,12 @@ conv3d_gather_kernel(const ConvArgs a) {
                 off = (unsigned)(ihc * a.Wi + iwr) * 32 + part4;
             }
             pre[it] = *reinterpret_cast<const float4 *>(plane0 + off);
-            okv[it] = ok;
+            okbits |= ok ? (1u << it) : 0u;
             sx += 8;
             if (sx >= SX) { sx -= SX; ++sy; }
         }
-        // pass 2: ... and padding is applied afterwards with scalar selects
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            pre[it].x = okv[it] ? pre[it].x : 0.f;
-            pre[it].y = okv[it] ? pre[it].y : 0.f;
-            pre[it].z = okv[it] ? pre[it].z : 0.f;
-            pre[it].w = okv[it] ? pre[it].w : 0.f;
-        }
+        // (padding is applied at commit time, after the MFMAs this prefetch hides under: touching
+        //  the loaded registers here would put the whole memory latency back on the critical path)
     };
     auto commit = [&]() {
         int sy = (lane >> 3) / SX, sx = (lane >> 3) - sy * SX;
@@ -197,6 +211,7 @@ conv3d_gather_kernel(const ConvArgs a) {
         for (int it = 0; it < NLD; ++it) {
             const int q = lane + 64 * it;
             const int vox = sy * SXP + sx;
+            if (!((okbits >> it) & 1u)) pre[it] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding
             if (PREC == 0) {
                 if (q < NQ) *reinterpret_cast<float4 *>(&slab[vox * CV_VS + (q & 7) * 4]) = pre[it];
             } else if (q < NQ) {
@@ -231,58 +246,67 @@ conv3d_gather_kernel(const ConvArgs a) {
         return (kd * 3 + kh) * 3 + kw;
     };
 
+    // shared by both loop variants
+    auto load_a = [&](float4 (&aq)[NF], int m, int eh_, int ew_) {
+        const int sy = ((MODE == 1) ? 2 * rty : rty) + eh_;
+        const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew_;
+        if (PREC == 0) {
+            const float *ap = &slab[(sy * SXP + sx) * CV_VS + 16 * half];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
+        } else {
+            const float *ap = &slab[(sy * SXP + sx) * X6_VS + 4 * half];
+#pragma unroll
+            for (int f = 0; f < 6; ++f)  // part f>>1 at +16 dwords, K16 block f&1 at +8 dwords
+                aq[f] = *reinterpret_cast<const float4 *>(ap + (f >> 1) * 16 + (f & 1) * 8);
+        }
+    };
+    auto mfma16 = [&](f32x16 (&c)[NR], const float4 (&aq)[NF], const float4 (&bw)[NR][NF]) {
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+            if (PREC == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bw[n][j].x, c[n], 0, 0, 0);
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bw[n][j].y, c[n], 0, 0, 0);
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bw[n][j].z, c[n], 0, 0, 0);
+                    c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
+                }
+            } else {
+                // fp32 product on the bf16 pipe: (ah+am+al)(bh+bm+bl) without the three
+                // terms below 2^-24: six v_mfma_f32_32x32x16_bf16 per 16-deep K block,
+                // smallest terms first
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#define X6(A, B) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
+                    __builtin_bit_cast(bf16x8, aq[(A) * 2 + kb]), __builtin_bit_cast(bf16x8, bw[n][(B) * 2 + kb]), c[n], 0, 0, 0)
+                    X6(2, 0); X6(0, 2); X6(1, 1); X6(1, 0); X6(0, 1); X6(0, 0);
+#undef X6
+                }
+            }
+        }
+    };
+
+    CV_T0();
     issue(0);
+    CV_ACC(0);
     for (int s = 0; s < NS; ++s) {
         const int sd = s / NCH, cc = s - sd * NCH;
         const int kd = (MODE == 2) ? (pd ? 2 - 2 * sd : 1) : sd;
         const int id = plane_of(sd);
         __syncthreads();  // previous slab fully consumed (single-wave group: fence only)
+        CV_T0();
         commit();
+        CV_ACC(1);
         __syncthreads();
         float4 bq[NR][NF];
         int eh, ew;
         load_b(bq, tap_of(kd, 0, eh, ew), cc);
+        CV_T0();
         if (s + 1 < NS) issue(s + 1);
+        CV_ACC(2);
+        CV_T0();
         if (id < 0 || id >= a.Di) continue;  // wave-uniform: a zero-padding plane
-        auto load_a = [&](float4 (&aq)[NF], int m, int eh_, int ew_) {
-            const int sy = ((MODE == 1) ? 2 * rty : rty) + eh_;
-            const int sx = ((MODE == 1) ? 2 * (rtx + 8 * m) : (rtx + 8 * m)) + ew_;
-            if (PREC == 0) {
-                const float *ap = &slab[(sy * SXP + sx) * CV_VS + 16 * half];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
-            } else {
-                const float *ap = &slab[(sy * SXP + sx) * X6_VS + 4 * half];
-#pragma unroll
-                for (int f = 0; f < 6; ++f)  // part f>>1 at +16 dwords, K16 block f&1 at +8 dwords
-                    aq[f] = *reinterpret_cast<const float4 *>(ap + (f >> 1) * 16 + (f & 1) * 8);
-            }
-        };
-        auto mfma16 = [&](f32x16 (&c)[NR], const float4 (&aq)[NF], const float4 (&bw)[NR][NF]) {
-#pragma unroll
-            for (int n = 0; n < NR; ++n) {
-                if (PREC == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bw[n][j].x, c[n], 0, 0, 0);
-                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].y, bw[n][j].y, c[n], 0, 0, 0);
-                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bw[n][j].z, c[n], 0, 0, 0);
-                        c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
-                    }
-                } else {
-                    // fp32 product on the bf16 pipe: (ah+am+al)(bh+bm+bl) without the three
-                    // terms below 2^-24: six v_mfma_f32_32x32x16_bf16 per 16-deep K block,
-                    // smallest terms first
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-#define X6(A, B) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
-                        __builtin_bit_cast(bf16x8, aq[(A) * 2 + kb]), __builtin_bit_cast(bf16x8, bw[n][(B) * 2 + kb]), c[n], 0, 0, 0)
-                        X6(2, 0); X6(0, 2); X6(1, 1); X6(1, 0); X6(0, 1); X6(0, 0);
-#undef X6
-                    }
-                }
-            }
-        };
         // A fragments are read one MFMA block (16*NR instructions) ahead of their use:
         // tile 1's while tile 0 multiplies, the next tap's tile 0 while tile 1 multiplies.
         float4 a0[NF], a1[NF];
@@ -317,8 +341,10 @@ conv3d_gather_kernel(const ConvArgs a) {
         } else {
             for (int t = 0; t < ntaps; ++t) tap_body(t, bq, bq);
         }
+        CV_ACC(3);
     }
 
+    CV_T0();
     // ---- epilogue ---------------------------------------------------------------------
     // C/D map of 32x32 MFMA: column (out channel) = lane & 31, row (voxel) =
     // (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -416,6 +442,8 @@ conv3d_gather_kernel(const ConvArgs a) {
         }
         if (lane == 0) a.cnt[tile_id] = (float)ntot;
     }
+    CV_ACC(4);
+    CV_FLUSH();
 }
 
 // ---- weight packing -----------------------------------------------------------------
@@ -516,6 +544,14 @@ static int conv_tiles(int mode, int Di, int Hi, int Wi, int &Dt, int &ty, int &t
     else { Dt = Do; ty = (Ho + 3) / 4; tx = (Wo + TX - 1) / TX; }
     return 0;
 }
+
+#ifdef CV_STAMP
+extern "C" int az_debug_conv_stamps(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cv_stamp_sum), 8 * sizeof(unsigned long long)) != hipSuccess) return AZ_ELAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cv_stamp_sum), z, sizeof(z)) != hipSuccess) return AZ_ELAUNCH; }
+    return AZ_OK;
+}
+#endif
 
 extern "C" long long az_conv3d_num_tiles(int mode, int B, int Di, int Hi, int Wi) {
     if (mode < 0 || mode > 2 || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return AZ_EINVAL;
