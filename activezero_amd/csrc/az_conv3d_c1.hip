@@ -116,13 +116,11 @@ c1_dgrad_kernel(float *__restrict__ gin, const float *__restrict__ gout,
 
 __global__ void __launch_bounds__(256)
 c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
-                const float *__restrict__ gout, int D, int H, int W, int tiles_x) {
+                const float *__restrict__ gout, int D, int H, int W, int tiles_x, int tiles_y,
+                long long ntiles) {
     constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
     __shared__ float gt[3 * SY * SX];
     __shared__ float red[864];
-    const int tx0 = (blockIdx.x % tiles_x) * C1_TW, ty0 = (blockIdx.x / tiles_x) * C1_TH;
-    const int od = blockIdx.y, b = blockIdx.z;
-    c1_load_gtile(gt, gout, b, od, ty0, tx0, D, H, W);
     for (int q = threadIdx.x; q < 864; q += 256) red[q] = 0.f;
     const int quad = threadIdx.x & 7, vl = threadIdx.x >> 3;
     float acc[4][27];
@@ -130,25 +128,36 @@ c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int t = 0; t < 27; ++t) acc[c][t] = 0.f;
-    __syncthreads();
-    for (int p = 0; p < C1_TH; ++p) {
-        const int ly = p, lx = vl;
-        const int ih = ty0 + ly, iw = tx0 + lx;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ih < H && iw < W)
-            x = *reinterpret_cast<const float4 *>(in + ((((size_t)b * D + od) * H + ih) * W + iw) * 32 + quad * 4);
+    // a block walks a strided list of (b, d, tile) items and keeps its 108 partial sums per
+    // lane in registers, so the 864 global atomics are paid once per block, not once per tile
+    for (long long item = blockIdx.x; item < ntiles; item += gridDim.x) {
+        long long r = item;
+        const int tx0 = (int)(r % tiles_x) * C1_TW; r /= tiles_x;
+        const int ty0 = (int)(r % tiles_y) * C1_TH; r /= tiles_y;
+        const int od = (int)(r % D);
+        const int b = (int)(r / D);
+        __syncthreads();
+        c1_load_gtile(gt, gout, b, od, ty0, tx0, D, H, W);
+        __syncthreads();
+        for (int p = 0; p < C1_TH; ++p) {
+            const int ly = p, lx = vl;
+            const int ih = ty0 + ly, iw = tx0 + lx;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ih < H && iw < W)
+                x = *reinterpret_cast<const float4 *>(in + ((((size_t)b * D + od) * H + ih) * W + iw) * 32 + quad * 4);
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd)
+            for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    // out[o] = sum_k in[o - 1 + k] w[k]  =>  gw[k] += in[v] * gout[v + 1 - k]
-                    const float g = gt[((2 - kd) * SY + (ly + 2 - kh)) * SX + lx + 2 - kw];
-                    const int t = (kd * 3 + kh) * 3 + kw;
-                    acc[0][t] += x.x * g; acc[1][t] += x.y * g;
-                    acc[2][t] += x.z * g; acc[3][t] += x.w * g;
-                }
+                    for (int kw = 0; kw < 3; ++kw) {
+                        // out[o] = sum_k in[o - 1 + k] w[k]  =>  gw[k] += in[v] * gout[v + 1 - k]
+                        const float g = gt[((2 - kd) * SY + (ly + 2 - kh)) * SX + lx + 2 - kw];
+                        const int t = (kd * 3 + kh) * 3 + kw;
+                        acc[0][t] += x.x * g; acc[1][t] += x.y * g;
+                        acc[2][t] += x.z * g; acc[3][t] += x.w * g;
+                    }
+        }
     }
     // reduce the 32 voxel-lanes that share a channel quad: lanes with equal (lane & 7);
     // xor-shuffle over lane bits 3..5 inside the wave, then LDS atomics across the 4 waves.
@@ -198,7 +207,9 @@ extern "C" int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *g
     if (hipMemsetAsync(grad_w, 0, 864 * sizeof(float), az_stream(stream)) != hipSuccess)
         return AZ_ELAUNCH;
     const int tiles_x = (W + C1_TW - 1) / C1_TW, tiles_y = (H + C1_TH - 1) / C1_TH;
-    hipLaunchKernelGGL(c1_wgrad_kernel, dim3(tiles_x * tiles_y, D, B), dim3(256), 0,
-                       az_stream(stream), grad_w, in, grad_logits, D, H, W, tiles_x);
+    const long long ntiles = (long long)B * D * tiles_y * tiles_x;
+    const unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);
+    hipLaunchKernelGGL(c1_wgrad_kernel, dim3(grid), dim3(256), 0, az_stream(stream), grad_w, in,
+                       grad_logits, D, H, W, tiles_x, tiles_y, ntiles);
     return az_launch_status();
 }
