@@ -83,23 +83,24 @@ cost_volume_bwd_ncdhw(float *__restrict__ gl, float *__restrict__ gr,
 // ---- channels-last ----------------------------------------------------------
 __global__ void __launch_bounds__(256)
 cost_volume_fwd_ndhwc(float4 *__restrict__ cost, const float4 *__restrict__ fl,
-                      const float4 *__restrict__ fr, int C4, int d, int h, int w,
-                      long long total4) {
-    // index over [B, d, h, w, 2*C4] float4 elements
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total4;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int c = idx % (2 * C4);
-        long long r = idx / (2 * C4);
-        const int x = r % w; r /= w;
-        const int y = r % h; r /= h;
-        const int i = r % d;
-        const long long b = r / d;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (x >= i) {
-            const size_t rowbase = ((size_t)b * h + y) * w;
-            v = (c < C4) ? fl[(rowbase + x) * C4 + c] : fr[(rowbase + x - i) * C4 + (c - C4)];
+                      const float4 *__restrict__ fr, int C4, int d, int h, int w, long long rows) {
+    // one (b, i, y) output row per block iteration: w voxels of 2*C4 float4, written as one
+    // contiguous stream; no per-element index decode
+    const int per = 2 * C4;  // float4 per voxel
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int y = (int)(r % h);
+        const long long t = r / h;
+        const int i = (int)(t % d);
+        const long long b = t / d;
+        const float4 *lrow = fl + ((size_t)b * h + y) * w * C4;
+        const float4 *rrow = fr + ((size_t)b * h + y) * w * C4;
+        float4 *orow = cost + (size_t)r * w * per;
+        for (int e = threadIdx.x; e < w * per; e += 256) {
+            const int x = e / per, c = e - x * per;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x >= i) v = (c < C4) ? lrow[x * C4 + c] : rrow[(x - i) * C4 + (c - C4)];
+            orow[e] = v;
         }
-        cost[idx] = v;
     }
 }
 
@@ -167,11 +168,11 @@ extern "C" int az_cost_volume_fwd_ndhwc(float *cost, const float *fl, const floa
     AZ_REQUIRE_PTR(cost); AZ_REQUIRE_PTR(fl); AZ_REQUIRE_PTR(fr);
     if (int e = check_dims(B, C, d, h, w)) return e;
     if (C % 4) return AZ_EUNSUPPORTED;
-    const long long total4 = (long long)B * d * h * w * (2 * C / 4);
-    hipLaunchKernelGGL(cost_volume_fwd_ndhwc, dim3(az_grid_for(total4, 256)), dim3(256), 0,
+    const long long rows = (long long)B * d * h;
+    hipLaunchKernelGGL(cost_volume_fwd_ndhwc, dim3((unsigned)(rows < 8192 ? rows : 8192)), dim3(256), 0,
                        az_stream(stream), reinterpret_cast<float4 *>(cost),
                        reinterpret_cast<const float4 *>(fl),
-                       reinterpret_cast<const float4 *>(fr), C / 4, d, h, w, total4);
+                       reinterpret_cast<const float4 *>(fr), C / 4, d, h, w, rows);
     return az_launch_status();
 }
 
