@@ -7,7 +7,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libazhip.so")
+LIB_PATH = os.environ.get("AZ_LIB_PATH") or os.path.join(HERE, "lib", "libazhip.so")  # AZ_LIB_PATH: kernel A/B experiments
 HEADER = os.path.join(HERE, "..", "include", "azhip.h")
 
 _lib = None

@@ -54,28 +54,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ unsigned long long cv_stamp_sum[8];
 #define CV_T0() cv_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
 #define CV_ACC(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long cv_t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); cv_acc[i] += cv_t1 - cv_t0; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define CV_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&cv_stamp_sum[i_], cv_acc[i_]); atomicAdd(&cv_stamp_sum[5], 1ull); } } while (0)
+#define CV_FLUSH() do { if (lane == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&cv_stamp_sum[i_], cv_acc[i_]); atomicAdd(&cv_stamp_sum[5], 1ull); \
+    atomicAdd(&cv_stamp_sum[6], (unsigned long long)__builtin_amdgcn_s_memtime() - cv_k0); \
+    atomicAdd(&cv_stamp_sum[7], (unsigned long long)__builtin_amdgcn_s_memrealtime() - cv_r0); } } while (0)
 #else
 #define CV_T0()
 #define CV_ACC(i)
 #define CV_FLUSH()
 #endif
 
-struct ConvArgs {
-    const float *in;    // NDHWC input (coarse tensor for MODE 2); SRC 1: left features NHWC
-    const float *in2;   // SRC 1: right features NHWC
-    const float *wp;    // packed weights
-    float *out;         // NDHWC output
-    const float *scale, *shift, *res;  // EPI 0 (any may be null)
-    float *part;        // EPI 1: [COUT][tiles][2] (channel-major: finalize reads it coalesced)
-    long long ntiles;
-    float *cnt;         // EPI 1: [tiles]
-    int B, Di, Hi, Wi;  // input dims
-    int Do, Ho, Wo;     // output dims
-    int Dt, tiles_y, tiles_x;  // index-space extents (MODE 2: coarse dims / phase tiles)
-    int relu;
-    int map_mode;  // block->tile map: 0 linear, 1 XCD-chunked linear, 2 XCD-chunked + banded
-};
+#include "az_conv3d_args.h"
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
 __global__ void __launch_bounds__(64, X6_WIDE(COUT, MODE, PREC) ? 1 : 2)
@@ -87,14 +75,22 @@ conv3d_gather_kernel(const ConvArgs a) {
     constexpr int SX = (MODE == 0) ? TX + 2 : (MODE == 1) ? 2 * TX + 1 : TX + 1;
     // PREC 0: fp32 slab, 36 dwords per voxel.  PREC 1: three bf16 planes (hi, mid, lo) of 32
     // channels each, 52 dwords per voxel (3 x 64 B + 16 B bank padding).
-    constexpr int VS = (PREC == 0) ? CV_VS : X6_VS;
-    // LDS row pitch of the slab in voxels: SX, or padded (X6_ROWPAD) so that the A-fragment
-    // ds_read_b128 of a 4x8-voxel M-tile is bank-conflict free (rows 24 voxels apart)
-    constexpr int SXP = (X6_WIDE(COUT, MODE, PREC) && MODE == 0) ? 24 : SX;
+    // PREC 1, unit-stride reads (MODE 0/2): no padding (48 dwords per voxel); instead the four
+    // 16-byte pieces of every 64-byte part are XOR-swizzled with (slab row & 3).  A ds_read_b128
+    // is served in four 16-lane groups {0-3,12-15,20-27}, ... = four runs of 4 consecutive x on
+    // 4 consecutive slab rows: with a 12-slot voxel stride a run covers the four 64-byte quads
+    // of the 256-byte bank row once, and the row swizzle sends the four runs to different
+    // 16-byte slots of each quad -> conflict-free (the padded layout was 3-way conflicted and
+    // made the LDS, not the MFMA pipe, the bound of the 32-wide kernels).
+    constexpr bool SWZ = (PREC == 1) && (MODE != 1);
+    constexpr int VS = (PREC == 0) ? CV_VS : SWZ ? 48 : X6_VS;
+    constexpr int SXP = SX;  // LDS row pitch of the slab in voxels
     __shared__ __attribute__((aligned(16))) float slab[SY * SXP * VS];
 
 #ifdef CV_STAMP
     unsigned long long cv_acc[5] = {0, 0, 0, 0, 0}, cv_t0 = 0;
+    // whole-wave shader cycles and 100 MHz real-time ticks: in-kernel clock = ratio x 100 MHz
+    const unsigned long long cv_k0 = __builtin_amdgcn_s_memtime(), cv_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int lane = threadIdx.x;
     // ---- block -> tile map -------------------------------------------------------------
@@ -161,7 +157,11 @@ conv3d_gather_kernel(const ConvArgs a) {
     // stage s run; weights are fetched one tap ahead.
     constexpr int NQ = SY * SX * 8;          // float4 pieces of one slab
     constexpr int NLD = (NQ + 63) / 64;      // pieces per lane
-    constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : X6_WIDE(COUT, MODE, PREC);
+    #ifndef X6_BPIPE_NR1
+#define X6_BPIPE_NR1 0
+#endif
+    constexpr bool ASINGLE = X6_BPIPE_NR1 && PREC == 1 && NR == 1 && MR == 2 && !X6_WIDE(COUT, MODE, PREC);
+    constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : (X6_WIDE(COUT, MODE, PREC) || ASINGLE);
     const int NS = nd * NCH;
     float4 pre[NLD];
     unsigned okbits = 0;  // bit it: pre[it] holds real data (else zero padding)
@@ -217,7 +217,8 @@ conv3d_gather_kernel(const ConvArgs a) {
             } else if (q < NQ) {
                 uint2 hi, mid, lo;
                 az_split3_bf16x4(pre[it], hi, mid, lo);
-                unsigned *dst = reinterpret_cast<unsigned *>(slab) + vox * X6_VS + (q & 7) * 2;
+                unsigned *dst = reinterpret_cast<unsigned *>(slab) + vox * VS +
+                                (SWZ ? ((((q & 7) >> 1) ^ (sy & 3)) * 4 + (q & 1) * 2) : (q & 7) * 2);
                 *reinterpret_cast<uint2 *>(dst) = hi;
                 *reinterpret_cast<uint2 *>(dst + 16) = mid;
                 *reinterpret_cast<uint2 *>(dst + 32) = lo;
@@ -255,10 +256,13 @@ conv3d_gather_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) aq[j] = *reinterpret_cast<const float4 *>(ap + 4 * j);
         } else {
-            const float *ap = &slab[(sy * SXP + sx) * X6_VS + 4 * half];
+            const float *vp = &slab[(sy * SXP + sx) * VS];
+            // part f>>1 at +16 dwords; inside a part, piece (K16 block f&1)*2 + half
+            const float *ap0 = vp + (SWZ ? ((half ^ (sy & 3)) * 4) : 4 * half);
+            const float *ap1 = vp + (SWZ ? (((2 + half) ^ (sy & 3)) * 4) : 4 * half + 8);
 #pragma unroll
-            for (int f = 0; f < 6; ++f)  // part f>>1 at +16 dwords, K16 block f&1 at +8 dwords
-                aq[f] = *reinterpret_cast<const float4 *>(ap + (f >> 1) * 16 + (f & 1) * 8);
+            for (int f = 0; f < 6; ++f)
+                aq[f] = *reinterpret_cast<const float4 *>(((f & 1) ? ap1 : ap0) + (f >> 1) * 16);
         }
     };
     auto mfma16 = [&](f32x16 (&c)[NR], const float4 (&aq)[NF], const float4 (&bw)[NR][NF]) {
@@ -316,6 +320,22 @@ conv3d_gather_kernel(const ConvArgs a) {
         auto tap_body = [&](int t, float4 (&cur)[NR][NF], float4 (&nxt)[NR][NF]) {
             int eh_, ew_, eh2 = 0, ew2 = 0;
             const int tap = tap_of(kd, t, eh_, ew_);
+            if (ASINGLE) {
+                // weights double-buffered, A fragments single-buffered: the exposed LDS latency
+                // (twice per tap) is covered by the SIMD's other wave, the L2 latency of the
+                // weights (several times longer) by this wave's own MFMAs
+                if (t + 1 < ntaps) load_b(nxt, tap_of(kd, t + 1, eh2, ew2), cc);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(acc[0], a0, cur);
+                __builtin_amdgcn_sched_barrier(0);
+                load_a(a0, 1, eh_, ew_);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(acc[MR - 1], a0, cur);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < ntaps) load_a(a0, 0, eh2, ew2);
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             if (MR == 2) load_a(a1, 1, eh_, ew_);
             if (t + 1 < ntaps) {
                 const int tap2 = tap_of(kd, t + 1, eh2, ew2);
@@ -500,8 +520,20 @@ static int launch_conv(const ConvArgs &a, hipStream_t s) {
     return az_launch_status();
 }
 
+// AZ_CONV_M128=0 keeps the 4x16-patch kernel for the bf16x6 stride-1 32-output-channel layers
+static bool conv_m128_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("AZ_CONV_M128");
+        on = e ? (atoi(e) != 0) : 1;
+    }
+    return on != 0;
+}
+
 template <int MODE, int EPI, int PREC>
 static int dispatch_channels(const ConvArgs &a, int cin, int cout, int src, hipStream_t s) {
+    if (PREC == 1 && MODE == 0 && cout == 32 && conv_m128_enabled())
+        return az_conv3d_m128_launch(a, cin, EPI, src, s);
     if (src == 1) {
         if (MODE != 0 || cin != 64) return AZ_EUNSUPPORTED;
         if (cout == 32) return launch_conv<64, 32, 0, EPI, 1, PREC>(a, s);

@@ -1,0 +1,22 @@
+// Launch arguments shared by the 3x3x3 convolution kernels (az_conv3d.hip, az_conv3d_m128.hip).
+#pragma once
+#include "az_common.h"
+
+struct ConvArgs {
+    const float *in;    // NDHWC input (coarse tensor for MODE 2); SRC 1: left features NHWC
+    const float *in2;   // SRC 1: right features NHWC
+    const float *wp;    // packed weights
+    float *out;         // NDHWC output
+    const float *scale, *shift, *res;  // EPI 0 (any may be null)
+    float *part;        // EPI 1: [COUT][tiles][2] (channel-major: finalize reads it coalesced)
+    long long ntiles;
+    float *cnt;         // EPI 1: [tiles]
+    int B, Di, Hi, Wi;  // input dims
+    int Do, Ho, Wo;     // output dims
+    int Dt, tiles_y, tiles_x;  // index-space extents (MODE 2: coarse dims / phase tiles)
+    int relu;
+    int map_mode;  // block->tile map: 0 linear, 1 XCD-chunked linear, 2 XCD-chunked + banded
+};
+
+// bf16x6, stride-1, 32 output channels, 8x16-voxel tile per wave (az_conv3d_m128.hip)
+int az_conv3d_m128_launch(const ConvArgs &a, int cin, int epi, int src, hipStream_t s);

@@ -15,9 +15,15 @@ for prec in ("bf16x6", "fp32"):
     pk, ci, co = conv3d._pack_forward(w, 0)
     conv3d._run_gather(x, pk, 0, ci, co, stats=True); torch.cuda.synchronize()
     lib.az_debug_conv_stamps(buf, 1)
+    reps = int(os.environ.get("STAMP_REPS", "600"))   # ~1.5 s of back-to-back launches: steady-state clock
+    for _ in range(reps):
+        conv3d._run_gather(x, pk, 0, ci, co, stats=True)
+    torch.cuda.synchronize()
+    lib.az_debug_conv_stamps(buf, 1)
     conv3d._run_gather(x, pk, 0, ci, co, stats=True); torch.cuda.synchronize()
     lib.az_debug_conv_stamps(buf, 1)
     n = buf[5]
+    print(prec, "in-kernel clock %.3f GHz (shader cycles / 100 MHz ticks)" % (0.1 * buf[6] / max(buf[7], 1)))
     names = ["prologue(issue0)", "commit", "issue(next)", "taps(MFMA)", "epilogue"]
     tot = sum(buf[i] for i in range(5))
     print(prec, "waves", n, "cycles/wave", tot / n, {nm: round(buf[i] / n) for i, nm in enumerate(names)})
