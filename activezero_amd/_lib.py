@@ -32,6 +32,9 @@ _SIGS = {
     "az_patch_reproj_bwd": [_PTR] * 7 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_patch_reproj_vis": [_PTR] * 3 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
+    "az_disp_loss_fwd": [_PTR] * 6 + [_C.c_float, _C.c_float, _C.c_longlong, _PTR],
+    "az_disp_loss_bwd": [_PTR] * 8 + [_C.c_float, _C.c_float, _PTR, _PTR] + [_C.c_float] * 3 + [_C.c_longlong, _PTR],
+    "az_disp_metrics": [_PTR] * 7 + [_INT, _C.c_longlong, _PTR],
     "az_conv3d_packed_floats": [_INT, _INT, _INT],
     "az_conv3d_pack_weights": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
     "az_conv3d_num_tiles": [_INT] * 5,

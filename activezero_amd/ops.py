@@ -235,3 +235,80 @@ def local_contrast_norm(image, kernel_size=9, eps=1e-5):
         _call("az_lcn", _p(normed), _p(std), _p(img), b, h, w, int(kernel_size), float(eps),
               c * h * w, _stream())
     return normed, std
+
+
+# ----------------------------------------------------------------------------
+# K12 disparity loss + error metrics (the step after the path)
+# ----------------------------------------------------------------------------
+def _mask_u8(mask, like, name="mask"):
+    if mask is None:
+        return None
+    if mask.shape != like.shape:
+        raise RuntimeError(f"{name}: shape {tuple(mask.shape)} != {tuple(like.shape)}")
+    if mask.dtype == torch.bool:
+        mask = mask.contiguous().view(torch.uint8)  # same bytes, no copy
+    return _chk(mask, name, torch.uint8)
+
+
+class _DispLoss(torch.autograd.Function):
+    WEIGHTS = (1.0, 0.7, 0.5)  # pred3, pred2, pred1 (utils/losses.py:9-14)
+
+    @staticmethod
+    def forward(ctx, pred3, pred2, pred1, gt, mask, lo, hi):
+        p3, p2, p1 = (_chk(p.contiguous(), f"pred{k}") for p, k in ((pred3, 3), (pred2, 2), (pred1, 1)))
+        gt = _chk(gt.contiguous(), "disp_gt")
+        if not (p3.shape == p2.shape == p1.shape == gt.shape):
+            raise RuntimeError("predictions and ground truth must have identical shapes")
+        m = _mask_u8(mask, gt)
+        acc = torch.zeros(4, dtype=torch.float64, device=gt.device)
+        with torch.cuda.device(gt.device):
+            _call("az_disp_loss_fwd", _p(acc), _p(p3), _p(p2), _p(p1), _p(gt), _p(m), float(lo), float(hi),
+                  gt.numel(), _stream())
+        w3, w2, w1 = _DispLoss.WEIGHTS
+        loss = ((w3 * acc[0] + w2 * acc[1] + w1 * acc[2]) / acc[3]).to(torch.float32)  # 0/0 = nan, as the reference's empty mean
+        ctx.save_for_backward(p3, p2, p1, gt, m if m is not None else gt.new_empty(0), acc)
+        ctx.has_mask, ctx.lo, ctx.hi = m is not None, float(lo), float(hi)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        p3, p2, p1, gt, m, acc = ctx.saved_tensors
+        gloss = _chk(gloss.contiguous().to(torch.float32).reshape(1), "grad_loss")
+        g3, g2, g1 = torch.empty_like(p3), torch.empty_like(p2), torch.empty_like(p1)
+        w3, w2, w1 = _DispLoss.WEIGHTS
+        with torch.cuda.device(gt.device):
+            _call("az_disp_loss_bwd", _p(g3), _p(g2), _p(g1), _p(p3), _p(p2), _p(p1), _p(gt),
+                  _p(m) if ctx.has_mask else None, ctx.lo, ctx.hi, _p(gloss), _p(acc), w3, w2, w1,
+                  gt.numel(), _stream())
+        return g3, g2, g1, None, None, None, None
+
+
+def disp_loss(pred3, pred2, pred1, gt, mask=None, lo=0.0, hi=float("inf")):
+    """smooth_l1(pred3) + 0.7 smooth_l1(pred2) + 0.5 smooth_l1(pred1), each a mean over the valid
+    pixels: `mask` (bool/uint8, same shape) or, when mask is None, lo < gt < hi.  One pass, no sync."""
+    return _DispLoss.apply(pred3, pred2, pred1, gt, mask, lo, hi)
+
+
+def disp_metrics(disp_gt, depth_gt, disp_pred, mask, focal_x_baseline=None, depth_pred=None):
+    """fp64 sums [sum|dd|, #(|dd|>1), #(|dd|>2), sum clip(|1000 dz|,0,100), #(|dz|>2e-3), #(|dz|>4e-3),
+    #(|dz|>8e-3), count] over the masked pixels, on the device (no sync)."""
+    dg = _chk(disp_gt.contiguous(), "disp_gt")
+    zg = _chk(depth_gt.contiguous(), "depth_gt")
+    dp = _chk(disp_pred.contiguous(), "disp_pred")
+    if not (dg.shape == zg.shape == dp.shape):
+        raise RuntimeError("disp_gt, depth_gt and disp_pred must have identical shapes")
+    m = _mask_u8(mask, dg)
+    if m is None:
+        raise RuntimeError("mask is required")
+    b = dg.shape[0]
+    zp = _chk(depth_pred.contiguous(), "depth_pred") if depth_pred is not None else None
+    fb = None
+    if zp is None:
+        fb = _chk(focal_x_baseline.contiguous().reshape(-1), "focal_x_baseline")
+        if fb.numel() != b:
+            raise RuntimeError("focal_x_baseline must hold one value per batch element")
+    acc = torch.zeros(8, dtype=torch.float64, device=dg.device)
+    with torch.cuda.device(dg.device):
+        _call("az_disp_metrics", _p(acc), _p(dg), _p(zg), _p(dp), _p(zp), _p(fb), _p(m), b,
+              dg.numel() // max(b, 1), _stream())
+    return acc

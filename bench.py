@@ -72,13 +72,10 @@ def synth_batch(b, h_img, w_img, maxdisp, device, seed):
 
 
 def disp_loss(preds, gt, maxdisp):
-    """utils/losses.py:7-15 psmnet_disp with the train.py:272 mask, written without
-    boolean-index compaction (no host sync)."""
-    mask = ((gt < maxdisp) & (gt > 0)).to(gt.dtype)
-    n = mask.sum()
-    p3, p2, p1 = preds
-    sl1 = lambda p: (F.smooth_l1_loss(p, gt, reduction="none") * mask).sum() / n
-    return 0.5 * sl1(p1) + 0.7 * sl1(p2) + sl1(p3)
+    """utils/losses.py:7-15 psmnet_disp with the train.py:272 mask (0 < gt < maxdisp): the fused K12
+    kernel -- one pass, no boolean-index compaction, no host sync."""
+    from activezero_amd.utils import disp_losses
+    return disp_losses.psmnet_disp_range(preds, gt, maxdisp)
 
 
 def cpu_baseline(args):

@@ -219,6 +219,26 @@ int az_corr1d_lookup_bwd(float *grad_pyr_level, const float *grad_out, const flo
                          int H, int W1, int W_level, int radius, int level, int ch_offset,
                          int ch_total, void *stream);
 
+/* ---- K12: disparity loss + error metrics (the step after the path) -------------------------
+ * Replaces utils/losses.py:7-15 psmnet_disp (boolean-index compaction + three smooth_l1 means)
+ * and utils/cascade_metrics.py:16-62 compute_err_metric (ten masked reductions with .item()).
+ * All maps are [B,1,H,W] fp32 flattened to n elements; `mask` is one byte per element, or NULL
+ * for the range rule lo < gt < hi (train.py:272).  Accumulators are caller-zeroed fp64. */
+/* acc4[0..2] += sum smooth_l1(pred3|pred2|pred1 - gt) over valid pixels, acc4[3] += count */
+int az_disp_loss_fwd(double *acc4, const float *pred3, const float *pred2, const float *pred1,
+                     const float *gt, const unsigned char *mask, float lo, float hi, long long n,
+                     void *stream);
+/* g_k = w_k * gloss[0] / acc4[3] * clamp(pred_k - gt, -1, 1) on valid pixels, 0 elsewhere */
+int az_disp_loss_bwd(float *g3, float *g2, float *g1, const float *pred3, const float *pred2,
+                     const float *pred1, const float *gt, const unsigned char *mask, float lo,
+                     float hi, const float *gloss, const double *acc4, float w3, float w2, float w1,
+                     long long n, void *stream);
+/* acc8 += {sum|dd|, #(|dd|>1), #(|dd|>2), sum clip(|1000 dz|,0,100), #(|dz|>2e-3), #(|dz|>4e-3),
+ * #(|dz|>8e-3), count}; depth_pred NULL -> focal_x_baseline[b] / disp_pred (cascade_metrics.py:36) */
+int az_disp_metrics(double *acc8, const float *disp_gt, const float *depth_gt,
+                    const float *disp_pred, const float *depth_pred, const float *focal_x_baseline,
+                    const unsigned char *mask, int B, long long per_batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,3 +181,26 @@ def test_psmnet_disp_loss_formula():
     mask = po.disparity_mask(gt, 16)
     ref = sum(w * F.smooth_l1_loss(p[mask], gt[mask]) for w, p in zip((1.0, 0.7, 0.5), ps))
     assert torch.allclose(po.psmnet_disp_loss(ps, gt, mask), ref)
+
+
+def test_g10_loss_and_metrics(golden):
+    """Loss restatement and error metrics against the reference's outputs (G10)."""
+    from oracle import metrics_oracle as mo
+
+    g = golden("g10_metrics")
+    gt, mask = T(g["gt"]), T(g["mask"])
+    preds = [T(g[k]).requires_grad_() for k in ("pred3", "pred2", "pred1")]
+    loss = po.psmnet_disp_loss(tuple(preds), gt, mask)
+    close(loss, g["loss"], rtol=1e-6)
+    for p, k in zip(preds, ("grad3", "grad2", "grad1")):
+        close(torch.autograd.grad(loss, p, retain_graph=True)[0], g[k], rtol=1e-6, atol=1e-9)
+    assert torch.equal(mask, po.disparity_mask(gt, float(g["maxdisp"])))
+    focal, base, zg, dp = (T(g[k]) for k in ("focal", "baseline", "depth_gt", "disp_pred"))
+    keys = [str(k) for k in g["metric_keys"]]
+    m = mo.compute_err_metric(gt, zg, dp, focal, base, mask)
+    close([m[k] for k in keys], g["metrics"], rtol=1e-6)
+    m = mo.compute_err_metric(gt, zg, dp, focal, base, mask, depth_pred=T(g["depth_pred"]))
+    close([m[k] for k in keys], g["metrics_dp"], rtol=1e-6)
+    obj = mo.compute_obj_err(gt[:1], zg[:1], dp[:1], focal[:1], base[:1], T(g["label"]), mask[:1])
+    for i, o in enumerate(obj):
+        close(o, g[f"obj{i}"], rtol=1e-6)

@@ -318,10 +318,46 @@ def g9_corr():
          **{f"pyr{i}": p for i, p in enumerate(blk.corr_pyramid[:4])})
 
 
+# ---------------------------------------------------------------- G10 loss + error metrics
+def g10_metrics():
+    """compute_err_metric / compute_obj_err: the imported reference (utils/cascade_metrics.py).
+    psmnet_disp: utils/losses.py is not importable here (its module imports the yacs config), so
+    its three-line formula (losses.py:7-15) is evaluated with the same torch calls on boolean-
+    indexed operands, as SURVEY.md 8c prescribes."""
+    from utils import cascade_metrics as ref_metrics
+
+    b, h, w = 2, 24, 40
+    gt = seeded((b, 1, h, w), 1001, 0.0, 60.0)
+    gt[:, :, :3] = 0.0          # invalid rows (gt == 0)
+    gt[0, 0, 10, :5] = 70.0     # beyond maxdisp
+    maxdisp = 64.0
+    mask = (gt < maxdisp) & (gt > 0)
+    preds = [(gt + seeded((b, 1, h, w), 1002 + k, -3.0, 3.0)).requires_grad_() for k in range(3)]
+    p3, p2, p1 = preds
+    loss = (0.5 * F.smooth_l1_loss(p1[mask], gt[mask], reduction="mean")
+            + 0.7 * F.smooth_l1_loss(p2[mask], gt[mask], reduction="mean")
+            + F.smooth_l1_loss(p3[mask], gt[mask], reduction="mean"))
+    g3, g2, g1 = torch.autograd.grad(loss, (p3, p2, p1))
+    focal = seeded((b, 1, 1, 1), 1010, 400.0, 500.0)
+    base = seeded((b, 1, 1, 1), 1011, 0.05, 0.06)
+    depth_gt = torch.where(gt > 0, focal * base / gt.clamp(min=1e-3), torch.zeros_like(gt))
+    pred = p3.detach().clamp(min=0.5)
+    m = ref_metrics.compute_err_metric(gt, depth_gt, pred, focal, base, mask)
+    depth_pred = focal * base / pred + 1e-3
+    m2 = ref_metrics.compute_err_metric(gt, depth_gt, pred, focal, base, mask, depth_pred=depth_pred)
+    label = (seeded((1, 1, h, w), 1012, 0.0, 4.99)).floor()
+    obj = ref_metrics.compute_obj_err(gt[:1], depth_gt[:1], pred[:1], focal[:1], base[:1], label, mask[:1])
+    keys = sorted(m)
+    save("g10_metrics", gt=gt, mask=mask, pred3=p3, pred2=p2, pred1=p1, maxdisp=maxdisp, loss=loss,
+         grad3=g3, grad2=g2, grad1=g1, focal=focal, baseline=base, depth_gt=depth_gt, disp_pred=pred,
+         depth_pred=depth_pred, metric_keys=np.array(keys), metrics=np.array([m[k] for k in keys]),
+         metrics_dp=np.array([m2[k] for k in keys]), label=label, **{f"obj{i}": o for i, o in enumerate(obj)})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for fn in (g1_cost_volume, g2_softargmin, g3_blocks, g4_full, g6_apply_disparity, g7_patch,
-               g8_lcn, g9_corr):
+               g8_lcn, g9_corr, g10_metrics):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

@@ -7,14 +7,14 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/stall_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $out -o a --output-format csv -- python3 $root/tools/pmc_sq_probe.py > $out/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES -d $out -o b --output-format csv -- python3 $root/tools/pmc_sq_probe.py > $out/b.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $out -o a --output-format csv -- python3 $root/tools/${PROBE:-pmc_sq_probe.py} > $out/a.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES -d $out -o b --output-format csv -- python3 $root/tools/${PROBE:-pmc_sq_probe.py} > $out/b.log 2>&1
 python3 - <<PY
 import csv, collections, glob
 agg = collections.defaultdict(list)
 for f in glob.glob("$out/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "gather" in r["Kernel_Name"] or "m128" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in ("gather", "m128", "wgrad")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(agg):
     print("$tag", k, "%.4g" % (sum(agg[k]) / len(agg[k])))
