@@ -318,10 +318,14 @@ class _Lift2d(torch.autograd.Function):
         return g3[:, :, 1].contiguous()
 
 
+# AZ_FE2D_CH: channel counts of the 2-D layers routed to the 3-D kernels when AZ_FE2D=hip
+_FE2D_CH = tuple(int(c) for c in os.environ.get("AZ_FE2D_CH", "32,64").split(","))
+
+
 def supports_2d(conv):
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
             and conv.dilation == (1, 1) and conv.padding == (1, 1) and conv.groups == 1 and conv.bias is None
-            and conv.in_channels in (32, 64) and conv.out_channels in (32, 64))
+            and conv.in_channels in _FE2D_CH and conv.out_channels in _FE2D_CH)
 
 
 def _as_volume(x):

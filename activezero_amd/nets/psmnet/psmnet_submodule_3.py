@@ -165,7 +165,17 @@ class FeatureExtraction(nn.Module):
         raw = self.layer2(self.layer1(y))
         skip = self.layer4(self.layer3(raw))
         size = skip.shape[-2:]
-        pyramid = [upsample_bilinear_ac(getattr(self, f"branch{i}")(skip), size) for i in (4, 3, 2, 1)]
+        # SPP pooling as a hierarchy: the 16/32/64 windows are 2x2 means of the previous level
+        # (floor division composes, so sizes and covered pixels equal AvgPool2d(win, win)); the
+        # full-resolution map is read once instead of four times, and written once in backward
+        pooled, p = {}, skip
+        for _, win in sorted(_SPP_WINDOWS, key=lambda iw: iw[1]):
+            p = F.avg_pool2d(p, win, win) if not pooled else F.avg_pool2d(p, 2, 2)
+            pooled[win] = p
+        assert sorted(pooled) == [8, 16, 32, 64]
+        win_of = dict(_SPP_WINDOWS)
+        pyramid = [upsample_bilinear_ac(getattr(self, f"branch{i}")[1:](pooled[win_of[i]]), size)
+                   for i in (4, 3, 2, 1)]
         return self.lastconv(torch.cat([raw, skip] + pyramid, 1))
 
     def forward(self, x):
