@@ -258,13 +258,16 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
         const float *fbase = a.fine + (((size_t)b * a.Df + fd) * a.Hf) * a.Wf * CN + nt * 32;
 
         float4 pa[NLA], pf[NLF];
+        unsigned okbits = 0;  // bit it: pa[it] is real data; bit 8+it: pf[it] (else zero padding)
+        // loads only: clamped (always valid) addresses, padding applied at commit time -- touching
+        // the loaded registers here puts the whole memory latency in front of this row's MFMAs
         auto issue = [&](int ch) {
-            bool oka[NLA], okf[NLF];
+            okbits = 0;
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it, pos = q >> 3, part = q & 7;
                 const int cw = cw0 + pos;
-                oka[it] = (q < NQA) && cw < a.Wc;
+                okbits |= ((q < NQA) && cw < a.Wc) ? (1u << it) : 0u;
                 pa[it] = *reinterpret_cast<const float4 *>(
                     cbase + ((size_t)ch * a.Wc + min(cw, a.Wc - 1)) * CM + part * 4);
             }
@@ -274,24 +277,15 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
                 const int rr = min(p / FW, NEW - 1), lw = p - (p / FW) * FW;
                 const int fh = S * ch + 2 - NEW + rr, fw = fw0 + lw;
                 const int fhc = min(max(fh, 0), a.Hf - 1), fwc = min(max(fw, 0), a.Wf - 1);
-                okf[it] = (q < NQF) && fh == fhc && fw == fwc;
+                okbits |= ((q < NQF) && fh == fhc && fw == fwc) ? (1u << (8 + it)) : 0u;
                 pf[it] = *reinterpret_cast<const float4 *>(fbase + ((size_t)fhc * a.Wf + fwc) * CN + part * 4);
-            }
-#pragma unroll
-            for (int it = 0; it < NLA; ++it) {
-                pa[it].x = oka[it] ? pa[it].x : 0.f; pa[it].y = oka[it] ? pa[it].y : 0.f;
-                pa[it].z = oka[it] ? pa[it].z : 0.f; pa[it].w = oka[it] ? pa[it].w : 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < NLF; ++it) {
-                pf[it].x = okf[it] ? pf[it].x : 0.f; pf[it].y = okf[it] ? pf[it].y : 0.f;
-                pf[it].z = okf[it] ? pf[it].z : 0.f; pf[it].w = okf[it] ? pf[it].w : 0.f;
             }
         };
         auto commit = [&](int ch) {
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it;
+                if (!((okbits >> it) & 1u)) pa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < NQA) split_store(&sa[(q >> 3) * 32 + (q & 7) * 4], WCH * 32, pa[it]);
             }
 #pragma unroll
@@ -300,6 +294,7 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
                 const int rr = p / FW, lw = p - rr * FW;
                 const int fh = S * ch + 2 - NEW + rr;
                 const int slot = (fh + 3) % 3;
+                if (!((okbits >> (8 + it)) & 1u)) pf[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < NQF) split_store(&sf[(slot * 3 * FW + lw) * 32 + part * 4], FW * 32, pf[it]);
             }
         };
