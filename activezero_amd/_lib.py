@@ -24,8 +24,8 @@ _SIGS = {
     "az_cost_volume_bwd": [_PTR] * 3 + [_INT] * 5 + [_PTR],
     "az_cost_volume_fwd_ndhwc": [_PTR] * 3 + [_INT] * 5 + [_PTR],
     "az_cost_volume_bwd_ndhwc": [_PTR] * 3 + [_INT] * 5 + [_PTR],
-    "az_softargmin_fwd": [_PTR] * 2 + [_INT] * 4 + [_PTR],
-    "az_softargmin_bwd": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_softargmin_fwd": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_softargmin_bwd": [_PTR] * 5 + [_INT] * 4 + [_PTR],
     "az_warp_gather_fwd": [_PTR] * 3 + [_INT] * 4 + [_PTR],
     "az_warp_gather_bwd": [_PTR] * 5 + [_INT] * 4 + [_PTR],
     "az_patch_reproj_fwd": [_PTR] * 5 + [_INT] * 5 + [_C.c_float, _PTR],

@@ -81,15 +81,17 @@ conv3d_wgrad_kernel(const WgArgs a) {
         const float *fbase = a.fine + (((size_t)b * a.Df + fd) * a.Hf) * a.Wf * CN + nt * 32;
 
         float4 pa[NLA], pf[NLF];
-        // fetch (branch-free) what step `ch` adds: its coarse row chunk and its NEW newest fine rows
+        unsigned okbits = 0;  // bit it: pa[it] is real data; bit 8+it: pf[it] (else zero padding)
+        // fetch (branch-free) what step `ch` adds: its coarse row chunk and its NEW newest fine rows.
+        // Loads only, from clamped (always valid) addresses; the padding is applied at commit time
+        // so that nothing waits on these registers before this row's MFMAs have been issued.
         auto issue = [&](int ch) {
-            bool oka[NLA], okf[NLF];
-            // all loads first, from clamped (always valid) addresses; padding by select after
+            okbits = 0;
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it, pos = q >> 3, part = q & 7;
                 const int cw = cw0 + pos;
-                oka[it] = (q < NQA) && cw < a.Wc;
+                okbits |= ((q < NQA) && cw < a.Wc) ? (1u << it) : 0u;
                 pa[it] = *reinterpret_cast<const float4 *>(
                     cbase + ((size_t)ch * a.Wc + min(cw, a.Wc - 1)) * CM + part * 4);
             }
@@ -99,24 +101,15 @@ conv3d_wgrad_kernel(const WgArgs a) {
                 const int rr = min(p / FW, NEW - 1), lw = p - (p / FW) * FW;
                 const int fh = S * ch + 2 - NEW + rr, fw = fw0 + lw;
                 const int fhc = min(max(fh, 0), a.Hf - 1), fwc = min(max(fw, 0), a.Wf - 1);
-                okf[it] = (q < NQF) && fh == fhc && fw == fwc;
+                okbits |= ((q < NQF) && fh == fhc && fw == fwc) ? (1u << (8 + it)) : 0u;
                 pf[it] = *reinterpret_cast<const float4 *>(fbase + ((size_t)fhc * a.Wf + fwc) * CN + part * 4);
-            }
-#pragma unroll
-            for (int it = 0; it < NLA; ++it) {
-                pa[it].x = oka[it] ? pa[it].x : 0.f; pa[it].y = oka[it] ? pa[it].y : 0.f;
-                pa[it].z = oka[it] ? pa[it].z : 0.f; pa[it].w = oka[it] ? pa[it].w : 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < NLF; ++it) {
-                pf[it].x = okf[it] ? pf[it].x : 0.f; pf[it].y = okf[it] ? pf[it].y : 0.f;
-                pf[it].z = okf[it] ? pf[it].z : 0.f; pf[it].w = okf[it] ? pf[it].w : 0.f;
             }
         };
         auto commit = [&](int ch) {
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it;
+                if (!((okbits >> it) & 1u)) pa[it] = zero4;
                 if (q < NQA) *reinterpret_cast<float4 *>(&sa[(q >> 3) * 32 + (q & 7) * 4]) = pa[it];
             }
 #pragma unroll
@@ -125,6 +118,7 @@ conv3d_wgrad_kernel(const WgArgs a) {
                 const int rr = p / FW, lw = p - rr * FW;
                 const int fh = S * ch + 2 - NEW + rr;
                 const int slot = (fh + 3) % 3;
+                if (!((okbits >> (8 + it)) & 1u)) pf[it] = zero4;
                 if (q < NQF) *reinterpret_cast<float4 *>(&sf[(slot * FW + lw) * 32 + part * 4]) = pf[it];
             }
         };
@@ -192,8 +186,12 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 #define X6_WCH 16  // coarse positions per chunk = one K16 block
 
+#ifndef WGX6_S2_OCC
+#define WGX6_S2_OCC 1
+#endif
+#define WGX6_S2_WAVES(S) ((S) == 1 ? 2 : WGX6_S2_OCC)
 template <int CM, int CN, int S>
-__global__ void __launch_bounds__(64, S == 1 ? 2 : 1)
+__global__ void __launch_bounds__(64, WGX6_S2_WAVES(S))
 conv3d_wgrad_x6_kernel(const WgArgs a) {
     constexpr int WCH = X6_WCH;
     constexpr int FW = S * (WCH - 1) + 3;  // fine positions per staged row

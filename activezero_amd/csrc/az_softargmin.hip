@@ -15,11 +15,13 @@
 // area_pixel_compute_source_index + min(i0+1, size-1)).
 // Algorithmic HBM bytes per head: 4*(d*h*w + H*W); the kernel is VALU/exp bound.
 //
-// Backward recomputes the softmax (nothing saved), forms
+// Backward reads the per-pixel softmax shift / normaliser the forward saved (8 B per pixel; it
+// recomputes them when given none), forms
 //   d out / d u_D = p_D * (D - out)
-// folds the D-lerp back onto the 48 planes, pre-reduces the 4 pixels of an
-// x-quad with wave shuffles, accumulates the tile's (3 x 18 x d) gradient in LDS
-// (ds_add_f32) and flushes it with one global float atomic per LDS cell.
+// folds the D-lerp back onto the 48 planes, reduces the wave's 64 pixels onto their 18 x-cells
+// with shuffles (quad xor, then +-4 lanes), accumulates the tile's (3 x 18 x d) gradient in LDS
+// (one conflict-free ds_add_f32 lane per cell and wave) and flushes it with one global float
+// atomic per LDS cell.
 #include "az_common.h"
 
 #define SA_TY 4
@@ -39,6 +41,9 @@ __device__ __forceinline__ void sa_load_tile(float *tile, const float *__restric
         tile[e] = logits[(((size_t)b * d + k) * h + gy) * w + gx];
     }
 }
+
+// exp(x) for x <= 0 on the hardware exp2 (backward pass only)
+__device__ __forceinline__ float sa_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 struct SaPix {
     int ly0, lx0;    // tile-local index of the lower cell; the upper one is +1
@@ -105,8 +110,8 @@ __device__ __forceinline__ void sa_stats(const float *tile, int d, const SaPix &
 }
 
 __global__ void __launch_bounds__(256)
-softargmin_fwd_kernel(float *__restrict__ out, const float *__restrict__ logits, int d, int h,
-                      int w, int tiles_x) {
+softargmin_fwd_kernel(float *__restrict__ out, float2 *__restrict__ stats,
+                      const float *__restrict__ logits, int d, int h, int w, int tiles_x) {
     extern __shared__ float tile[];
     const int H = 4 * h, W = 4 * w;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -122,11 +127,13 @@ softargmin_fwd_kernel(float *__restrict__ out, const float *__restrict__ logits,
     float M, s, t;
     sa_stats(tile, d, p, M, s, t);
     out[((size_t)b * H + Y) * W + X] = t / s;
+    if (stats) stats[((size_t)b * H + Y) * W + X] = make_float2(M, s);  // saved for the backward pass
 }
 
 __global__ void __launch_bounds__(256)
 softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gout,
-                      const float *__restrict__ logits, int d, int h, int w, int tiles_x) {
+                      const float *__restrict__ logits, const float2 *__restrict__ stats,
+                      const float *__restrict__ fwd_out, int d, int h, int w, int tiles_x) {
     extern __shared__ float smem[];
     float *tile = smem;
     float *gtile = smem + d * SA_LY * SA_LX;
@@ -143,13 +150,23 @@ softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gou
     SaPix p;
     sa_axis(Y, ybase, p.ly0, p.wy1);  // indices depend on the thread id only: always in-tile
     sa_axis(X, xbase, p.lx0, p.wx1);
-    float M, s, t;
-    sa_stats(tile, d, p, M, s, t);
-    const float pred = t / s;
+    // softmax shift M, normaliser s and the prediction: read back when the forward saved them
+    // (training), recomputed otherwise.  p_D = exp(u_D - M) / s below uses the hardware exp2
+    // (v_exp_f32, 1 ulp): gradients do not need expf's range reduction, the forward keeps it.
+    float M, s, pred;
+    if (stats) {
+        const size_t pix = live ? ((size_t)b * H + Y) * W + X : 0;
+        const float2 ms = stats[pix];
+        M = ms.x; s = ms.y; pred = fwd_out[pix];
+    } else {
+        float t;
+        sa_stats(tile, d, p, M, s, t);
+        pred = t / s;
+    }
     const float g = live ? gout[((size_t)b * H + Y) * W + X] / s : 0.f;  // g * (1/s)
 
     // x-quad roles: the 4 pixels X = 4q..4q+3 touch cells q-1, q, q+1.
-    const int r = threadIdx.x & 3;
+    const int r = threadIdx.x & 3, wl = threadIdx.x & 63;  // lane in the quad / in the wave (= X - 64 tx)
     const int cq = (X >> 2) - xbase;  // tile-local column of cell q, in [1,16]
     const float wx0 = 1.f - p.wx1;
     const float f_m1 = (r < 2) ? wx0 : 0.f;   // share going to cell q-1
@@ -159,7 +176,7 @@ softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gou
     float v0 = sa_plane(tile, 0, p);
     float acc0;  // gradient being collected for plane k
     {
-        const float e = expf(v0 - M);
+        const float e = sa_exp_fast(v0 - M);
         acc0 = g * e * ((0.f - pred) + (1.f - pred));
     }
     for (int k = 0; k < d; ++k) {
@@ -170,26 +187,38 @@ softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gou
             for (int m = 0; m < 4; ++m) {
                 const float w1 = 0.125f + 0.25f * m;
                 const float u = (1.f - w1) * v0 + w1 * v1;
-                const float gu = g * expf(u - M) * ((float)(4 * k + 2 + m) - pred);
+                const float gu = g * sa_exp_fast(u - M) * ((float)(4 * k + 2 + m) - pred);
                 acc0 += (1.f - w1) * gu;
                 acc1 += w1 * gu;
             }
             v0 = v1;
         } else {
-            const float e = expf(v0 - M);
+            const float e = sa_exp_fast(v0 - M);
             acc0 += g * e * (((float)(4 * d - 2) - pred) + ((float)(4 * d - 1) - pred));
         }
-        // plane k complete: quad-reduce the three x-cell shares, then 3 lanes add
+        // plane k complete: quad-reduce the three x-cell shares, then finish the reduction across
+        // quads in registers -- cell q also receives the right share of quad q-1 and the left share
+        // of quad q+1 -- so that every LDS cell gets ONE ds_add_f32 lane per wave.  (Three lanes per
+        // quad adding their own shares made each instruction a 3-way same-address conflict; those
+        // serialised atomics were 0.6 ms of this kernel's 0.87 ms.)
         float s_m1 = f_m1 * acc0, s_0 = f_0 * acc0, s_p1 = f_p1 * acc0;
         s_m1 += __shfl_xor(s_m1, 1); s_m1 += __shfl_xor(s_m1, 2);
         s_0 += __shfl_xor(s_0, 1);   s_0 += __shfl_xor(s_0, 2);
         s_p1 += __shfl_xor(s_p1, 1); s_p1 += __shfl_xor(s_p1, 2);
-        // lanes 0,1,2 of the quad add the shares of cells q-1, q, q+1 (two rows each)
-        if (r < 3) {
-            const float val = (r == 0) ? s_m1 : (r == 1 ? s_0 : s_p1);
-            float *gt = gtile + k * (SA_LY * SA_LX) + p.ly0 * SA_LX + (cq - 1 + r);
+        const float from_left = __shfl_up(s_p1, 4), from_right = __shfl_down(s_m1, 4);
+        const float cell = s_0 + (wl >= 4 ? from_left : 0.f) + (wl < 60 ? from_right : 0.f);
+        // lane 0 of every quad owns cell q; lane 1 of the first / last quad owns the halo cells
+        const bool edge_l = (wl == 1), edge_r = (wl == 61);
+        if (r == 0 || edge_l || edge_r) {
+            const float val = (r == 0) ? cell : (edge_l ? s_m1 : s_p1);
+            const int col = (r == 0) ? cq : (edge_l ? cq - 1 : cq + 1);
+            float *gt = gtile + k * (SA_LY * SA_LX) + p.ly0 * SA_LX + col;
+#if defined(SA_DIAG) && (SA_DIAG & 1)
+            gt[0] = (1.f - p.wy1) * val; gt[SA_LX] = p.wy1 * val;
+#else
             atomicAdd(gt, (1.f - p.wy1) * val);
             atomicAdd(gt + SA_LX, p.wy1 * val);
+#endif
         }
         acc0 = acc1;
     }
@@ -202,7 +231,11 @@ softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gou
         const int ly = rr % SA_LY, k = rr / SA_LY;
         const int gy = min(max(ybase + ly, 0), h - 1);
         const int gx = min(max(xbase + lx, 0), w - 1);
+#if defined(SA_DIAG) && (SA_DIAG & 2)
+        glogits[(((size_t)b * d + k) * h + gy) * w + gx] = v;
+#else
         atomicAdd(&glogits[(((size_t)b * d + k) * h + gy) * w + gx], v);
+#endif
     }
 }
 
@@ -213,21 +246,22 @@ static int sa_check(int B, int d, int h, int w) {
     return AZ_OK;
 }
 
-extern "C" int az_softargmin_fwd(float *disp_out, const float *logits, int B, int d, int h,
-                                 int w, void *stream) {
+extern "C" int az_softargmin_fwd(float *disp_out, float *stats_out, const float *logits, int B, int d,
+                                 int h, int w, void *stream) {
     AZ_REQUIRE_PTR(disp_out); AZ_REQUIRE_PTR(logits);
     if (int e = sa_check(B, d, h, w)) return e;
     const int tiles_x = (4 * w + SA_TX - 1) / SA_TX, tiles_y = (4 * h) / SA_TY;
     hipLaunchKernelGGL(softargmin_fwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256),
                        (size_t)d * SA_LY * SA_LX * sizeof(float), az_stream(stream), disp_out,
-                       logits, d, h, w, tiles_x);
+                       reinterpret_cast<float2 *>(stats_out), logits, d, h, w, tiles_x);
     return az_launch_status();
 }
 
 extern "C" int az_softargmin_bwd(float *grad_logits, const float *grad_disp,
-                                 const float *logits, int B, int d, int h, int w,
-                                 void *stream) {
+                                 const float *logits, const float *stats, const float *disp_fwd,
+                                 int B, int d, int h, int w, void *stream) {
     AZ_REQUIRE_PTR(grad_logits); AZ_REQUIRE_PTR(grad_disp); AZ_REQUIRE_PTR(logits);
+    if ((stats == nullptr) != (disp_fwd == nullptr)) return AZ_EINVAL;
     if (int e = sa_check(B, d, h, w)) return e;
     if (hipMemsetAsync(grad_logits, 0, (size_t)B * d * h * w * sizeof(float),
                        az_stream(stream)) != hipSuccess)
@@ -235,6 +269,7 @@ extern "C" int az_softargmin_bwd(float *grad_logits, const float *grad_disp,
     const int tiles_x = (4 * w + SA_TX - 1) / SA_TX, tiles_y = (4 * h) / SA_TY;
     hipLaunchKernelGGL(softargmin_bwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256),
                        (size_t)2 * d * SA_LY * SA_LX * sizeof(float), az_stream(stream),
-                       grad_logits, grad_disp, logits, d, h, w, tiles_x);
+                       grad_logits, grad_disp, logits, reinterpret_cast<const float2 *>(stats), disp_fwd,
+                       d, h, w, tiles_x);
     return az_launch_status();
 }

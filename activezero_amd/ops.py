@@ -112,20 +112,25 @@ class _SoftArgmin(torch.autograd.Function):
         else:
             b, d, h, w = lg.shape
         out = lg.new_empty(b, 1, 4 * h, 4 * w)
+        # per-pixel softmax shift / normaliser (8 B per pixel) so that backward skips that pass
+        stats = lg.new_empty(b, 4 * h, 4 * w, 2) if ctx.needs_input_grad[0] else None
         with torch.cuda.device(lg.device):
-            _call("az_softargmin_fwd", _p(out), _p(lg), b, d, h, w, _stream())
-        ctx.save_for_backward(lg)
+            _call("az_softargmin_fwd", _p(out), _p(stats), _p(lg), b, d, h, w, _stream())
+        if stats is not None:
+            ctx.save_for_backward(lg, stats, out)
+        else:
+            ctx.save_for_backward(lg)
         ctx.dims = (b, d, h, w)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (lg,) = ctx.saved_tensors
+        lg, stats, out = (tuple(ctx.saved_tensors) + (None, None))[:3]
         g = _chk(g.contiguous(), "grad_disp")
         b, d, h, w = ctx.dims
         gl = torch.empty_like(lg)
         with torch.cuda.device(g.device):
-            _call("az_softargmin_bwd", _p(gl), _p(g), _p(lg), b, d, h, w, _stream())
+            _call("az_softargmin_bwd", _p(gl), _p(g), _p(lg), _p(stats), _p(out), b, d, h, w, _stream())
         return gl
 
 

@@ -69,12 +69,15 @@ int az_cost_volume_bwd_ndhwc(float *grad_l, float *grad_r, const float *grad_cos
  * replaces nets/psmnet/psmnet_3.py:184-215 (F.interpolate trilinear x4,
  * squeeze, F.softmax over D) + nets/psmnet/psmnet_submodule_3.py:80-89
  * (DisparityRegression).  logits: [B,d,h,w]; disp_out: [B,4h,4w]; D = 4d. */
-int az_softargmin_fwd(float *disp_out, const float *logits, int B, int d, int h, int w,
+/* stats_out (may be NULL): [B,4h,4w,2] = per-pixel softmax shift and normaliser for the backward pass */
+int az_softargmin_fwd(float *disp_out, float *stats_out, const float *logits, int B, int d, int h,
+                      int w, void *stream);
+/* grad_logits [B,d,h,w] is OVERWRITTEN with d(sum grad_disp*disp)/d logits (the kernel zero-fills
+ * it first); logits are re-read.  stats + disp_fwd: what the forward wrote (both or neither; with
+ * neither the softmax statistics are recomputed). */
+int az_softargmin_bwd(float *grad_logits, const float *grad_disp, const float *logits,
+                      const float *stats, const float *disp_fwd, int B, int d, int h, int w,
                       void *stream);
-/* grad_logits [B,d,h,w] is OVERWRITTEN with d(sum grad_disp*disp)/d logits
- * (the kernel zero-fills it first); logits are re-read, nothing is saved. */
-int az_softargmin_bwd(float *grad_logits, const float *grad_disp, const float *logits, int B,
-                      int d, int h, int w, void *stream);
 
 /* ---- K7: bilinear gather warp ----------------------------------------------
  * replaces utils/reprojection.py:13-35 (apply_disparity: linspace grid +

@@ -35,7 +35,7 @@ def test_argument_validation_happens_before_any_launch(handle):
     p = ctypes.cast(buf, ctypes.c_void_p)
     assert handle.az_warp_scatter(p, p, p, 1, 1, 0, 4, 1, None) == -1
     assert handle.az_cost_volume_fwd(p, p, p, 1, 32, 0, 4, 4, None) == -1
-    assert handle.az_softargmin_fwd(p, None, 1, 4, 4, 4, None) == -2
+    assert handle.az_softargmin_fwd(p, None, None, 1, 4, 4, 4, None) == -2
     assert handle.az_patch_reproj_fwd(p, p, p, p, None, 1, 1, 8, 8, 4, -1.0, None) == -1
     assert handle.az_patch_reproj_fwd(p, p, p, p, None, 1, 1, 8, 8, 17, -1.0, None) == -4
 

@@ -53,7 +53,7 @@ out = ops.softargmin(lg)
 row("K6 `az_softargmin_fwd` (per head)", timeit(lambda: ops.softargmin(lg.detach())), 4.0 * B * (d * h * w + H * W), "VALU/exp bound: 192 expf per pixel")
 go = torch.randn_like(out)
 glg = torch.empty_like(lg)
-row("K6 `az_softargmin_bwd` (per head)", timeit(lambda: ops._call("az_softargmin_bwd", glg.data_ptr(), go.data_ptr(), lg.data_ptr(), B, d, h, w, ops._stream())), 4.0 * B * (2 * d * h * w + H * W), "recompute + LDS/global float atomics")
+row("K6 `az_softargmin_bwd` (per head)", timeit(lambda: ops._call("az_softargmin_bwd", glg.data_ptr(), go.data_ptr(), lg.data_ptr(), None, None, B, d, h, w, ops._stream())), 4.0 * B * (2 * d * h * w + H * W), "recompute + LDS/global float atomics")
 # K7 gather warp
 img = torch.randn(B, 1, H, W, device=dev)
 dsp = (8 * torch.rand(B, 1, H, W, device=dev)).requires_grad_()
