@@ -4,9 +4,10 @@
 //
 // N = 1 is not MFMA-shaped (and fp32 MFMA runs at the VALU rate anyway): these are
 // VALU kernels, 2*27*32 flops per voxel against 128 B of input -> HBM/LDS bound.
-//   fwd   : block = 8x32 output voxels of one (b, d) plane; per kd the 10x34x32ch
-//           input slab is staged in LDS (voxel stride 36 dwords), weights are
-//           wave-uniform scalar loads.  Optional fused "+ previous cost".
+//   fwd   : block = 8x32 output voxels marching over a depth segment (chosen per launch); each 10x34x32ch input
+//           slab is staged once in LDS (voxel stride 36 dwords) and feeds three output planes
+//           through rolling accumulators; weights are wave-uniform scalar loads.  Optional
+//           fused "+ previous cost".
 //   dgrad : gin[v][c] = sum_k gout[v+1-k] * w[c][k]; 8 lanes per voxel (one channel
 //           quad each) -> every voxel's 128 B is written coalesced; the 3x10x34 gout
 //           halo tile lives in LDS, the lane's 108 weights in registers.
@@ -18,49 +19,61 @@
 #define C1_TW 32
 #define C1_VS 36
 
+
+// Marches along depth: input plane `id` is staged once and feeds the three output planes
+// id+1 (kd=0), id (kd=1), id-1 (kd=2) through three rolling accumulators, so the slab and every
+// LDS read are shared by three taps (the first version re-staged three planes per output plane:
+// 3x the global and LDS traffic, 0.75 ms at B=4 full size).
 __global__ void __launch_bounds__(256)
 c1_fwd_kernel(float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
-              const float *__restrict__ addend, int D, int H, int W, int tiles_x) {
+              const float *__restrict__ addend, int D, int H, int W, int tiles_x, int dseg) {
     extern __shared__ __attribute__((aligned(16))) float slab[];  // (TH+2)*(TW+2)*36
     const int tx0 = (blockIdx.x % tiles_x) * C1_TW, ty0 = (blockIdx.x / tiles_x) * C1_TH;
-    const int od = blockIdx.y, b = blockIdx.z;
+    const int d0 = blockIdx.y * dseg, d1 = min(d0 + dseg, D), b = blockIdx.z;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
-    float acc = 0.f;
-    for (int kd = 0; kd < 3; ++kd) {
-        const int id = od - 1 + kd;
-        if (id < 0 || id >= D) continue;  // block-uniform
-        __syncthreads();
-        for (int q = threadIdx.x; q < SY * SX * 8; q += 256) {
-            const int v = q >> 3, part = q & 7;
-            const int sy = v / SX, sx = v - sy * SX;
-            const int ih = ty0 - 1 + sy, iw = tx0 - 1 + sx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-                val = *reinterpret_cast<const float4 *>(
-                    in + ((((size_t)b * D + id) * H + ih) * W + iw) * 32 + part * 4);
-            *reinterpret_cast<float4 *>(&slab[v * C1_VS + part * 4]) = val;
-        }
-        __syncthreads();
-        for (int kh = 0; kh < 3; ++kh)
-            for (int kw = 0; kw < 3; ++kw) {
-                const float *ap = &slab[((ly + kh) * SX + lx + kw) * C1_VS];
-                const int tap = (kd * 3 + kh) * 3 + kw;
+    const int oh = ty0 + ly, ow = tx0 + lx;
+    const bool live = oh < H && ow < W;
+    float a_prev = 0.f, a_cur = 0.f, a_next = 0.f;  // output planes id-1, id, id+1
+    for (int id = d0 - 1; id <= d1; ++id) {
+        if (id >= 0 && id < D) {  // block-uniform; planes outside the volume are zero padding
+            __syncthreads();
+            for (int q = threadIdx.x; q < SY * SX * 8; q += 256) {
+                const int v = q >> 3, part = q & 7;
+                const int sy = v / SX, sx = v - sy * SX;
+                const int ih = ty0 - 1 + sy, iw = tx0 - 1 + sx;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                    val = *reinterpret_cast<const float4 *>(
+                        in + ((((size_t)b * D + id) * H + ih) * W + iw) * 32 + part * 4);
+                *reinterpret_cast<float4 *>(&slab[v * C1_VS + part * 4]) = val;
+            }
+            __syncthreads();
+            // channel quad outermost: its 4 x 27 weights are contiguous in w ([1][32][27]) and
+            // wave-uniform -> wide scalar loads
+#pragma unroll 1
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const float *wq = w + c4 * 4 * 27;
 #pragma unroll
-                for (int c4 = 0; c4 < 8; ++c4) {
-                    const float4 x = *reinterpret_cast<const float4 *>(ap + 4 * c4);
-                    // w is [1][32][27]: element (ci, tap) at ci*27 + tap (wave-uniform)
-                    acc += x.x * w[(4 * c4 + 0) * 27 + tap];
-                    acc += x.y * w[(4 * c4 + 1) * 27 + tap];
-                    acc += x.z * w[(4 * c4 + 2) * 27 + tap];
-                    acc += x.w * w[(4 * c4 + 3) * 27 + tap];
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    const float4 x = *reinterpret_cast<const float4 *>(
+                        &slab[((ly + t9 / 3) * SX + lx + t9 % 3) * C1_VS + 4 * c4]);
+                    const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a_next += xs[e] * wq[e * 27 + t9];       // kd = 0 -> output plane id+1
+                        a_cur += xs[e] * wq[e * 27 + 9 + t9];    // kd = 1 -> id
+                        a_prev += xs[e] * wq[e * 27 + 18 + t9];  // kd = 2 -> id-1
+                    }
                 }
             }
-    }
-    const int oh = ty0 + ly, ow = tx0 + lx;
-    if (oh < H && ow < W) {
-        const size_t o = (((size_t)b * D + od) * H + oh) * W + ow;
-        out[o] = addend ? acc + addend[o] : acc;
+        }
+        const int od = id - 1;  // complete now: it has seen planes od-1, od, od+1
+        if (od >= d0 && od < d1 && live) {
+            const size_t o = (((size_t)b * D + od) * H + oh) * W + ow;
+            out[o] = addend ? a_prev + addend[o] : a_prev;
+        }
+        a_prev = a_cur; a_cur = a_next; a_next = 0.f;
     }
 }
 
@@ -185,8 +198,18 @@ extern "C" int az_conv3d_c1_fwd(float *logits, const float *in, const float *w,
     if (int e = c1_check(B, D, H, W)) return e;
     const int tiles_x = (W + C1_TW - 1) / C1_TW, tiles_y = (H + C1_TH - 1) / C1_TH;
     const size_t lds = (size_t)(C1_TH + 2) * (C1_TW + 2) * C1_VS * sizeof(float);
-    hipLaunchKernelGGL(c1_fwd_kernel, dim3(tiles_x * tiles_y, D, B), dim3(256), lds,
-                       az_stream(stream), logits, in, w, addend, D, H, W, tiles_x);
+    // depth segment per block: every segment stages 2 halo planes, and the grid should fill a whole
+    // number of residency rounds (3 blocks of 49 KB LDS per CU x 256 CUs); minimise rounds x planes
+    int best = 1;
+    long long best_cost = -1;
+    for (int nseg = 1; nseg <= D; ++nseg) {
+        const int dseg = (D + nseg - 1) / nseg;
+        const long long blocks = (long long)tiles_x * tiles_y * B * ((D + dseg - 1) / dseg);
+        const long long cost = ((blocks + 767) / 768) * (dseg + 2);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = dseg; }
+    }
+    hipLaunchKernelGGL(c1_fwd_kernel, dim3(tiles_x * tiles_y, (D + best - 1) / best, B), dim3(256), lds,
+                       az_stream(stream), logits, in, w, addend, D, H, W, tiles_x, best);
     return az_launch_status();
 }
 

@@ -42,14 +42,17 @@ class hourglass(nn.Module):
         self.conv5 = _up_unit(c2, c2)
         self.conv6 = _up_unit(c2, inplanes)
 
-    def forward(self, x, presqu, postqu):
+    def forward(self, x, presqu, postqu, out_add=None):
+        """Reference signature (psmnet_3.py:36) plus `out_add`: a tensor added to `out` inside conv6's
+        BatchNorm pass -- PSMNet.forward adds cost0 to every hourglass output (psmnet_3.py:166-175),
+        which otherwise is one more read+write of the 32-channel V0 tensor per hourglass."""
         down = agg3d.conv_bn(x, self.conv1[0], relu=True)
         pre = agg3d.conv_bn(down, self.conv2, relu=True, add=postqu)
         deep = agg3d.conv_bn(pre, self.conv3[0], relu=True)
         deep = agg3d.conv_bn(deep, self.conv4[0], relu=True)
         post = agg3d.deconv_bn(deep, self.conv5, relu=True,
                                add=pre if presqu is None else presqu)
-        out = agg3d.deconv_bn(post, self.conv6)
+        out = agg3d.deconv_bn(post, self.conv6, add=out_add)
         return out, pre, post
 
 
@@ -100,12 +103,9 @@ class PSMNet(nn.Module):
         t = agg3d.conv_bn(c0, self.dres1[0], relu=True)
         c0 = agg3d.conv_bn(t, self.dres1[2], add=c0)
 
-        out1, pre1, post1 = self.dres2(c0, None, None)
-        out1 = agg3d.add(out1, c0)
-        out2, _pre2, post2 = self.dres3(out1, pre1, post1)
-        out2 = agg3d.add(out2, c0)
-        out3, _pre3, _post3 = self.dres4(out2, pre1, post2)
-        out3 = agg3d.add(out3, c0)
+        out1, pre1, post1 = self.dres2(c0, None, None, out_add=c0)   # out_k + cost0 fused
+        out2, _pre2, post2 = self.dres3(out1, pre1, post1, out_add=c0)
+        out3, _pre3, _post3 = self.dres4(out2, pre1, post2, out_add=c0)
 
         def head(cls, v, running):
             return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True), cls[2], running)
