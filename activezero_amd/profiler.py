@@ -55,8 +55,10 @@ def stop():
 
 
 # profiler scope name -> kernel symbol in the rocprofv3 PMC summary
-_PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_gather_kernel<32, 32, 0, 1, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 1, 0, 0>"),
-              "dgrad_m0_32_32": ("conv3d_gather_kernel<32, 32, 0, 0, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 0, 0, 0>"),
+_PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_m128_kernel<32, 1, 0>", "conv3d_gather_kernel<32, 32, 0, 1, 0, 1>",
+                                  "conv3d_gather_kernel<32, 32, 0, 1, 0, 0>"),
+              "dgrad_m0_32_32": ("conv3d_m128_kernel<32, 0, 0>", "conv3d_gather_kernel<32, 32, 0, 0, 0, 1>",
+                                 "conv3d_gather_kernel<32, 32, 0, 0, 0, 0>"),
               "conv_wgrad_s1_32_32": ("conv3d_wgrad_x6_kernel<32, 32, 1>", "conv3d_wgrad_kernel<32, 32, 1>")}
 
 
