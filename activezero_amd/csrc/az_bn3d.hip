@@ -240,6 +240,54 @@ add_relu_kernel(float4 *__restrict__ y, const float4 *__restrict__ a,
     }
 }
 
+
+// Standalone batch statistics of a channels-last tensor x[nvox][C] (used where the producer is not
+// one of our convolutions: the 2-D feature extractor's MIOpen convs).  Block `t` reduces voxels
+// t*VPB + k*gridDim*VPB ... to one (sum, centred M2, count) partial per channel, in the layout
+// az_bn3d_finalize consumes ([C][tiles][2], counts[tiles]).  Sums are taken about the block's first
+// voxel (shifted data) so M2 = S2 - S1^2/n does not cancel.
+template <int C>
+__global__ void __launch_bounds__(256)
+bn_stats_kernel(float *__restrict__ part, float *__restrict__ cnt, const float *__restrict__ x,
+                long long nvox, long long ntiles) {
+    constexpr int C4 = C / 4, VPB = 256 / C4;
+    const int c4 = threadIdx.x % C4, vl = threadIdx.x / C4;
+    const long long v0 = (long long)blockIdx.x * VPB;  // first voxel of this block: always < nvox
+    const float4 K = reinterpret_cast<const float4 *>(x)[(size_t)v0 * C4 + c4];
+    float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    int n = 0;
+    for (long long v = v0 + vl; v < nvox; v += (long long)gridDim.x * VPB) {
+        const float4 a = reinterpret_cast<const float4 *>(x)[(size_t)v * C4 + c4];
+        const float dx = a.x - K.x, dy = a.y - K.y, dz = a.z - K.z, dw = a.w - K.w;
+        s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+        s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+        ++n;
+    }
+    __shared__ float4 r1[256], r2[256];
+    __shared__ int rn[256];
+    r1[threadIdx.x] = s1; r2[threadIdx.x] = s2; rn[threadIdx.x] = n;
+    __syncthreads();
+    if (vl == 0) {
+        for (int k = 1; k < VPB; ++k) {
+            const float4 a = r1[k * C4 + c4], b = r2[k * C4 + c4];
+            s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+            s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+            n += rn[k * C4 + c4];
+        }
+        const float fn = (float)n;
+        const float s[4] = {s1.x, s1.y, s1.z, s1.w}, q[4] = {s2.x, s2.y, s2.z, s2.w};
+        const float k4[4] = {K.x, K.y, K.z, K.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float2 o;
+            o.x = s[e] + fn * k4[e];                       // sum of x
+            o.y = fmaxf(q[e] - s[e] * s[e] / fn, 0.f);     // centred second moment
+            reinterpret_cast<float2 *>(part)[(size_t)(c4 * 4 + e) * ntiles + blockIdx.x] = o;
+        }
+        if (c4 == 0) cnt[blockIdx.x] = fn;
+    }
+}
+
 #define BN_GRID(total) az_grid_for((total), 256)
 
 extern "C" int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
@@ -281,13 +329,16 @@ extern "C" int az_bn3d_apply(float *y, const float *x, const float *scale, const
     else if (C == 64)
         hipLaunchKernelGGL(bn_apply_kernel<64>, dim3(BN_GRID(total4)), dim3(256), 0, az_stream(stream),
                            (float4 *)y, (const float4 *)x, scale, shift, r4, relu, total4);
+    else if (C == 128)
+        hipLaunchKernelGGL(bn_apply_kernel<128>, dim3(BN_GRID(total4)), dim3(256), 0, az_stream(stream),
+                           (float4 *)y, (const float4 *)x, scale, shift, r4, relu, total4);
     else
         return AZ_EUNSUPPORTED;
     return az_launch_status();
 }
 
 extern "C" long long az_bn3d_bwd_workspace(long long nvox, int C) {
-    if (nvox <= 0 || (C != 32 && C != 64)) return AZ_EINVAL;
+    if (nvox <= 0 || (C != 32 && C != 64 && C != 128)) return AZ_EINVAL;
     const int vpb = 256 / (C / 4);
     const long long blocks = az_grid_for((nvox + vpb - 1) / vpb * 256, 256);
     return blocks * C * 2 * (long long)sizeof(float);
@@ -311,8 +362,11 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
     if (C == 32) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
                            x, mean, invstd, relu, nvox);
-    } else {
+    } else if (C == 64) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
+                           x, mean, invstd, relu, nvox);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<128>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
                            x, mean, invstd, relu, nvox);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef,
@@ -321,8 +375,12 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
         hipLaunchKernelGGL(bn_bwd_apply_kernel<32>, dim3(BN_GRID(total4)), dim3(256), 0, s,
                            (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
                            (const float4 *)x, mean, invstd, coef, relu, total4);
-    else
+    else if (C == 64)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<64>, dim3(BN_GRID(total4)), dim3(256), 0, s,
+                           (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
+                           (const float4 *)x, mean, invstd, coef, relu, total4);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<128>, dim3(BN_GRID(total4)), dim3(256), 0, s,
                            (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
                            (const float4 *)x, mean, invstd, coef, relu, total4);
     return az_launch_status();
@@ -334,5 +392,30 @@ extern "C" int az_add_relu(float *y, const float *a, const float *b, int relu, l
     AZ_REQUIRE(n > 0 && n % 4 == 0);
     hipLaunchKernelGGL(add_relu_kernel, dim3(BN_GRID(n / 4)), dim3(256), 0, az_stream(stream),
                        (float4 *)y, (const float4 *)a, (const float4 *)b, relu, n / 4);
+    return az_launch_status();
+}
+
+// number of partial tiles az_bn3d_stats writes for a tensor of nvox voxels
+extern "C" long long az_bn3d_stats_tiles(long long nvox, int C) {
+    if (nvox <= 0 || (C != 32 && C != 64 && C != 128)) return AZ_EINVAL;
+    const int vpb = 256 / (C / 4);
+    long long t = (nvox + (long long)vpb * 16 - 1) / ((long long)vpb * 16);  // >= 16 voxels per thread
+    if (t > 2048) t = 2048;
+    if (t < 1) t = 1;
+    return t;
+}
+
+extern "C" int az_bn3d_stats(float *partials, float *counts, const float *x, long long nvox, int C,
+                             void *stream) {
+    AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts); AZ_REQUIRE_PTR(x);
+    const long long tiles = az_bn3d_stats_tiles(nvox, C);
+    if (tiles < 0) return (int)tiles;
+    hipStream_t s = az_stream(stream);
+    if (C == 32)
+        hipLaunchKernelGGL(bn_stats_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, s, partials, counts, x, nvox, tiles);
+    else if (C == 64)
+        hipLaunchKernelGGL(bn_stats_kernel<64>, dim3((unsigned)tiles), dim3(256), 0, s, partials, counts, x, nvox, tiles);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, s, partials, counts, x, nvox, tiles);
     return az_launch_status();
 }

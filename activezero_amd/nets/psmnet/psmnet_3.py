@@ -128,5 +128,5 @@ class PSMNet(nn.Module):
         return img.contiguous(memory_format=torch.channels_last)
 
     def forward(self, img_L, img_R):
-        return self._from_features(self.feature_extraction(self._nhwc(img_L)),
-                                   self.feature_extraction(self._nhwc(img_R)))
+        # both images in one pass of the extractor, statistics per image set (forward_pair)
+        return self._from_features(*self.feature_extraction.forward_pair(self._nhwc(img_L), self._nhwc(img_R)))

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 import os
 
-from activezero_amd import conv3d, ops
+from activezero_amd import bn2d, conv3d, ops
 
 # 2-D stage backend.  "miopen" (default): PyTorch-ROCm/MIOpen modules, channels-last.
 # "hip" (opt-in experiment): the 3x3 stride-1 32/64-channel conv+BN(+ReLU)(+residual) units of
@@ -21,14 +21,23 @@ from activezero_amd import conv3d, ops
 # MI355X at B=4, 544x960: 190.2 ms/step vs 184.9 ms with MIOpen -- the 2-D layers are small
 # (<= 10 GFLOP each) and launch/occupancy bound on the 3-D tiling, so MIOpen stays the default
 # until the 2-D stage gets its own tiling.
-FE2D_BACKEND = os.environ.get("AZ_FE2D", "miopen")
+# AZ_FE2D: "fused" (default) = MIOpen convolutions + the HIP BatchNorm kernels with ReLU / residual
+# folded into the normalisation pass and per-group batch statistics (left and right images run as
+# ONE batch of 2B, activezero_amd/bn2d.py); "miopen" = plain torch modules, two passes; "hip" = the
+# stride-1 3x3 layers on the 3-D gather kernels (experiment, slower).
+FE2D_BACKEND = os.environ.get("AZ_FE2D", "fused")
+_STAT_GROUPS = 1  # batch-statistic groups of the pass in flight (2 inside forward_pair)
 
 
 def _convbn_unit(x, unit, relu=False, residual=None):
     """unit = Sequential(Conv2d, BatchNorm2d): y = relu?(bn(conv(x)) + residual)"""
     conv, bn = unit[0], unit[1]
-    if FE2D_BACKEND == "hip" and x.is_cuda and conv3d.supports_2d(conv):
+    if FE2D_BACKEND == "hip" and x.is_cuda and conv3d.supports_2d(conv) and _STAT_GROUPS == 1:
         return conv3d.conv_bn_2d(x, conv, bn, relu, residual)
+    if FE2D_BACKEND != "miopen" and bn2d.supported(bn, x):
+        return bn2d.bn_act(conv(x), bn, relu, residual, _STAT_GROUPS)
+    if _STAT_GROUPS != 1:
+        raise RuntimeError("grouped batch statistics need the fused BatchNorm path")
     y = unit(x)
     if residual is not None:
         y = y + residual
@@ -73,7 +82,7 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
+        shortcut = x if self.downsample is None else _convbn_unit(x, self.downsample)
         y = _convbn_unit(x, self.conv1[0], relu=True)
         return _convbn_unit(y, self.conv2, relu=False, residual=shortcut)
 
@@ -162,7 +171,7 @@ class FeatureExtraction(nn.Module):
         return nn.Sequential(*layers)
 
     def _trunk(self, x):
-        y = F.relu(self.firstconv[0](x))
+        y = _convbn_unit(x, self.firstconv[0], relu=True)
         y = _convbn_unit(y, self.firstconv[2], relu=True)
         y = _convbn_unit(y, self.firstconv[4], relu=True)
         raw = self.layer2(self.layer1(y))
@@ -177,10 +186,27 @@ class FeatureExtraction(nn.Module):
             pooled[win] = p
         assert sorted(pooled) == [8, 16, 32, 64]
         win_of = dict(_SPP_WINDOWS)
-        pyramid = [upsample_bilinear_ac(getattr(self, f"branch{i}")[1:](pooled[win_of[i]]), size)
-                   for i in (4, 3, 2, 1)]
-        return self.lastconv(torch.cat([raw, skip] + pyramid, 1))
+        pyramid = [upsample_bilinear_ac(_convbn_unit(pooled[win_of[i]], getattr(self, f"branch{i}")[1], relu=True),
+                                        size) for i in (4, 3, 2, 1)]
+        y = _convbn_unit(torch.cat([raw, skip] + pyramid, 1), self.lastconv[0], relu=True)
+        return self.lastconv[2](y)
 
     def forward(self, x):
         """[B,3,H,W] -> [B,32,H/4,W/4]"""
         return self._trunk(x)
+
+    def forward_pair(self, left, right):
+        """(feature_extraction(left), feature_extraction(right)) of psmnet_3.py:145-146 in ONE pass
+        over the stacked batch: every BatchNorm takes its statistics per image set and updates its
+        running statistics left first, then right, exactly as the two sequential calls do."""
+        global _STAT_GROUPS
+        if FE2D_BACKEND == "miopen" or not left.is_cuda or left.shape != right.shape:
+            return self._trunk(left), self._trunk(right)
+        x = torch.cat([left, right], 0).contiguous(memory_format=torch.channels_last)
+        _STAT_GROUPS = 2
+        try:
+            y = self._trunk(x)
+        finally:
+            _STAT_GROUPS = 1
+        b = left.shape[0]
+        return y[:b], y[b:]

@@ -181,6 +181,11 @@ int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
                      float *running_mean, float *running_var, const float *partials,
                      const float *counts, const float *gamma, const float *beta,
                      long long ntiles, int C, float eps, float momentum, void *stream);
+/* batch statistics of a channels-last tensor x[nvox][C] (C = 32, 64, 128) whose producer is not one
+ * of these convolutions (the 2-D extractor's layers, nets/psmnet/psmnet_submodule_3.py:8-22):
+ * partials [C][tiles][2], counts [tiles] with tiles = az_bn3d_stats_tiles(nvox, C), for az_bn3d_finalize */
+long long az_bn3d_stats_tiles(long long nvox, int C);
+int az_bn3d_stats(float *partials, float *counts, const float *x, long long nvox, int C, void *stream);
 int az_bn3d_eval_affine(float *scale, float *shift, const float *gamma, const float *beta,
                         const float *running_mean, const float *running_var, float eps, int C,
                         void *stream);

@@ -94,3 +94,53 @@ def test_config0_shape_eval_forward_vs_oracle():
         out = model(il.to(DEV), ir.to(DEV))
     assert out.shape == (1, 1, 256, 512)
     disp_close(out, ref.numpy())
+
+
+def test_feature_extraction_pair_equals_two_sequential_passes():
+    """forward_pair (one pass over the stacked batch, HIP BatchNorm with per-image-set statistics,
+    ReLU / residual fused) against the reference order of operations: feature_extraction(left) then
+    feature_extraction(right) on plain torch modules (psmnet_3.py:145-146).  Features and every
+    BatchNorm's running statistics / batch counter must agree to rounding.  Gradients pass through
+    ~60 train-mode BatchNorms, some over a handful of samples (the 64-pixel SPP branch), which
+    amplifies the rounding differences between MIOpen's batch-2B and batch-B convolution algorithms
+    (two runs of the SAME torch path differ by 1e-2 at 256x320): they are checked in the L2 sense;
+    the exact BatchNorm forward/backward formulas are pinned in test_gpu_bn2d.py."""
+    import copy
+
+    from activezero_amd.nets.psmnet import psmnet_submodule_3 as sub
+
+    torch.manual_seed(3)
+    fused = sub.FeatureExtraction().to(DEV).to(memory_format=torch.channels_last).train()
+    plain = copy.deepcopy(fused)
+    left = torch.randn(2, 3, 512, 640, device=DEV).contiguous(memory_format=torch.channels_last)
+    right = torch.randn(2, 3, 512, 640, device=DEV).contiguous(memory_format=torch.channels_last)
+    gl, gr = torch.randn(2, 32, 128, 160, device=DEV), torch.randn(2, 32, 128, 160, device=DEV)
+
+    def run(net, backend):
+        old = sub.FE2D_BACKEND
+        sub.FE2D_BACKEND = backend
+        try:
+            a, b = left.clone().requires_grad_(), right.clone().requires_grad_()
+            fa, fb = net.forward_pair(a, b)
+            ((fa * gl).sum() + (fb * gr).sum()).backward()
+            return fa.detach(), fb.detach(), a.grad, b.grad
+        finally:
+            sub.FE2D_BACKEND = old
+
+    got = run(fused, "fused")
+    want = run(plain, "miopen")
+    for g, w in zip(got[:2], want[:2]):
+        assert torch.allclose(g, w, rtol=1e-4, atol=2e-5 * float(w.abs().max())), float((g - w).abs().max())
+    rel = lambda g, w: float((g - w).norm() / (w.norm() + 1e-20))
+    for g, w in zip(got[2:], want[2:]):
+        assert rel(g, w) < 2e-2, rel(g, w)
+    want_params = dict(plain.named_parameters())
+    for name, p in fused.named_parameters():
+        assert rel(p.grad, want_params[name].grad) < 2e-2, (name, rel(p.grad, want_params[name].grad))
+    want_buf = dict(plain.named_buffers())
+    for name, b in fused.named_buffers():
+        w = want_buf[name]
+        if b.dtype.is_floating_point:
+            assert torch.allclose(b, w, rtol=1e-5, atol=1e-6), name
+        else:
+            assert torch.equal(b, w), name  # num_batches_tracked: two updates per BatchNorm
