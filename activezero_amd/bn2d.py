@@ -86,18 +86,17 @@ class _BNAct(torch.autograd.Function):
         lib = _lib.lib()
         dxr = torch.empty_like(xr)
         dzr = torch.empty_like(xr) if (has_res and relu) else None
-        dgamma, dbeta = gr.new_zeros(c), gr.new_zeros(c)
+        dgb = gr.new_empty(groups, 2, c)  # per-group (dgamma, dbeta), summed once below
         with torch.cuda.device(gr.device):
             ws_bytes = lib.az_bn3d_bwd_workspace(nvox, c)
             ws, coef = gr.new_empty(ws_bytes // 4), gr.new_empty(c, 3)
             for g in range(groups):
                 sl = slice(g * nb, (g + 1) * nb)
-                dg, db = gr.new_empty(c), gr.new_empty(c)
-                _call("az_bn3d_bwd", _p(dxr[sl]), _p(dzr[sl]) if dzr is not None else None, _p(dg), _p(db),
-                      _p(coef), _p(ws), ws_bytes, _p(gr[sl]), _p(yr[sl]) if relu else None, _p(xr[sl]),
-                      _p(means[g]), _p(invstds[g]), _p(gamma.detach()), int(relu), nvox, c, _stream())
-                dgamma += dg
-                dbeta += db
+                _call("az_bn3d_bwd", _p(dxr[sl]), _p(dzr[sl]) if dzr is not None else None, _p(dgb[g, 0]),
+                      _p(dgb[g, 1]), _p(coef), _p(ws), ws_bytes, _p(gr[sl]), _p(yr[sl]) if relu else None,
+                      _p(xr[sl]), _p(means[g]), _p(invstds[g]), _p(gamma.detach()), int(relu), nvox, c, _stream())
+        dgb = dgb.sum(0) if groups > 1 else dgb[0]
+        dgamma, dbeta = dgb[0], dgb[1]
         g_res = None
         if has_res:
             g_res = (dzr if relu else gr).permute(0, 3, 1, 2)

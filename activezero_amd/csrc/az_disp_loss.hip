@@ -14,15 +14,25 @@ __device__ __forceinline__ bool dl_valid(const unsigned char *mask, float gt, fl
     return mask ? (mask[i] != 0) : (gt > lo && gt < hi);
 }
 
-// wave reduction (64 lanes) then one fp64 atomic per wave and accumulator
+// block reduction (wave shuffles, then LDS across the 4 waves) and ONE fp64 atomic per block and
+// accumulator: with an atomic per wave the 130 k same-address adds of a 4 x 544 x 960 map
+// serialised in L2 and the kernel took 0.79 ms instead of ~15 us
 template <int N>
 __device__ __forceinline__ void dl_flush(double (&v)[N], double *acc) {
+    __shared__ double red[DL_BLOCK / 64][N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double x = v[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(&acc[k], x);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double x = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < DL_BLOCK / 64; ++wv) x += red[wv][threadIdx.x];
+        if (x != 0.0) atomicAdd(&acc[threadIdx.x], x);
     }
 }
 
@@ -90,13 +100,19 @@ disp_metrics_kernel(double *__restrict__ acc, const float *__restrict__ disp_gt,
     dl_flush<8>(v, acc);
 }
 
+// reductions: at most 1024 blocks (4 per CU), each strides over the map
+static unsigned dl_reduce_grid(long long n) {
+    const unsigned g = az_grid_for(n, DL_BLOCK);
+    return g > 1024u ? 1024u : g;
+}
+
 extern "C" int az_disp_loss_fwd(double *acc4, const float *pred3, const float *pred2, const float *pred1,
                                 const float *gt, const unsigned char *mask, float lo, float hi,
                                 long long n, void *stream) {
     AZ_REQUIRE_PTR(acc4); AZ_REQUIRE_PTR(pred3); AZ_REQUIRE_PTR(pred2); AZ_REQUIRE_PTR(pred1); AZ_REQUIRE_PTR(gt);
     AZ_REQUIRE(n >= 0);
     if (n == 0) return AZ_OK;
-    hipLaunchKernelGGL(disp_loss_fwd_kernel, dim3(az_grid_for(n, DL_BLOCK)), dim3(DL_BLOCK), 0, az_stream(stream),
+    hipLaunchKernelGGL(disp_loss_fwd_kernel, dim3(dl_reduce_grid(n)), dim3(DL_BLOCK), 0, az_stream(stream),
                        acc4, pred3, pred2, pred1, gt, mask, lo, hi, n);
     return az_launch_status();
 }
@@ -124,7 +140,7 @@ extern "C" int az_disp_metrics(double *acc8, const float *disp_gt, const float *
     AZ_REQUIRE(B >= 0 && per_batch >= 0);
     const long long n = (long long)B * per_batch;
     if (n == 0) return AZ_OK;
-    hipLaunchKernelGGL(disp_metrics_kernel, dim3(az_grid_for(n, DL_BLOCK)), dim3(DL_BLOCK), 0, az_stream(stream),
+    hipLaunchKernelGGL(disp_metrics_kernel, dim3(dl_reduce_grid(n)), dim3(DL_BLOCK), 0, az_stream(stream),
                        acc8, disp_gt, depth_gt, disp_pred, depth_pred, focal_x_baseline, mask, per_batch, n);
     return az_launch_status();
 }
