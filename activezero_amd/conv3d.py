@@ -111,6 +111,8 @@ def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=Non
     do, ho, wo = _out_dims(mode, d, h, w)
     out = x.new_empty(b, do, ho, wo, cout)
     flops = _conv_flops(b, do * ho * wo, cin, cout, mode)
+    if d == 1 and mode == CONV_S1:
+        flops /= 3.0  # a depth-1 volume (2-D layer): only the 9 taps of the centre depth slice exist
     name = f"{tag}_m{mode}_{cin}_{cout}"
     if stats:
         ntiles = _lib.lib().az_conv3d_num_tiles(mode, b, d, h, w)
@@ -132,7 +134,8 @@ def _wgrad(coarse, fine, stride, cm, cn, tag):
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
     ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
     ws = coarse.new_empty(ws_bytes // 4)
-    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
+    taps = 9 if (dc == 1 and df == 1) else 27  # depth-1 volumes: the 2-D layers
+    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * taps * cm * cn * b * dc * hc * wc,
                         peak=_peak(WGRAD_PRECISION)):
         _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, WGRAD_PRECISION,
               b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
@@ -337,6 +340,46 @@ def _as_volume(x):
 def _as_image(v):
     """[B,1,H,W,C] volume -> [B,C,H,W] tensor in channels_last memory format (a view)."""
     return v.squeeze(1).permute(0, 3, 1, 2)
+
+
+class _Conv2dS1(torch.autograd.Function):
+    """conv2d(x, w) for a 3x3, stride-1, pad-1, dilation-1 layer with 32 or 64 channels on the bf16x6 gather
+    kernels (the image is a depth-1 volume).  Backward: input gradient on the same kernels; weight
+    gradient on the bf16x6 wgrad kernel or, with AZ_FE2D_WGRAD=miopen, through ATen."""
+
+    @staticmethod
+    def forward(ctx, x, w2d):
+        xv = _chk(_as_volume(x), "x")
+        w3 = w2d.detach().new_zeros(*w2d.shape[:2], 3, 3, 3)
+        w3[:, :, 1] = w2d.detach()
+        packed, cin, cout = _pack_forward(w3, CONV_S1)
+        y = _run_gather(xv, packed, CONV_S1, cin, cout, tag="fe2d")
+        ctx.save_for_backward(xv, w3)
+        ctx.cfg = (cin, cout)
+        return _as_image(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, w3 = ctx.saved_tensors
+        cin, cout = ctx.cfg
+        gv = _chk(_as_volume(gy), "grad_y")
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            pk = _pack(w3, cout, cin, 27, cin * 27, True)
+            gx = _as_image(_run_gather(gv, pk, CONV_S1, cout, cin, tag="fe2d_dgrad"))
+        if ctx.needs_input_grad[1]:
+            if os.environ.get("AZ_FE2D_WGRAD", "hip") == "miopen":
+                gw = torch.ops.aten.convolution_backward(
+                    gy, _as_image(xv), w3[:, :, 1], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                    [False, True, False])[1]
+            else:
+                gw = _wgrad(gv, xv, 1, cout, cin, "fe2d")[:, :, 1].contiguous()
+        return gx, gw
+
+
+def conv2d_s1(x, conv):
+    """conv(x) for a supports_2d() layer, differentiable; BatchNorm is applied by the caller (bn2d)."""
+    return _Conv2dS1.apply(x, conv.weight)
 
 
 def conv_bn_2d(x, conv, bn, relu=False, residual=None):

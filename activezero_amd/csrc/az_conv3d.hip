@@ -162,7 +162,16 @@ conv3d_gather_kernel(const ConvArgs a) {
 #endif
     constexpr bool ASINGLE = X6_BPIPE_NR1 && PREC == 1 && NR == 1 && MR == 2 && !X6_WIDE(COUT, MODE, PREC);
     constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : (X6_WIDE(COUT, MODE, PREC) || ASINGLE);
-    const int NS = nd * NCH;
+    // stages cover only the input planes that exist (a contiguous sd range): a zero-padding plane
+    // contributes nothing, so neither its slab nor its split / LDS traffic is spent -- matters at the
+    // depth borders and, above all, for depth-1 volumes (the extractor's 2-D layers: 1 plane of 3)
+    int sd_lo = 0, sd_hi = nd - 1;
+    {
+        const int p0 = (MODE == 0) ? td - 1 : (MODE == 1) ? 2 * td - 1 : td;  // plane of sd = 0
+        if (p0 < 0) sd_lo = -p0;                                             // (only MODE 0/1 start at -1)
+        if (p0 + sd_hi >= a.Di) sd_hi = a.Di - 1 - p0;
+    }
+    const int S0 = sd_lo * NCH, NS = (sd_hi + 1) * NCH;  // stage index range [S0, NS)
     float4 pre[NLD];
     unsigned okbits = 0;  // bit it: pre[it] holds real data (else zero padding)
 
@@ -292,9 +301,9 @@ conv3d_gather_kernel(const ConvArgs a) {
     };
 
     CV_T0();
-    issue(0);
+    if (S0 < NS) issue(S0);
     CV_ACC(0);
-    for (int s = 0; s < NS; ++s) {
+    for (int s = S0; s < NS; ++s) {
         const int sd = s / NCH, cc = s - sd * NCH;
         const int kd = (MODE == 2) ? (pd ? 2 - 2 * sd : 1) : sd;
         const int id = plane_of(sd);

@@ -26,6 +26,7 @@ from activezero_amd import bn2d, conv3d, ops
 # ONE batch of 2B, activezero_amd/bn2d.py); "miopen" = plain torch modules, two passes; "hip" = the
 # stride-1 3x3 layers on the 3-D gather kernels (experiment, slower).
 FE2D_BACKEND = os.environ.get("AZ_FE2D", "fused")
+FE2D_CONV = os.environ.get("AZ_FE2D_CONV", "miopen")
 _STAT_GROUPS = 1  # batch-statistic groups of the pass in flight (2 inside forward_pair)
 
 
@@ -35,7 +36,9 @@ def _convbn_unit(x, unit, relu=False, residual=None):
     if FE2D_BACKEND == "hip" and x.is_cuda and conv3d.supports_2d(conv) and _STAT_GROUPS == 1:
         return conv3d.conv_bn_2d(x, conv, bn, relu, residual)
     if FE2D_BACKEND != "miopen" and bn2d.supported(bn, x):
-        return bn2d.bn_act(conv(x), bn, relu, residual, _STAT_GROUPS)
+        # AZ_FE2D_CONV=hip: the stride-1 3x3 32/64-channel layers on the bf16x6 gather kernels
+        y = conv3d.conv2d_s1(x, conv) if (FE2D_CONV == "hip" and conv3d.supports_2d(conv)) else conv(x)
+        return bn2d.bn_act(y, bn, relu, residual, _STAT_GROUPS)
     if _STAT_GROUPS != 1:
         raise RuntimeError("grouped batch statistics need the fused BatchNorm path")
     y = unit(x)
