@@ -42,7 +42,7 @@ def close(a, b, rtol=1e-4, atol=1e-5):
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (32, 64), (64, 64)])
-@pytest.mark.parametrize("dims", [(1, 5, 7, 19), (2, 4, 8, 16), (1, 3, 9, 33)])
+@pytest.mark.parametrize("dims", [(1, 5, 7, 19), (2, 4, 8, 16), (1, 3, 9, 33), (1, 1, 9, 20), (1, 2, 16, 35)])
 def test_conv_stride1_vs_torch(cin, cout, dims):
     b, d, h, w = dims
     x = seeded((b, cin, d, h, w), 1)
@@ -250,3 +250,27 @@ def test_conv_bn_2d_unit_matches_torch_modules():
     close(unit[0].weight.grad, ref[0].weight.grad, 1e-3, 3e-4)
     close(unit[1].weight.grad, ref[1].weight.grad, 1e-3, 1e-3)
     close(unit[1].running_var, ref[1].running_var, 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("ch", [32, 64])
+@pytest.mark.parametrize("wgrad", ["hip", "miopen"])
+def test_conv2d_s1_matches_torch(ch, wgrad, monkeypatch):
+    """The opt-in convolution-only 2-D route (AZ_FE2D_CONV=hip): conv2d forward, input and weight
+    gradients against F.conv2d."""
+    monkeypatch.setenv("AZ_FE2D_WGRAD", wgrad)
+    conv = torch.nn.Conv2d(ch, ch, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(seeded((ch, ch, 3, 3), 71, -0.2, 0.2))
+    ref = torch.nn.Conv2d(ch, ch, 3, 1, 1, bias=False)
+    ref.load_state_dict(conv.state_dict())
+    conv = conv.to(DEV)
+    x, ct = seeded((3, ch, 13, 22), 72), seeded((3, ch, 13, 22), 73)
+    xr = x.clone().requires_grad_()
+    ref(xr).backward(ct)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    assert conv3d.supports_2d(conv)
+    y = conv3d.conv2d_s1(xg, conv)
+    close(y, ref(x), 1e-4, 2e-5)
+    y.backward(ct.to(DEV))
+    close(xg.grad, xr.grad, 1e-4, 5e-5)
+    close(conv.weight.grad, ref.weight.grad, 1e-4, 2e-4)
