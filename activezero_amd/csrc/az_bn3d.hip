@@ -25,8 +25,13 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
                    float *__restrict__ running_mean, float *__restrict__ running_var,
                    const float *__restrict__ part, const float *__restrict__ cnt,
                    const float *__restrict__ gamma, const float *__restrict__ beta,
-                   long long ntiles, int C, float eps, float momentum) {
+                   long long ntiles, int C, float eps, float momentum, int groups) {
     const int c = blockIdx.x;
+    // statistic groups (bn2d: the left and the right image set) are finalised one after the other
+    // by the same block, so the running statistics see them in order, as two module calls would
+    for (int grp = 0; grp < groups; ++grp, part += (long long)C * ntiles * 2, cnt += ntiles,
+             mean_out += C, invstd_out += C, scale += C, shift += C) {
+    __syncthreads();
     // pass 1: N = sum n_t, S = sum s_t  ->  mean
     // pass 2: M2 = sum [ M2_t + n_t (s_t/n_t - mean)^2 ]   (Chan's merge with the final mean)
     __shared__ double sn[BN_FIN_THREADS], sm[BN_FIN_THREADS], s2[BN_FIN_THREADS];
@@ -77,6 +82,7 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
     }
+    }  // groups
 }
 
 __global__ void bn_eval_affine_kernel(float *scale, float *shift, const float *gamma,
@@ -96,6 +102,11 @@ bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
                 const float4 *__restrict__ res, int relu, long long total4) {
     constexpr int C4 = C / 4;
     __shared__ float4 ssc[C4], ssh[C4];
+    {   // blockIdx.y = statistic group: its own slice of the tensors and its own (scale, shift)
+        const long long go = (long long)blockIdx.y * total4;
+        y += go; x += go; if (res) res += go;
+        scale += blockIdx.y * C; shift += blockIdx.y * C;
+    }
     if (threadIdx.x < C4) {
         ssc[threadIdx.x] = reinterpret_cast<const float4 *>(scale)[threadIdx.x];
         ssh[threadIdx.x] = reinterpret_cast<const float4 *>(shift)[threadIdx.x];
@@ -127,6 +138,12 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
                      long long nvox) {
     // thread t owns channel quad (t % C4) and voxel lane (t / C4); C4 divides 256
     constexpr int C4 = C / 4, VPB = 256 / C4;
+    {   // blockIdx.y = statistic group
+        const long long go = (long long)blockIdx.y * nvox * C;
+        dy += go; x += go; if (relu) y += go;
+        mean += blockIdx.y * C; invstd += blockIdx.y * C;
+        partial += (size_t)blockIdx.y * gridDim.x * C * 2;
+    }
     const int c4 = threadIdx.x % C4, vl = threadIdx.x / C4;
     const float4 mu = reinterpret_cast<const float4 *>(mean)[c4];
     const float4 is = reinterpret_cast<const float4 *>(invstd)[c4];
@@ -163,30 +180,38 @@ __global__ void __launch_bounds__(256)
 bn_bwd_finalize_kernel(float *__restrict__ dgamma, float *__restrict__ dbeta,
                        float *__restrict__ coef, const float *__restrict__ partial,
                        const float *__restrict__ gamma, const float *__restrict__ invstd,
-                       int nblocks, int C, double nvox) {
+                       int nblocks, int C, double nvox, int groups) {
     const int c = blockIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int t = threadIdx.x; t < nblocks; t += 256) {
-        a += partial[((size_t)t * C + c) * 2 + 0];
-        b += partial[((size_t)t * C + c) * 2 + 1];
-    }
     __shared__ double sa[256], sb[256];
-    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            sa[threadIdx.x] += sa[threadIdx.x + o];
-            sb[threadIdx.x] += sb[threadIdx.x + o];
+    double dg_tot = 0.0, db_tot = 0.0;  // parameter gradients: summed over the statistic groups
+    for (int grp = 0; grp < groups; ++grp, partial += (size_t)nblocks * C * 2, invstd += C, coef += C * 3) {
+        double a = 0.0, b = 0.0;
+        for (int t = threadIdx.x; t < nblocks; t += 256) {
+            a += partial[((size_t)t * C + c) * 2 + 0];
+            b += partial[((size_t)t * C + c) * 2 + 1];
         }
         __syncthreads();
+        sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                sa[threadIdx.x] += sa[threadIdx.x + o];
+                sb[threadIdx.x] += sb[threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            db_tot += sa[0];
+            dg_tot += sb[0];
+            // dx = k0 * (dz - k1 - xhat * k2)
+            coef[c * 3 + 0] = gamma[c] * invstd[c];
+            coef[c * 3 + 1] = (float)(sa[0] / nvox);
+            coef[c * 3 + 2] = (float)(sb[0] / nvox);
+        }
     }
     if (threadIdx.x == 0) {
-        dbeta[c] = (float)sa[0];
-        dgamma[c] = (float)sb[0];
-        // dx = k0 * (dz - k1 - xhat * k2)
-        coef[c * 3 + 0] = gamma[c] * invstd[c];
-        coef[c * 3 + 1] = (float)(sa[0] / nvox);
-        coef[c * 3 + 2] = (float)(sb[0] / nvox);
+        dbeta[c] = (float)db_tot;
+        dgamma[c] = (float)dg_tot;
     }
 }
 
@@ -199,6 +224,11 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
                     long long total4) {
     constexpr int C4 = C / 4;
     __shared__ float smu[C], sis[C], k0[C], k1[C], k2[C];
+    {   // blockIdx.y = statistic group
+        const long long go = (long long)blockIdx.y * total4;
+        dx += go; dy += go; x += go; if (relu) y += go; if (dz_out) dz_out += go;
+        mean += blockIdx.y * C; invstd += blockIdx.y * C; coef += blockIdx.y * C * 3;
+    }
     if (threadIdx.x < C) {
         smu[threadIdx.x] = mean[threadIdx.x];
         sis[threadIdx.x] = invstd[threadIdx.x];
@@ -252,6 +282,9 @@ bn_stats_kernel(float *__restrict__ part, float *__restrict__ cnt, const float *
                 long long nvox, long long ntiles) {
     constexpr int C4 = C / 4, VPB = 256 / C4;
     const int c4 = threadIdx.x % C4, vl = threadIdx.x / C4;
+    x += (size_t)blockIdx.y * nvox * C;  // blockIdx.y = statistic group
+    part += (size_t)blockIdx.y * C * ntiles * 2;
+    cnt += (size_t)blockIdx.y * ntiles;
     const long long v0 = (long long)blockIdx.x * VPB;  // first voxel of this block: always < nvox
     const float4 K = reinterpret_cast<const float4 *>(x)[(size_t)v0 * C4 + c4];
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
@@ -301,7 +334,7 @@ extern "C" int az_bn3d_finalize(float *mean, float *invstd, float *scale, float 
     if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_FIN_THREADS), 0, az_stream(stream), mean, invstd,
                        scale, shift, running_mean, running_var, partials, counts, gamma, beta,
-                       ntiles, C, eps, momentum);
+                       ntiles, C, eps, momentum, 1);
     return az_launch_status();
 }
 
@@ -370,7 +403,7 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
                            x, mean, invstd, relu, nvox);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef,
-                       workspace, gamma, invstd, blocks, C, (double)nvox);
+                       workspace, gamma, invstd, blocks, C, (double)nvox, 1);
     if (C == 32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<32>, dim3(BN_GRID(total4)), dim3(256), 0, s,
                            (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
@@ -417,5 +450,92 @@ extern "C" int az_bn3d_stats(float *partials, float *counts, const float *x, lon
         hipLaunchKernelGGL(bn_stats_kernel<64>, dim3((unsigned)tiles), dim3(256), 0, s, partials, counts, x, nvox, tiles);
     else
         hipLaunchKernelGGL(bn_stats_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, s, partials, counts, x, nvox, tiles);
+    return az_launch_status();
+}
+
+// ---- grouped BatchNorm of a channels-last tensor [groups][nvox][C] (the extractor's layers) ------
+// One call = statistics + finalize + apply (forward) or reduce + finalize + apply (backward) for ALL
+// statistic groups: three launches per layer instead of six per group.
+static int bn2d_blocks(long long nvox, int C) {
+    const int vpb = 256 / (C / 4);
+    return (int)az_grid_for((nvox + vpb - 1) / vpb * 256, 256);
+}
+
+// floats of scratch: forward {partials G*C*T*2, counts G*T}, backward {partials G*blocks*C*2, coef G*C*3}
+extern "C" long long az_bn2d_workspace(int groups, long long nvox, int C) {
+    const long long tiles = az_bn3d_stats_tiles(nvox, C);
+    if (tiles < 0 || groups <= 0) return AZ_EINVAL;
+    const long long fwd = (long long)groups * (C * tiles * 2 + tiles);
+    const long long bwd = (long long)groups * ((long long)bn2d_blocks(nvox, C) * C * 2 + C * 3);
+    return (fwd > bwd ? fwd : bwd) * (long long)sizeof(float);
+}
+
+template <int C>
+static void bn2d_fwd_launch(float *y, float *mean, float *invstd, float *scale, float *shift, float *rm,
+                            float *rv, const float *x, const float *res, const float *gamma,
+                            const float *beta, float *ws, int relu, int groups, long long nvox, float eps,
+                            float momentum, hipStream_t s) {
+    const long long tiles = az_bn3d_stats_tiles(nvox, C);
+    float *part = ws, *cnt = ws + (size_t)groups * C * tiles * 2;
+    hipLaunchKernelGGL(bn_stats_kernel<C>, dim3((unsigned)tiles, groups), dim3(256), 0, s, part, cnt, x, nvox, tiles);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_FIN_THREADS), 0, s, mean, invstd, scale, shift, rm, rv,
+                       part, cnt, gamma, beta, tiles, C, eps, momentum, groups);
+    const long long total4 = nvox * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel<C>, dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)y,
+                       (const float4 *)x, scale, shift, (const float4 *)res, relu, total4);
+}
+
+/* y = relu?(bn(x) + residual) with batch statistics per group; mean/invstd/scale/shift: [groups][C] outputs */
+extern "C" int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, float *shift,
+                           float *running_mean, float *running_var, const float *x, const float *residual,
+                           const float *gamma, const float *beta, float *workspace, long long workspace_bytes,
+                           int relu, int groups, long long nvox, int C, float eps, float momentum,
+                           void *stream) {
+    AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
+    AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta); AZ_REQUIRE_PTR(workspace);
+    if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
+    const long long need = az_bn2d_workspace(groups, nvox, C);
+    if (need < 0) return (int)need;
+    if (workspace_bytes < need) return AZ_EWORKSPACE;
+    if (groups > 65535) return AZ_EUNSUPPORTED;
+    hipStream_t s = az_stream(stream);
+    if (C == 32) bn2d_fwd_launch<32>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, s);
+    else if (C == 64) bn2d_fwd_launch<64>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, s);
+    else bn2d_fwd_launch<128>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, s);
+    return az_launch_status();
+}
+
+template <int C>
+static void bn2d_bwd_launch(float *dx, float *dz, float *dgamma, float *dbeta, float *ws, const float *dy,
+                            const float *y, const float *x, const float *mean, const float *invstd,
+                            const float *gamma, int relu, int groups, long long nvox, hipStream_t s) {
+    const int blocks = bn2d_blocks(nvox, C);
+    float *partial = ws, *coef = ws + (size_t)groups * blocks * C * 2;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<C>, dim3(blocks, groups), dim3(256), 0, s, partial, dy, y, x, mean,
+                       invstd, relu, nvox);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef, partial, gamma,
+                       invstd, blocks, C, (double)nvox, groups);
+    const long long total4 = nvox * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<C>, dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)dx,
+                       (float4 *)dz, (const float4 *)dy, (const float4 *)y, (const float4 *)x, mean, invstd,
+                       coef, relu, total4);
+}
+
+/* backward of az_bn2d_fwd; dgamma/dbeta [C] are summed over the groups; dz_out may be NULL */
+extern "C" int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *workspace,
+                           long long workspace_bytes, const float *dy, const float *y, const float *x,
+                           const float *mean, const float *invstd, const float *gamma, int relu, int groups,
+                           long long nvox, int C, void *stream) {
+    AZ_REQUIRE_PTR(dx); AZ_REQUIRE_PTR(dgamma); AZ_REQUIRE_PTR(dbeta); AZ_REQUIRE_PTR(workspace);
+    AZ_REQUIRE_PTR(dy); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(gamma);
+    if (relu) AZ_REQUIRE_PTR(y);
+    const long long need = az_bn2d_workspace(groups, nvox, C);
+    if (need < 0) return (int)need;
+    if (workspace_bytes < need) return AZ_EWORKSPACE;
+    if (groups > 65535) return AZ_EUNSUPPORTED;
+    hipStream_t s = az_stream(stream);
+    if (C == 32) bn2d_bwd_launch<32>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, relu, groups, nvox, s);
+    else if (C == 64) bn2d_bwd_launch<64>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, relu, groups, nvox, s);
+    else bn2d_bwd_launch<128>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, relu, groups, nvox, s);
     return az_launch_status();
 }

@@ -186,6 +186,21 @@ int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
  * partials [C][tiles][2], counts [tiles] with tiles = az_bn3d_stats_tiles(nvox, C), for az_bn3d_finalize */
 long long az_bn3d_stats_tiles(long long nvox, int C);
 int az_bn3d_stats(float *partials, float *counts, const float *x, long long nvox, int C, void *stream);
+/* The same for ALL statistic groups of a tensor [groups][nvox][C] in three launches: y = relu?(bn(x) +
+ * residual) with batch statistics per group (groups = 2: the left and the right image set of
+ * psmnet_3.py:145-146 stacked in one batch; running statistics are updated group after group).
+ * mean/invstd/scale/shift are [groups][C] outputs; workspace of az_bn2d_workspace() bytes. */
+long long az_bn2d_workspace(int groups, long long nvox, int C);
+int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, float *shift, float *running_mean,
+                float *running_var, const float *x, const float *residual, const float *gamma,
+                const float *beta, float *workspace, long long workspace_bytes, int relu, int groups,
+                long long nvox, int C, float eps, float momentum, void *stream);
+/* backward: dx [groups][nvox][C]; dgamma/dbeta [C] summed over the groups; dz_out (may be NULL) = the
+ * gradient of the residual branch when relu != 0 */
+int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *workspace,
+                long long workspace_bytes, const float *dy, const float *y, const float *x,
+                const float *mean, const float *invstd, const float *gamma, int relu, int groups,
+                long long nvox, int C, void *stream);
 int az_bn3d_eval_affine(float *scale, float *shift, const float *gamma, const float *beta,
                         const float *running_mean, const float *running_var, float eps, int C,
                         void *stream);
