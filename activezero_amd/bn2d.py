@@ -61,7 +61,8 @@ class _BNAct(torch.autograd.Function):
                   float(bn.momentum) if bn.momentum is not None else 0.1, _stream())
             if track and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(groups)
-        ctx.save_for_backward(xr, yr if relu else None, gamma, stats)
+        # a ReLU layer without residual recomputes its mask from x in backward: y need not be kept
+        ctx.save_for_backward(xr, yr if (relu and residual is not None) else None, gamma, stats)
         ctx.cfg = (True, relu, residual is not None, groups, (n, c, h, w))
         return yr.permute(0, 3, 1, 2)  # [N,C,H,W] view in channels_last memory
 
@@ -81,9 +82,11 @@ class _BNAct(torch.autograd.Function):
         with torch.cuda.device(gr.device):
             ws_bytes = lib.az_bn2d_workspace(groups, nvox, c)
             ws = gr.new_empty(ws_bytes // 4)
+            remask = relu and not has_res
             _call("az_bn2d_bwd", _p(dxr), _p(dzr), _p(dgb[0]), _p(dgb[1]), _p(ws), ws_bytes, _p(gr),
-                  _p(yr) if relu else None, _p(xr), _p(stats[0]), _p(stats[1]), _p(gamma.detach()), int(relu),
-                  groups, nvox, c, _stream())
+                  _p(yr) if (relu and has_res) else None, _p(xr), _p(stats[0]), _p(stats[1]), _p(gamma.detach()),
+                  _p(stats[2]) if remask else None, _p(stats[3]) if remask else None, int(relu), groups, nvox, c,
+                  _stream())
         g_res = None
         if has_res:
             g_res = (dzr if relu else gr).permute(0, 3, 1, 2)

@@ -179,13 +179,16 @@ class _ConvBN(torch.autograd.Function):
                                 bound="hbm"):
                 _call("az_bn3d_apply", _p(y), _p(raw), _p(scale), _p(shift), _p(residual), int(relu),
                       nvox, cout, _stream())
-        ctx.save_for_backward(x, weight, gamma, raw, y if relu else None, mean, invstd)
+        # a ReLU layer without residual recomputes its mask from raw in backward (fma(raw, scale, shift) > 0)
+        remask = relu and residual is None
+        ctx.save_for_backward(x, weight, gamma, raw, y if (relu and not remask) else None, mean, invstd,
+                              scale if remask else None, shift if remask else None)
         ctx.cfg = (mode, relu, residual is not None, cin, cout)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, gamma, raw, y, mean, invstd = ctx.saved_tensors
+        x, weight, gamma, raw, y, mean, invstd, scale, shift = ctx.saved_tensors
         mode, relu, has_res, cin, cout = ctx.cfg
         gy = _chk(gy.contiguous(), "grad_y")
         nvox = raw.numel() // cout
@@ -197,10 +200,10 @@ class _ConvBN(torch.autograd.Function):
             coef = gy.new_empty(cout, 3)
             ws_bytes = lib.az_bn3d_bwd_workspace(nvox, cout)
             ws = gy.new_empty(ws_bytes // 4)
-            with profiler.scope(f"bn3d_bwd_{cout}", bytes=4.0 * raw.numel() * (7 if relu else 5), bound="hbm"):
+            with profiler.scope(f"bn3d_bwd_{cout}", bytes=4.0 * raw.numel() * (7 if (relu and y is not None) else 5), bound="hbm"):
                 _call("az_bn3d_bwd", _p(dx_raw), _p(dz), _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes,
-                      _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), int(relu), nvox,
-                      cout, _stream())
+                      _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), _p(scale), _p(shift),
+                      int(relu), nvox, cout, _stream())
             g_res = (dz if relu else gy) if has_res else None
             gx = gw = None
             if ctx.needs_input_grad[0]:

@@ -115,8 +115,10 @@ bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
         const int c4 = (int)(i % C4);
         const float4 v = x[i], sc = ssc[c4], sh = ssh[c4];
-        float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z,
-                               v.w * sc.w + sh.w);
+        // (fmaf spelled out: the backward kernels recompute this value for the ReLU mask and must
+        //  round identically)
+        float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z),
+                               fmaf(v.w, sc.w, sh.w));
         if (res) {
             const float4 r = res[i];
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -128,22 +130,32 @@ bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
     }
 }
 
+__device__ __forceinline__ int c4_of(int tid, int C4) { return tid % C4; }
+
 // ---- backward ---------------------------------------------------------------------------
 // partial[block][C][2]: sum(dz), sum(dz * xhat) over the block's voxels
 template <int C>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
                      const float *__restrict__ y, const float *__restrict__ x,
-                     const float *__restrict__ mean, const float *__restrict__ invstd, int relu,
+                     const float *__restrict__ mean, const float *__restrict__ invstd,
+                     const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                      long long nvox) {
     // thread t owns channel quad (t % C4) and voxel lane (t / C4); C4 divides 256
     constexpr int C4 = C / 4, VPB = 256 / C4;
+    // ReLU mask: from the saved output y, or -- when the forward's (scale, shift) are given and the
+    // layer had no residual -- recomputed from x with the apply kernel's own expression
+    // (x*scale + shift > 0), which saves reading y (one tensor pass here and one in the apply kernel)
+    const bool remask = relu && scale != nullptr;
     {   // blockIdx.y = statistic group
         const long long go = (long long)blockIdx.y * nvox * C;
-        dy += go; x += go; if (relu) y += go;
+        dy += go; x += go; if (relu && !remask) y += go;
         mean += blockIdx.y * C; invstd += blockIdx.y * C;
+        if (remask) { scale += blockIdx.y * C; shift += blockIdx.y * C; }
         partial += (size_t)blockIdx.y * gridDim.x * C * 2;
     }
+    float4 sc = make_float4(0, 0, 0, 0), sh = sc;
+    if (remask) { sc = reinterpret_cast<const float4 *>(scale)[c4_of(threadIdx.x, C4)]; sh = reinterpret_cast<const float4 *>(shift)[c4_of(threadIdx.x, C4)]; }
     const int c4 = threadIdx.x % C4, vl = threadIdx.x / C4;
     const float4 mu = reinterpret_cast<const float4 *>(mean)[c4];
     const float4 is = reinterpret_cast<const float4 *>(invstd)[c4];
@@ -151,12 +163,14 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
     for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
         const size_t i = (size_t)v * C4 + c4;
         float4 g = reinterpret_cast<const float4 *>(dy)[i];
+        const float4 xx = reinterpret_cast<const float4 *>(x)[i];
         if (relu) {
-            const float4 yy = reinterpret_cast<const float4 *>(y)[i];
+            float4 yy;
+            if (remask) yy = make_float4(fmaf(xx.x, sc.x, sh.x), fmaf(xx.y, sc.y, sh.y), fmaf(xx.z, sc.z, sh.z), fmaf(xx.w, sc.w, sh.w));
+            else yy = reinterpret_cast<const float4 *>(y)[i];
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
-        const float4 xx = reinterpret_cast<const float4 *>(x)[i];
         s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
         s2.x += g.x * ((xx.x - mu.x) * is.x); s2.y += g.y * ((xx.y - mu.y) * is.y);
         s2.z += g.z * ((xx.z - mu.z) * is.z); s2.w += g.w * ((xx.w - mu.w) * is.w);
@@ -220,15 +234,19 @@ __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
                     const float4 *__restrict__ dy, const float4 *__restrict__ y,
                     const float4 *__restrict__ x, const float *__restrict__ mean,
-                    const float *__restrict__ invstd, const float *__restrict__ coef, int relu,
+                    const float *__restrict__ invstd, const float *__restrict__ coef,
+                    const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                     long long total4) {
     constexpr int C4 = C / 4;
-    __shared__ float smu[C], sis[C], k0[C], k1[C], k2[C];
+    __shared__ float smu[C], sis[C], k0[C], k1[C], k2[C], ssc[C], ssh[C];
+    const bool remask = relu && scale != nullptr;  // see bn_bwd_reduce_kernel
     {   // blockIdx.y = statistic group
         const long long go = (long long)blockIdx.y * total4;
-        dx += go; dy += go; x += go; if (relu) y += go; if (dz_out) dz_out += go;
+        dx += go; dy += go; x += go; if (relu && !remask) y += go; if (dz_out) dz_out += go;
         mean += blockIdx.y * C; invstd += blockIdx.y * C; coef += blockIdx.y * C * 3;
+        if (remask) { scale += blockIdx.y * C; shift += blockIdx.y * C; }
     }
+    if (remask && threadIdx.x < C) { ssc[threadIdx.x] = scale[threadIdx.x]; ssh[threadIdx.x] = shift[threadIdx.x]; }
     if (threadIdx.x < C) {
         smu[threadIdx.x] = mean[threadIdx.x];
         sis[threadIdx.x] = invstd[threadIdx.x];
@@ -240,13 +258,16 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
         const int c = (int)(i % C4) * 4;
         float4 g = dy[i];
+        const float4 xx = x[i];
         if (relu) {
-            const float4 yy = y[i];
+            float4 yy;
+            if (remask) yy = make_float4(fmaf(xx.x, ssc[c + 0], ssh[c + 0]), fmaf(xx.y, ssc[c + 1], ssh[c + 1]),
+                                         fmaf(xx.z, ssc[c + 2], ssh[c + 2]), fmaf(xx.w, ssc[c + 3], ssh[c + 3]));
+            else yy = y[i];
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
         if (dz_out) dz_out[i] = g;
-        const float4 xx = x[i];
         float4 o;
         o.x = k0[c + 0] * (g.x - k1[c + 0] - (xx.x - smu[c + 0]) * sis[c + 0] * k2[c + 0]);
         o.y = k0[c + 1] * (g.y - k1[c + 1] - (xx.y - smu[c + 1]) * sis[c + 1] * k2[c + 1]);
@@ -380,12 +401,13 @@ extern "C" long long az_bn3d_bwd_workspace(long long nvox, int C) {
 extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
                            float *workspace, long long workspace_bytes, const float *dy,
                            const float *y, const float *x, const float *mean,
-                           const float *invstd, const float *gamma, int relu, long long nvox,
-                           int C, void *stream) {
+                           const float *invstd, const float *gamma, const float *scale,
+                           const float *shift, int relu, long long nvox, int C, void *stream) {
     AZ_REQUIRE_PTR(dx); AZ_REQUIRE_PTR(dgamma); AZ_REQUIRE_PTR(dbeta); AZ_REQUIRE_PTR(coef);
     AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(dy); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(mean);
     AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(gamma);
-    if (relu) AZ_REQUIRE_PTR(y);
+    if ((scale == nullptr) != (shift == nullptr)) return AZ_EINVAL;
+    if (relu && !scale) AZ_REQUIRE_PTR(y);
     const long long need = az_bn3d_bwd_workspace(nvox, C);
     if (need < 0) return (int)need;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
@@ -394,28 +416,28 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
     hipStream_t s = az_stream(stream);
     if (C == 32) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
-                           x, mean, invstd, relu, nvox);
+                           x, mean, invstd, scale, shift, relu, nvox);
     } else if (C == 64) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
-                           x, mean, invstd, relu, nvox);
+                           x, mean, invstd, scale, shift, relu, nvox);
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<128>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
-                           x, mean, invstd, relu, nvox);
+                           x, mean, invstd, scale, shift, relu, nvox);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef,
                        workspace, gamma, invstd, blocks, C, (double)nvox, 1);
     if (C == 32)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<32>, dim3(BN_GRID(total4)), dim3(256), 0, s,
                            (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
-                           (const float4 *)x, mean, invstd, coef, relu, total4);
+                           (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
     else if (C == 64)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<64>, dim3(BN_GRID(total4)), dim3(256), 0, s,
                            (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
-                           (const float4 *)x, mean, invstd, coef, relu, total4);
+                           (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<128>, dim3(BN_GRID(total4)), dim3(256), 0, s,
                            (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
-                           (const float4 *)x, mean, invstd, coef, relu, total4);
+                           (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
     return az_launch_status();
 }
 
@@ -508,34 +530,36 @@ extern "C" int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, f
 template <int C>
 static void bn2d_bwd_launch(float *dx, float *dz, float *dgamma, float *dbeta, float *ws, const float *dy,
                             const float *y, const float *x, const float *mean, const float *invstd,
-                            const float *gamma, int relu, int groups, long long nvox, hipStream_t s) {
+                            const float *gamma, const float *scale, const float *shift, int relu, int groups,
+                            long long nvox, hipStream_t s) {
     const int blocks = bn2d_blocks(nvox, C);
     float *partial = ws, *coef = ws + (size_t)groups * blocks * C * 2;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<C>, dim3(blocks, groups), dim3(256), 0, s, partial, dy, y, x, mean,
-                       invstd, relu, nvox);
+                       invstd, scale, shift, relu, nvox);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef, partial, gamma,
                        invstd, blocks, C, (double)nvox, groups);
     const long long total4 = nvox * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel<C>, dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)dx,
                        (float4 *)dz, (const float4 *)dy, (const float4 *)y, (const float4 *)x, mean, invstd,
-                       coef, relu, total4);
+                       coef, scale, shift, relu, total4);
 }
 
 /* backward of az_bn2d_fwd; dgamma/dbeta [C] are summed over the groups; dz_out may be NULL */
 extern "C" int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *workspace,
                            long long workspace_bytes, const float *dy, const float *y, const float *x,
-                           const float *mean, const float *invstd, const float *gamma, int relu, int groups,
-                           long long nvox, int C, void *stream) {
+                           const float *mean, const float *invstd, const float *gamma, const float *scale,
+                           const float *shift, int relu, int groups, long long nvox, int C, void *stream) {
     AZ_REQUIRE_PTR(dx); AZ_REQUIRE_PTR(dgamma); AZ_REQUIRE_PTR(dbeta); AZ_REQUIRE_PTR(workspace);
     AZ_REQUIRE_PTR(dy); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(gamma);
-    if (relu) AZ_REQUIRE_PTR(y);
+    if ((scale == nullptr) != (shift == nullptr)) return AZ_EINVAL;
+    if (relu && !scale) AZ_REQUIRE_PTR(y);
     const long long need = az_bn2d_workspace(groups, nvox, C);
     if (need < 0) return (int)need;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
     if (groups > 65535) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
-    if (C == 32) bn2d_bwd_launch<32>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, relu, groups, nvox, s);
-    else if (C == 64) bn2d_bwd_launch<64>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, relu, groups, nvox, s);
-    else bn2d_bwd_launch<128>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, relu, groups, nvox, s);
+    if (C == 32) bn2d_bwd_launch<32>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s);
+    else if (C == 64) bn2d_bwd_launch<64>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s);
+    else bn2d_bwd_launch<128>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s);
     return az_launch_status();
 }

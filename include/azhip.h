@@ -199,8 +199,8 @@ int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, float *shift
  * gradient of the residual branch when relu != 0 */
 int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *workspace,
                 long long workspace_bytes, const float *dy, const float *y, const float *x,
-                const float *mean, const float *invstd, const float *gamma, int relu, int groups,
-                long long nvox, int C, void *stream);
+                const float *mean, const float *invstd, const float *gamma, const float *scale,
+                const float *shift, int relu, int groups, long long nvox, int C, void *stream);
 int az_bn3d_eval_affine(float *scale, float *shift, const float *gamma, const float *beta,
                         const float *running_mean, const float *running_var, float eps, int C,
                         void *stream);
@@ -209,12 +209,15 @@ int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shi
                   const float *residual, int relu, long long nvox, int C, void *stream);
 /* backward of y = relu?(bn(x) + residual): dz = dy*[y>0] (or dy), dgamma, dbeta,
  * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (may be NULL) = dz =
- * gradient of the residual branch.  coef: [C][3] scratch. */
+ * gradient of the residual branch.  coef: [C][3] scratch.  scale/shift (both or neither): the
+ * forward's affine map; when given for a ReLU layer WITHOUT residual the mask is recomputed as
+ * fma(x, scale, shift) > 0 and y is not read (may be NULL). */
 long long az_bn3d_bwd_workspace(long long nvox, int C);
 int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
                 float *workspace, long long workspace_bytes, const float *dy, const float *y,
                 const float *x, const float *mean, const float *invstd, const float *gamma,
-                int relu, long long nvox, int C, void *stream);
+                const float *scale, const float *shift, int relu, long long nvox, int C,
+                void *stream);
 /* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175 */
 int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, void *stream);
 
