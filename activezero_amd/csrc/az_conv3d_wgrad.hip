@@ -210,6 +210,9 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 #define X6_WCH 16  // coarse positions per chunk = one K16 block
 
+#ifndef WGX6_BPIPE
+#define WGX6_BPIPE 0
+#endif
 #ifndef WGX6_S2_OCC
 #define WGX6_S2_OCC 1
 #endif
@@ -340,6 +343,41 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
             bf16x8 af[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) af[p] = frag(sa + p * WCH * 32, tr_row, tr_row + 4);
+#if WGX6_BPIPE
+            // fine-row fragments one tap ahead of their MFMAs (ping-pong registers, order pinned)
+            auto load_bf = [&](bf16x8 (&bfr)[3], int t) {
+                const unsigned short *frow = sf + ((s0 + t / 3) % 3) * 3 * FW * 32;
+                const int kw = t % 3;
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bfr[p] = frag(frow + p * FW * 32, S * tr_row + kw, S * (tr_row + 4) + kw);
+            };
+            auto tap_mfma = [&](int t, const bf16x8 (&bfr)[3]) {
+                f32x16 c = acc[t];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+                acc[t] = c;
+            };
+            bf16x8 b0[3], b1[3];
+            load_bf(b0, 0);
+#pragma unroll
+            for (int t = 0; t < 9; t += 2) {
+                if (t + 1 < 9) load_bf(b1, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                tap_mfma(t, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < 9) {
+                    if (t + 2 < 9) load_bf(b0, t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap_mfma(t + 1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#else
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const unsigned short *frow = sf + ((s0 + kh) % 3) * 3 * FW * 32;
@@ -359,6 +397,7 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
                     acc[kh * 3 + kw] = c;
                 }
             }
+#endif
         }
     }
 #pragma unroll
