@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""End-to-end training-dynamics check: N Adam steps of the bench workload (small size) on the HIP
+path and on stock PyTorch-ROCm modules (3-D aggregation on MIOpen, extractor as plain modules),
+same seed, same data.  Prints both loss curves; they must track each other (single-step parity is
+what tests/ pin; this looks at the compounded effect of forward + backward + optimizer)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def run(backend, steps, b, h, w, md):
+    from activezero_amd import agg3d
+    from activezero_amd.nets.psmnet import psmnet_submodule_3 as sub
+    from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
+
+    agg3d.set_backend("hip" if backend == "hip" else "miopen")
+    sub.FE2D_BACKEND = "fused" if backend == "hip" else "miopen"
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    model = PSMNet(md).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    il, ir, gt = bench.synth_batch(b, h, w, md, dev, 1234)
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        loss = bench.disp_loss(model(il, ir), gt, md)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return losses
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=25)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--maxdisp", type=int, default=64)
+    a = ap.parse_args()
+    hip = run("hip", a.steps, a.batch, a.height, a.width, a.maxdisp)
+    ref = run("miopen", a.steps, a.batch, a.height, a.width, a.maxdisp)
+    worst = 0.0
+    for i, (x, y) in enumerate(zip(hip, ref)):
+        rel = abs(x - y) / max(abs(y), 1e-12)
+        worst = max(worst, rel)
+        print(f"step {i:3d}  hip {x:.6f}  torch-rocm {y:.6f}  rel diff {rel:.2e}")
+    print(f"worst relative loss difference over {a.steps} steps: {worst:.2e}")
