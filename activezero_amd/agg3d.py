@@ -84,6 +84,13 @@ def add(a, b):
     return conv3d.add(a, b)
 
 
+def fanout(x, n):
+    """n handles on x for n consumers; on the HIP backend their gradients are summed in one pass."""
+    if BACKEND == "miopen":
+        return (x,) * n
+    return conv3d.fanout(x, n)
+
+
 # ------------------------------------------------------------------ miopen backend
 def _bn(x, bn):
     training = bn.training or not bn.track_running_stats

@@ -342,6 +342,19 @@ bn_stats_kernel(float *__restrict__ part, float *__restrict__ cnt, const float *
     }
 }
 
+// y = a + b (+ c) (+ d): gradients of a tensor with several consumers, summed in ONE pass
+__global__ void __launch_bounds__(256)
+sum4_kernel(float4 *__restrict__ y, const float4 *__restrict__ a, const float4 *__restrict__ b,
+            const float4 *__restrict__ c, const float4 *__restrict__ d, long long total4) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
+        const float4 p = a[i], q = b[i];
+        float4 o = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+        if (c) { const float4 r = c[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        if (d) { const float4 r = d[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        y[i] = o;
+    }
+}
+
 #define BN_GRID(total) az_grid_for((total), 256)
 
 extern "C" int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
@@ -447,6 +460,16 @@ extern "C" int az_add_relu(float *y, const float *a, const float *b, int relu, l
     AZ_REQUIRE(n > 0 && n % 4 == 0);
     hipLaunchKernelGGL(add_relu_kernel, dim3(BN_GRID(n / 4)), dim3(256), 0, az_stream(stream),
                        (float4 *)y, (const float4 *)a, (const float4 *)b, relu, n / 4);
+    return az_launch_status();
+}
+
+extern "C" int az_sum4(float *y, const float *a, const float *b, const float *c, const float *d, long long n,
+                       void *stream) {
+    AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(a); AZ_REQUIRE_PTR(b);
+    if (d && !c) return AZ_EINVAL;
+    AZ_REQUIRE(n > 0 && n % 4 == 0);
+    hipLaunchKernelGGL(sum4_kernel, dim3(BN_GRID(n / 4)), dim3(256), 0, az_stream(stream), (float4 *)y,
+                       (const float4 *)a, (const float4 *)b, (const float4 *)c, (const float4 *)d, n / 4);
     return az_launch_status();
 }
 

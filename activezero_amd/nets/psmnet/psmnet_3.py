@@ -103,9 +103,11 @@ class PSMNet(nn.Module):
         t = agg3d.conv_bn(c0, self.dres1[0], relu=True)
         c0 = agg3d.conv_bn(t, self.dres1[2], add=c0)
 
-        out1, pre1, post1 = self.dres2(c0, None, None, out_add=c0)   # out_k + cost0 fused
-        out2, _pre2, post2 = self.dres3(out1, pre1, post1, out_add=c0)
-        out3, _pre3, _post3 = self.dres4(out2, pre1, post2, out_add=c0)
+        # cost0 has four consumers (first hourglass + three residual sums): one fused gradient sum
+        c0a, c0b, c0c, c0d = agg3d.fanout(c0, 4)
+        out1, pre1, post1 = self.dres2(c0a, None, None, out_add=c0b)   # out_k + cost0 fused
+        out2, _pre2, post2 = self.dres3(out1, pre1, post1, out_add=c0c)
+        out3, _pre3, _post3 = self.dres4(out2, pre1, post2, out_add=c0d)
 
         def head(cls, v, running):
             return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True), cls[2], running)

@@ -220,6 +220,11 @@ int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *co
                 void *stream);
 /* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175 */
 int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, void *stream);
+/* y = a + b (+ c) (+ d), n floats (n % 4 == 0; c, d may be NULL): the gradient of a tensor with up to
+ * four consumers (cost0 of psmnet_3.py:165-175 feeds the first hourglass and three residual sums)
+ * in one pass instead of autograd's chain of pairwise adds */
+int az_sum4(float *y, const float *a, const float *b, const float *c, const float *d, long long n,
+            void *stream);
 
 /* ---- K10/K11: RAFT-Stereo 1-D correlation (secondary path) -----------------------
  * replaces nets/raft/corr.py:115-161 (CorrBlock1D: einsum all-pairs correlation /
