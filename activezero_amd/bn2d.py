@@ -42,9 +42,8 @@ class _BNAct(torch.autograd.Function):
         lib = _lib.lib()
         with torch.cuda.device(x.device):
             if not training:  # running statistics: one affine map for the whole batch
-                scale, shift = xr.new_empty(c), xr.new_empty(c)
-                _call("az_bn3d_eval_affine", _p(scale), _p(shift), _p(g_), _p(b_), _p(bn.running_mean),
-                      _p(bn.running_var), eps, c, _stream())
+                from .conv3d import eval_affine
+                scale, shift = eval_affine(bn, xr)
                 _call("az_bn3d_apply", _p(yr), _p(xr), _p(scale), _p(shift), _p(rr), int(relu), nvox * groups, c,
                       _stream())
                 ctx.cfg = (False, relu, residual is not None, groups, (n, c, h, w))

@@ -52,13 +52,54 @@ def _out_dims(mode, d, h, w):
     return 2 * d, 2 * h, 2 * w
 
 
+# Inference-time caches (used only while autograd is off): packed weights and folded BatchNorm
+# affine maps are functions of parameters that do not change between forward passes.  Entries
+# are keyed on the tensors' storage address AND version counter, so an optimizer step or a
+# load_state_dict (both write in place) invalidates them; each entry also holds its source tensors,
+# so their addresses cannot be recycled for other data while the entry lives.
+_PACK_CACHE, _AFFINE_CACHE = {}, {}
+
+
+def _cache_key(*tensors):
+    return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors)
+
+
 def _pack(weight, op_cin, op_cout, stride_out, stride_in, flip):
     w = _chk(weight.detach().contiguous(), "weight")
+    key = None
+    if not torch.is_grad_enabled():
+        key = (_cache_key(weight), op_cin, op_cout, stride_out, stride_in, bool(flip), PRECISION)
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit[0]
     n = _lib.lib().az_conv3d_packed_floats(op_cin, op_cout, PRECISION)
     packed = torch.empty(n, dtype=torch.float32, device=w.device)
     _call("az_conv3d_pack_weights", _p(packed), _p(w), op_cin, op_cout, stride_out, stride_in,
           int(flip), PRECISION, _stream())
+    if key is not None:
+        if len(_PACK_CACHE) > 256:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (packed, weight)
     return packed
+
+
+def eval_affine(bn, like):
+    """(scale, shift) of an eval-mode BatchNorm: gamma/sqrt(running_var+eps), beta - running_mean*scale."""
+    c = bn.num_features
+    key = None
+    if not torch.is_grad_enabled():
+        key = (_cache_key(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps))
+        hit = _AFFINE_CACHE.get(key)
+        if hit is not None:
+            return hit[0], hit[1]
+    scale, shift = like.new_empty(c), like.new_empty(c)
+    _call("az_bn3d_eval_affine", _p(scale), _p(shift), _p(bn.weight.detach()), _p(bn.bias.detach()),
+          _p(bn.running_mean), _p(bn.running_var), float(bn.eps), c, _stream())
+    if key is not None:
+        if len(_AFFINE_CACHE) > 512:
+            _AFFINE_CACHE.clear()
+        _AFFINE_CACHE[key] = (scale, shift, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    return scale, shift
 
 
 def _pack_forward(weight, mode):
@@ -154,16 +195,15 @@ class _ConvBN(torch.autograd.Function):
         eps = float(bn.eps)
         with torch.cuda.device(x.device):
             packed, cin, cout = _pack_forward(weight, mode)
-            scale, shift = x.new_empty(cout), x.new_empty(cout)
             if not training:
-                _call("az_bn3d_eval_affine", _p(scale), _p(shift), _p(gamma.detach()), _p(beta.detach()),
-                      _p(bn.running_mean), _p(bn.running_var), eps, cout, _stream())
+                scale, shift = eval_affine(bn, x)
                 if want_grad and any(ctx.needs_input_grad):
                     raise NotImplementedError(
                         "eval-mode BatchNorm backward is not implemented on the HIP path; "
                         "run validation under torch.no_grad() as the reference does")
                 return _run_gather(x, packed, mode, cin, cout, scale, shift, residual, relu)
             raw, part, cnt, ntiles = _run_gather(x, packed, mode, cin, cout, stats=True)
+            scale, shift = x.new_empty(cout), x.new_empty(cout)
             mean, invstd = x.new_empty(cout), x.new_empty(cout)
             track = bn.track_running_stats and bn.running_mean is not None
             momentum = 0.1 if bn.momentum is None else float(bn.momentum)
@@ -230,9 +270,7 @@ def conv_bn(x, conv, bn, mode, relu=False, residual=None):
             raise RuntimeError("LazyCostVolume is an inference-only operand")
         with torch.cuda.device(x.fl.device):
             packed, cin, cout = _pack_forward(conv.weight, mode)
-            scale, shift = x.fl.new_empty(cout), x.fl.new_empty(cout)
-            _call("az_bn3d_eval_affine", _p(scale), _p(shift), _p(bn.weight.detach()), _p(bn.bias.detach()),
-                  _p(bn.running_mean), _p(bn.running_var), float(bn.eps), cout, _stream())
+            scale, shift = eval_affine(bn, x.fl)
             return _run_gather(x, packed, mode, cin, cout, scale, shift, residual, relu)
     return _ConvBN.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, mode, relu,
                          torch.is_grad_enabled())
