@@ -64,10 +64,16 @@ def _cache_key(*tensors):
     return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors)
 
 
+def _inference_mode():
+    """autograd off AND not inside a backward pass (autograd also switches grad mode off while it runs
+    Function.backward; caching there would only churn: the weights change every step)."""
+    return not torch.is_grad_enabled() and torch._C._current_graph_task_id() == -1
+
+
 def _pack(weight, op_cin, op_cout, stride_out, stride_in, flip):
     w = _chk(weight.detach().contiguous(), "weight")
     key = None
-    if not torch.is_grad_enabled():
+    if _inference_mode():
         key = (_cache_key(weight), op_cin, op_cout, stride_out, stride_in, bool(flip), PRECISION)
         hit = _PACK_CACHE.get(key)
         if hit is not None:
@@ -87,7 +93,7 @@ def eval_affine(bn, like):
     """(scale, shift) of an eval-mode BatchNorm: gamma/sqrt(running_var+eps), beta - running_mean*scale."""
     c = bn.num_features
     key = None
-    if not torch.is_grad_enabled():
+    if _inference_mode():
         key = (_cache_key(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps))
         hit = _AFFINE_CACHE.get(key)
         if hit is not None:
