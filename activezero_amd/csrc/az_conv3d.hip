@@ -42,6 +42,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // stride-2 map the kernel takes the 1-wave/SIMD budget (512 registers) and prefetches the
 // weights one tap ahead; otherwise 2 waves/SIMD without weight prefetch.
 #define X6_WIDE(COUT, MODE, PREC) ((PREC) == 1 && (((COUT) == 64 && (MODE) != 2) || (MODE) == 1))
+// Experiment (-DT2Q_ENABLE=1, off): transposed conv, bf16x6, 32 output channels -- one wave owns the FOUR
+// (ph, pw) output-parity phases of its coarse patch for a given pd.  The phases read the same coarse
+// slab; with a wave per phase it is staged four times and the lightest phase runs 24 MFMAs per staged
+// slab.  Each of the nine (kh, kw) taps belongs to exactly one phase, so the stage loop is the plain
+// nine-tap loop with the accumulator chosen by the tap.  It needs 4 x MR accumulator tiles, i.e. the
+// 1-wave/SIMD register budget, and that costs what the sharing saves: 64->32 V1->V0 0.89 vs 1.00 ms
+// standalone, but 1.14 vs 1.08 ms as input gradient inside the step (156.5 vs 156.8 ms/step) and the
+// eval forward (affine + residual epilogue, nothing to overlap it with) 13.9 vs 13.3 ms.
+#ifndef T2Q_ENABLE
+#define T2Q_ENABLE 0
+#endif
+#define X6_T2Q(COUT, MODE, PREC) (T2Q_ENABLE && (PREC) == 1 && (MODE) == 2 && (COUT) == 32)
 // (Tried and dropped: a 3-deep register ring streaming the weights two taps ahead under the
 //  1-wave/SIMD budget for every shape -- 2.76 ms vs 2.2 ms on 32->32: one wave per SIMD cannot
 //  hide its own commit / epilogue phases, and the fully unrolled ring spills into AGPRs.)
@@ -66,7 +78,7 @@ __device__ unsigned long long cv_stamp_sum[8];
 #include "az_conv3d_args.h"
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
-__global__ void __launch_bounds__(64, X6_WIDE(COUT, MODE, PREC) ? 1 : 2)
+__global__ void __launch_bounds__(64, (X6_WIDE(COUT, MODE, PREC) || X6_T2Q(COUT, MODE, PREC)) ? 1 : 2)
 conv3d_gather_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32, NR = COUT / 32;
     constexpr int MR = (MODE == 1) ? 1 : 2;
@@ -105,8 +117,12 @@ conv3d_gather_kernel(const ConvArgs a) {
         const int nblk = gridDim.x, xcd = blockIdx.x & 7, q8 = nblk >> 3, r8 = nblk & 7;
         lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     }
+    constexpr bool T2Q = X6_T2Q(COUT, MODE, PREC);
+    constexpr int NPH = T2Q ? 4 : 1;  // output-parity phases owned by this wave
     int pd = 0, ph = 0, pw = 0;
-    if (MODE == 2) {
+    if (T2Q) {
+        pd = lin & 1; lin >>= 1;       // (ph, pw) are enumerated inside
+    } else if (MODE == 2) {
         const int phase = lin & 7; lin >>= 3;
         pd = phase >> 2; ph = (phase >> 1) & 1; pw = phase & 1;
     }
@@ -136,17 +152,17 @@ conv3d_gather_kernel(const ConvArgs a) {
     const int ih0 = (MODE == 0) ? ty0 - 1 : (MODE == 1) ? 2 * ty0 - 1 : ty0;
     const int iw0 = (MODE == 0) ? tx0 - 1 : (MODE == 1) ? 2 * tx0 - 1 : tx0;
 
-    f32x16 acc[MR][NR];
+    f32x16 acc[NPH * MR][NR];  // T2Q: tiles of phase q = ph*2+pw at [q*MR, q*MR+MR)
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+    for (int m = 0; m < NPH * MR; ++m)
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
     const int nd = (MODE == 2) ? 1 + pd : 3;
-    const int nh = (MODE == 2) ? 1 + ph : 3;
-    const int nw = (MODE == 2) ? 1 + pw : 3;
+    const int nh = (MODE == 2 && !T2Q) ? 1 + ph : 3;
+    const int nw = (MODE == 2 && !T2Q) ? 1 + pw : 3;
     const int row = lane & 31, half = lane >> 5;
     const int rty = row >> 3, rtx = row & 7;
     const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
@@ -161,7 +177,7 @@ conv3d_gather_kernel(const ConvArgs a) {
 #define X6_BPIPE_NR1 0
 #endif
     constexpr bool ASINGLE = X6_BPIPE_NR1 && PREC == 1 && NR == 1 && MR == 2 && !X6_WIDE(COUT, MODE, PREC);
-    constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : (X6_WIDE(COUT, MODE, PREC) || ASINGLE);
+    constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : (X6_WIDE(COUT, MODE, PREC) || ASINGLE || T2Q);
     // stages cover only the input planes that exist (a contiguous sd range): a zero-padding plane
     // contributes nothing, so neither its slab nor its split / LDS traffic is spent -- matters at the
     // depth borders and, above all, for depth-1 volumes (the extractor's 2-D layers: 1 plane of 3)
@@ -249,6 +265,11 @@ conv3d_gather_kernel(const ConvArgs a) {
     const int ntaps = nh * nw;
     auto tap_of = [&](int kd, int t, int &eh, int &ew) -> int {
         const int sh = t / nw, sw = t - sh * nw;
+        if (T2Q) {  // tap (kh, kw) = (sh, sw): k = 1 -> parity 0, source offset 0; k = 2 -> parity 1, offset 0; k = 0 -> parity 1, offset 1
+            eh = (sh == 0) ? 1 : 0;
+            ew = (sw == 0) ? 1 : 0;
+            return (kd * 3 + sh) * 3 + sw;
+        }
         const int kh = (MODE == 2) ? (ph ? 2 - 2 * sh : 1) : sh;
         const int kw = (MODE == 2) ? (pw ? 2 - 2 * sw : 1) : sw;
         eh = (MODE == 2) ? (ph ? sh : 0) : sh;
@@ -329,17 +350,19 @@ conv3d_gather_kernel(const ConvArgs a) {
         auto tap_body = [&](int t, float4 (&cur)[NR][NF], float4 (&nxt)[NR][NF]) {
             int eh_, ew_, eh2 = 0, ew2 = 0;
             const int tap = tap_of(kd, t, eh_, ew_);
+            // T2Q: the tap's phase selects the accumulator tiles (t is a compile-time constant there)
+            const int qb = T2Q ? ((((t / 3) != 1) ? 2 : 0) + (((t % 3) != 1) ? 1 : 0)) * MR : 0;
             if (ASINGLE) {
                 // weights double-buffered, A fragments single-buffered: the exposed LDS latency
                 // (twice per tap) is covered by the SIMD's other wave, the L2 latency of the
                 // weights (several times longer) by this wave's own MFMAs
                 if (t + 1 < ntaps) load_b(nxt, tap_of(kd, t + 1, eh2, ew2), cc);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma16(acc[0], a0, cur);
+                mfma16(acc[qb], a0, cur);
                 __builtin_amdgcn_sched_barrier(0);
                 load_a(a0, 1, eh_, ew_);
                 __builtin_amdgcn_sched_barrier(0);
-                mfma16(acc[MR - 1], a0, cur);
+                mfma16(acc[qb + MR - 1], a0, cur);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < ntaps) load_a(a0, 0, eh2, ew2);
                 __builtin_amdgcn_sched_barrier(0);
@@ -354,14 +377,21 @@ conv3d_gather_kernel(const ConvArgs a) {
             // hipcc otherwise sinks the LDS reads next to their consumers (register pressure)
             // and every MFMA quad then waits on a just-issued ds_read: pin the written order
             __builtin_amdgcn_sched_barrier(0);
-            mfma16(acc[0], a0, cur);
+            mfma16(acc[qb], a0, cur);
             __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < ntaps) load_a(a0, 0, eh2, ew2);
             __builtin_amdgcn_sched_barrier(0);
-            if (MR == 2) mfma16(acc[MR - 1], a1, cur);
+            if (MR == 2) mfma16(acc[qb + MR - 1], a1, cur);
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (BPIPE) {
+        if (T2Q) {  // nine taps, fully unrolled: the accumulator index must be static
+            float4 bq2[NR][NF];
+#pragma unroll
+            for (int t = 0; t < 9; t += 2) {
+                tap_body(t, bq, bq2);
+                if (t + 1 < 9) tap_body(t + 1, bq2, bq);
+            }
+        } else if (BPIPE) {
             float4 bq2[NR][NF];
             for (int t = 0; t < ntaps; t += 2) {
                 tap_body(t, bq, bq2);
@@ -383,8 +413,12 @@ conv3d_gather_kernel(const ConvArgs a) {
     const size_t plane_el = (((size_t)b * a.Do + od) * a.Ho) * a.Wo * COUT;
     float *outp = a.out + plane_el;
     const float *resp = a.res ? a.res + plane_el : nullptr;
+#pragma unroll
+    for (int q = 0; q < NPH; ++q) {
     const int ohs = (MODE == 2) ? 2 : 1;  // output step per index-space step
-    const int oh_base = (MODE == 2) ? 2 * ty0 + ph : ty0, ow_base = (MODE == 2) ? 2 * tx0 + pw : tx0;
+    const int phq = T2Q ? (q >> 1) : ph, pwq = T2Q ? (q & 1) : pw;  // this pass's output-parity phase
+    const int tile_q = tile_id + (T2Q ? q : 0), qb = q * MR;
+    const int oh_base = (MODE == 2) ? 2 * ty0 + phq : ty0, ow_base = (MODE == 2) ? 2 * tx0 + pwq : tx0;
     const bool full = (oh_base + ohs * (TY - 1) < a.Ho) && (ow_base + ohs * (TX - 1) < a.Wo);
     // offset (in floats) of accumulator register r of M-tile m, and its validity
     auto voxel = [&](int m, int r, unsigned &off) -> bool {
@@ -408,7 +442,7 @@ conv3d_gather_kernel(const ConvArgs a) {
                 if (!voxel(m, r, off)) continue;
 #pragma unroll
                 for (int n = 0; n < NR; ++n) {
-                    float y = acc[m][n][r] * sc[n] + sf[n];
+                    float y = acc[qb + m][n][r] * sc[n] + sf[n];
                     if (resp) y += resp[off + n * 32];
                     if (a.relu) y = fmaxf(y, 0.f);
                     outp[off + n * 32] = y;
@@ -427,7 +461,7 @@ conv3d_gather_kernel(const ConvArgs a) {
                     okmask |= 1u << (m * 16 + r);
                     nvalid++;
 #pragma unroll
-                    for (int n = 0; n < NR; ++n) outp[off + n * 32] = acc[m][n][r];
+                    for (int n = 0; n < NR; ++n) outp[off + n * 32] = acc[qb + m][n][r];
                 }
             }
         const int ntot = nvalid + __shfl_xor(nvalid, 32);
@@ -438,39 +472,40 @@ conv3d_gather_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+                    for (int r = 0; r < 16; ++r) s += acc[qb + m][n][r];
                 s += __shfl_xor(s, 32);
                 const float mean = s / (float)(MR * 32);
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float dlt = acc[m][n][r] - mean;
+                        const float dlt = acc[qb + m][n][r] - mean;
                         m2 += dlt * dlt;
                     }
             } else {
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s += ((okmask >> (m * 16 + r)) & 1u) ? acc[m][n][r] : 0.f;
+                    for (int r = 0; r < 16; ++r) s += ((okmask >> (m * 16 + r)) & 1u) ? acc[qb + m][n][r] : 0.f;
                 s += __shfl_xor(s, 32);
                 const float mean = s / (float)max(ntot, 1);
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float dlt = acc[m][n][r] - mean;
+                        const float dlt = acc[qb + m][n][r] - mean;
                         m2 += ((okmask >> (m * 16 + r)) & 1u) ? dlt * dlt : 0.f;
                     }
             }
             m2 += __shfl_xor(m2, 32);
             if (half == 0) {
                 const int co = n * 32 + row;
-                *reinterpret_cast<float2 *>(&a.part[((size_t)co * a.ntiles + tile_id) * 2]) = make_float2(s, m2);
+                *reinterpret_cast<float2 *>(&a.part[((size_t)co * a.ntiles + tile_q) * 2]) = make_float2(s, m2);
             }
         }
-        if (lane == 0) a.cnt[tile_id] = (float)ntot;
+        if (lane == 0) a.cnt[tile_q] = (float)ntot;
     }
+    }  // phases
     CV_ACC(4);
     CV_FLUSH();
 }
@@ -522,7 +557,8 @@ conv3d_pack_x6_kernel(unsigned short *__restrict__ dst, const float *__restrict_
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
 static int launch_conv(const ConvArgs &a, hipStream_t s) {
-    long long blocks = (long long)a.B * a.Dt * a.tiles_y * a.tiles_x * (MODE == 2 ? 8 : 1);
+    long long blocks = (long long)a.B * a.Dt * a.tiles_y * a.tiles_x *
+                       (MODE == 2 ? (X6_T2Q(COUT, MODE, PREC) ? 2 : 8) : 1);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     hipLaunchKernelGGL((conv3d_gather_kernel<CIN, COUT, MODE, EPI, SRC, PREC>),
                        dim3((unsigned)blocks), dim3(64), 0, s, a);
