@@ -26,7 +26,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import conv3d, ops, profiler
+from . import bn2d, conv3d, costconv, ops, profiler
 
 BACKEND = os.environ.get("AZ_AGG3D", "hip")
 FUSE_COST_VOLUME = os.environ.get("AZ_FUSE_COSTVOL", "1") != "0"
@@ -57,6 +57,25 @@ def volume_from_features(feat_l, feat_r, ndisp):
         # dres0[0] builds its operand from the two feature maps in-kernel
         return conv3d.LazyCostVolume(fl, fr, ndisp)
     return ops.cost_volume_ndhwc(fl, fr, ndisp)
+
+
+# AZ_COSTCONV=0: materialise the cost volume (training) / synthesise it inside the gather kernel
+# (inference) and run dres0[0] as a 64 -> 32 3-D convolution; default: the factored form (costconv.py)
+FACTORED_COSTCONV = os.environ.get("AZ_COSTCONV", "1") != "0"
+
+
+def use_costconv(feat_l):
+    return BACKEND == "hip" and FACTORED_COSTCONV and feat_l.is_cuda and feat_l.shape[1] == 32
+
+
+def costvol_conv_bn(feat_l, feat_r, ndisp, unit, relu=False):
+    """relu?(BatchNorm3d(Conv3d(64,32,3,pad 1)(concat cost volume))) straight from the two [B,32,h,w]
+    feature maps (psmnet_3.py:149-166): returns the [B,ndisp,h,w,32] activation, no volume in between."""
+    conv, bn = unit[0], unit[1]
+    raw = costconv.costvol_conv(feat_l, feat_r, ndisp, conv.weight)  # [B,D,h,w,32]
+    b, d, h, w, c = raw.shape
+    y = bn2d.bn_act(raw.view(b, d * h, w, c).permute(0, 3, 1, 2), bn, relu=relu)
+    return y.permute(0, 2, 3, 1).reshape(b, d, h, w, c)
 
 
 def conv_bn(vol, unit, relu=False, add=None):

@@ -16,7 +16,7 @@ CHANNELS = (32, 64, 128)
 
 
 def supported(bn, x):
-    return (isinstance(bn, torch.nn.BatchNorm2d) and bn.affine and bn.num_features in CHANNELS and x.is_cuda
+    return (isinstance(bn, torch.nn.modules.batchnorm._BatchNorm) and bn.affine and bn.num_features in CHANNELS and x.is_cuda
             and x.dtype == torch.float32 and (bn.momentum is not None or not bn.track_running_stats))
 
 

@@ -1,0 +1,84 @@
+"""dres0[0] on the concat cost volume without the cost volume (reference nets/psmnet/psmnet_3.py:
+149-166): the volume is constant along d in its left-feature half and an x-shift of the right feature map
+in the other half, so its 3x3x3 convolution factors into 2-D convolutions of the two feature maps
+(csrc/az_costconv.hip has the derivation) -- 80 GFLOP at B=4 instead of 693, no 1.6 GB volume, no
+1.6 GB volume gradient.
+
+  merged kernels (differentiable tensor ops on the Conv3d weight)
+    K_L[c, dl][o, i, kh, kw] = sum over kd in class c with kd - kw <= delta(dl) of W[o, i, kd, kh, kw]
+    K_R[c, xb][o, i, kh, j]  = sum over kd in class c, kw with kw - kd = j - 2 (and kw <= 1 if xb) of W[o, 32+i, kd, kh, kw]
+  F = conv2d(L, K_L, pad 1), G = conv2d(pad_left2(R), K_R, pad (1,2))        (MIOpen, autograd)
+  raw = assemble(F, G)                                                       (az_costconv_assemble_*)
+"""
+import torch
+import torch.nn.functional as F_
+
+from . import profiler
+from .ops import _call, _chk, _p, _stream
+
+NCLS, NDL = 4, 5
+_MASKS = {}
+
+
+def _masks(device):
+    """0/1 selection tensors: ML[c, dl, kd, kw], MR[c, xb, kd, kw, j]."""
+    key = str(device)
+    if key not in _MASKS:
+        ml = torch.zeros(NCLS, NDL, 3, 3)
+        mr = torch.zeros(NCLS, 2, 3, 3, 5)
+        for c in range(NCLS):
+            has = {0: bool(c & 1), 1: True, 2: bool(c & 2)}  # class = (d >= 1) + 2 (d <= D-2): which kd exist
+            for kd in range(3):
+                if not has[kd]:
+                    continue
+                for kw in range(3):
+                    for dl in range(NDL):
+                        delta = dl - 2  # dl = 4 stands for every delta >= 2: all taps pass
+                        if kd - kw <= delta:
+                            ml[c, dl, kd, kw] = 1.0
+                    for xb in range(2):
+                        if xb == 1 and kw == 2:
+                            continue  # x = W-1: the tap reads x' = W, outside the volume
+                        mr[c, xb, kd, kw, kw - kd + 2] = 1.0
+        _MASKS[key] = (ml.to(device), mr.to(device))
+    return _MASKS[key]
+
+
+class _Assemble(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, g, ndisp):
+        f, g = _chk(f, "F"), _chk(g, "G")  # [B,H,W,640], [B,H,W+2,256] channels-last rows
+        b, h, w, _ = f.shape
+        out = f.new_empty(b, ndisp, h, w, 32)
+        with torch.cuda.device(f.device):
+            with profiler.scope("costconv_assemble", bytes=4.0 * out.numel(), bound="hbm"):
+                _call("az_costconv_assemble_fwd", _p(out), _p(f), _p(g), b, ndisp, h, w, _stream())
+        ctx.dims = (b, ndisp, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        b, d, h, w = ctx.dims
+        gy = _chk(gy.contiguous(), "grad_out")
+        df = gy.new_empty(b, h, w, NCLS * NDL * 32)
+        dg = gy.new_empty(b, h, w + 2, NCLS * 2 * 32)
+        with torch.cuda.device(gy.device):
+            with profiler.scope("costconv_assemble_bwd", bytes=8.0 * gy.numel(), bound="hbm"):
+                _call("az_costconv_assemble_bwd", _p(df), _p(dg), _p(gy), b, d, h, w, _stream())
+        return df, dg, None
+
+
+def costvol_conv(feat_l, feat_r, ndisp, weight):
+    """conv3d(concat_cost_volume(feat_l, feat_r, ndisp), weight, padding=1) as [B,ndisp,h,w,32] (NDHWC).
+    feat_*: [B,32,h,w] (channels_last preferred); weight: [32,64,3,3,3]."""
+    if tuple(weight.shape) != (32, 64, 3, 3, 3) or feat_l.shape[1] != 32 or feat_l.shape != feat_r.shape:
+        raise RuntimeError("costvol_conv expects two [B,32,h,w] feature maps and a [32,64,3,3,3] weight")
+    ml, mr = _masks(weight.device)
+    kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml).reshape(NCLS * NDL * 32, 32, 3, 3)
+    kr = torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(NCLS * 2 * 32, 32, 3, 5)
+    cl = torch.channels_last
+    f = F_.conv2d(feat_l.contiguous(memory_format=cl), kl.contiguous(memory_format=cl), padding=1)
+    rp = F_.pad(feat_r, (2, 0)).contiguous(memory_format=cl)
+    g = F_.conv2d(rp, kr.contiguous(memory_format=cl), padding=(1, 2))
+    # [B,C,h,w] channels_last -> rows [B,h,w,C]
+    return _Assemble.apply(f.permute(0, 2, 3, 1).contiguous(), g.permute(0, 2, 3, 1).contiguous(), int(ndisp))

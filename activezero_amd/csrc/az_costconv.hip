@@ -1,0 +1,142 @@
+// K3+K4 fused algebraically: the first 3-D convolution of the cost aggregation applied to the
+// concat cost volume WITHOUT the volume (reference nets/psmnet/psmnet_3.py:149-166: the volume
+// V[d,y,x,:32] = L[y,x] (x >= d), V[d,y,x,32:] = R[y,x-d] (x >= d), then dres0[0] = Conv3d(64,32,3,pad 1)).
+//
+// V is constant along d in its left half and a pure x-shift in its right half, so
+//   conv3d(V)[d,y,x] = F_{c(d), min(x-d,2)}[y,x] + G_{c(d), [x = W-1]}[y, x-d]          (x - d >= -2, else 0)
+// where the F are 2-D 3x3 convolutions of L with the 3-D kernel summed over the depth taps that exist
+// for depth class c (first / middle / last plane) and that the staircase mask x' >= d' admits at offset
+// delta = x - d (only delta < 2 cuts taps), and the G are 2-D 3x5 convolutions of R whose horizontal
+// tap index is kw - kd (the mask is R's own left zero padding; only the image's right edge needs its own
+// variant).  The 2-D convolutions (32 -> 640 and 32 -> 256 channels at h x w: 80 GFLOP at B=4 instead of
+// 693) run on MIOpen through autograd (activezero_amd/costconv.py builds the merged kernels with
+// differentiable tensor ops); this file holds the memory-bound ends:
+//   assemble_fwd : out[b,d,y,x,:] = F[...] + G[...]                 (writes the 32-channel V0 tensor once)
+//   assemble_bwd : dF, dG = the matching reductions of grad_out over d (reads it twice)
+// Depth class of plane d: c = (d >= 1) + 2 * (d <= D-2)  (which of kd = 0 / kd = 2 exist).
+#include "az_common.h"
+
+#define CC_NCLS 4
+#define CC_NDL 5   // delta variants: -2, -1, 0, 1, >= 2
+#define CC_CF (CC_NCLS * CC_NDL * 32)
+#define CC_CG (CC_NCLS * 2 * 32)
+
+__device__ __forceinline__ int cc_class(int d, int D) { return (d >= 1 ? 1 : 0) + (d <= D - 2 ? 2 : 0); }
+
+// one thread = 4 channels of one output voxel
+__global__ void __launch_bounds__(256)
+costconv_assemble_fwd_kernel(float4 *__restrict__ out, const float4 *__restrict__ F,
+                             const float4 *__restrict__ G, int D, int H, int W, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i & 7);
+        long long v = i >> 3;
+        const int x = (int)(v % W); v /= W;
+        const int y = (int)(v % H); v /= H;
+        const int d = (int)(v % D);
+        const long long b = v / D;
+        const int delta = x - d;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (delta >= -2) {
+            const int cls = cc_class(d, D);
+            const int dl = min(delta, 2) + 2;
+            const float4 f = F[(((b * H + y) * W + x) * (CC_CF / 4)) + (cls * CC_NDL + dl) * 8 + cq];
+            const int xb = (x == W - 1) ? 1 : 0;
+            const float4 g = G[(((b * H + y) * (W + 2) + (delta + 2)) * (CC_CG / 4)) + (cls * 2 + xb) * 8 + cq];
+            o = make_float4(f.x + g.x, f.y + g.y, f.z + g.z, f.w + g.w);
+        }
+        out[i] = o;
+    }
+}
+
+// dF[b,y,x,(cls,dl),:]: dl = 4 (delta >= 2): sum over d <= x-2 of class cls; dl < 4: the single plane d = x - (dl-2)
+__global__ void __launch_bounds__(256)
+costconv_grad_f_kernel(float4 *__restrict__ dF, const float4 *__restrict__ gy, int D, int H, int W,
+                       long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i & 7);
+        long long v = i >> 3;
+        const int x = (int)(v % W); v /= W;
+        const int y = (int)(v % H);
+        const long long b = v / H;
+        const size_t plane = (size_t)H * W * 8;
+        const float4 *g0 = gy + (size_t)b * D * plane + ((size_t)y * W + x) * 8 + cq;
+        float4 bulk[CC_NCLS];
+#pragma unroll
+        for (int c = 0; c < CC_NCLS; ++c) bulk[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int dmax = min(D - 1, x - 2);
+        for (int d = 0; d <= dmax; ++d) {
+            const float4 g = g0[(size_t)d * plane];
+            const int cls = cc_class(d, D);
+#pragma unroll
+            for (int c = 0; c < CC_NCLS; ++c)
+                if (c == cls) { bulk[c].x += g.x; bulk[c].y += g.y; bulk[c].z += g.z; bulk[c].w += g.w; }
+        }
+        float4 *o = dF + (((size_t)b * H + y) * W + x) * (CC_CF / 4) + cq;
+#pragma unroll
+        for (int c = 0; c < CC_NCLS; ++c) {
+#pragma unroll
+            for (int dl = 0; dl < 4; ++dl) {  // delta = dl - 2 in {-2,-1,0,1}: plane d = x - delta
+                const int d = x - (dl - 2);
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d >= 0 && d < D && cc_class(d, D) == c) g = g0[(size_t)d * plane];
+                o[(c * CC_NDL + dl) * 8] = g;
+            }
+            o[(c * CC_NDL + 4) * 8] = bulk[c];
+        }
+    }
+}
+
+// dG[b,y,t,(cls,xb),:], t = u + 2, u = x - d in [-2, W): sum over d of grad_out[b,d,y,u+d,:]
+__global__ void __launch_bounds__(256)
+costconv_grad_g_kernel(float4 *__restrict__ dG, const float4 *__restrict__ gy, int D, int H, int W,
+                       long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cq = (int)(i & 7);
+        long long v = i >> 3;
+        const int t = (int)(v % (W + 2)); v /= (W + 2);
+        const int y = (int)(v % H);
+        const long long b = v / H;
+        const int u = t - 2;
+        const size_t plane = (size_t)H * W * 8;
+        const float4 *g0 = gy + (size_t)b * D * plane + (size_t)y * W * 8 + cq;
+        float4 acc[CC_NCLS][2];
+#pragma unroll
+        for (int c = 0; c < CC_NCLS; ++c) { acc[c][0] = make_float4(0.f, 0.f, 0.f, 0.f); acc[c][1] = acc[c][0]; }
+        const int d_lo = max(0, -u), d_hi = min(D - 1, W - 1 - u);  // 0 <= x = u + d <= W-1
+        for (int d = d_lo; d <= d_hi; ++d) {
+            const int x = u + d;
+            const float4 g = g0[(size_t)d * plane + (size_t)x * 8];
+            const int cls = cc_class(d, D), xb = (x == W - 1) ? 1 : 0;
+#pragma unroll
+            for (int c = 0; c < CC_NCLS; ++c)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    if (c == cls && e == xb) { acc[c][e].x += g.x; acc[c][e].y += g.y; acc[c][e].z += g.z; acc[c][e].w += g.w; }
+        }
+        float4 *o = dG + (((size_t)b * H + y) * (W + 2) + t) * (CC_CG / 4) + cq;
+#pragma unroll
+        for (int c = 0; c < CC_NCLS; ++c) { o[(c * 2 + 0) * 8] = acc[c][0]; o[(c * 2 + 1) * 8] = acc[c][1]; }
+    }
+}
+
+extern "C" int az_costconv_assemble_fwd(float *out, const float *F, const float *G, int B, int D, int H, int W,
+                                        void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(F); AZ_REQUIRE_PTR(G);
+    AZ_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0);
+    const long long total = (long long)B * D * H * W * 8;
+    hipLaunchKernelGGL(costconv_assemble_fwd_kernel, dim3(az_grid_for(total, 256)), dim3(256), 0, az_stream(stream),
+                       (float4 *)out, (const float4 *)F, (const float4 *)G, D, H, W, total);
+    return az_launch_status();
+}
+
+extern "C" int az_costconv_assemble_bwd(float *dF, float *dG, const float *grad_out, int B, int D, int H, int W,
+                                        void *stream) {
+    AZ_REQUIRE_PTR(dF); AZ_REQUIRE_PTR(dG); AZ_REQUIRE_PTR(grad_out);
+    AZ_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0);
+    const long long tf = (long long)B * H * W * 8, tg = (long long)B * H * (W + 2) * 8;
+    hipLaunchKernelGGL(costconv_grad_f_kernel, dim3(az_grid_for(tf, 256)), dim3(256), 0, az_stream(stream),
+                       (float4 *)dF, (const float4 *)grad_out, D, H, W, tf);
+    hipLaunchKernelGGL(costconv_grad_g_kernel, dim3(az_grid_for(tg, 256)), dim3(256), 0, az_stream(stream),
+                       (float4 *)dG, (const float4 *)grad_out, D, H, W, tg);
+    return az_launch_status();
+}

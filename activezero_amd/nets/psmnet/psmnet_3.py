@@ -97,8 +97,9 @@ class PSMNet(nn.Module):
                 m.bias.data.zero_()
 
     # -- hot path ------------------------------------------------------------
-    def _aggregate(self, vol):
-        c0 = agg3d.conv_bn(vol, self.dres0[0], relu=True)
+    def _aggregate(self, vol, first=None):
+        # `first`: dres0[0]'s activation when it was computed straight from the feature maps
+        c0 = first if first is not None else agg3d.conv_bn(vol, self.dres0[0], relu=True)
         c0 = agg3d.conv_bn(c0, self.dres0[2], relu=True)
         t = agg3d.conv_bn(c0, self.dres1[0], relu=True)
         c0 = agg3d.conv_bn(t, self.dres1[2], add=c0)
@@ -118,8 +119,14 @@ class PSMNet(nn.Module):
         return cost1, cost2, cost3
 
     def _from_features(self, feat_l, feat_r):
-        vol = agg3d.volume_from_features(feat_l, feat_r, self.maxdisp // 4)
-        cost1, cost2, cost3 = self._aggregate(vol)
+        if agg3d.use_costconv(feat_l):
+            # cost volume + dres0[0] factored into 2-D convolutions of the two feature maps: the
+            # [B,64,D/4,h,w] volume (psmnet_3.py:149-163) and its gradient are never formed
+            first = agg3d.costvol_conv_bn(feat_l, feat_r, self.maxdisp // 4, self.dres0[0], relu=True)
+            cost1, cost2, cost3 = self._aggregate(None, first)
+        else:
+            vol = agg3d.volume_from_features(feat_l, feat_r, self.maxdisp // 4)
+            cost1, cost2, cost3 = self._aggregate(vol)
         pred3 = ops.softargmin(cost3)
         if self.training:
             return pred3, ops.softargmin(cost2), ops.softargmin(cost1)
