@@ -33,8 +33,9 @@ _SIGS = {
     "az_patch_reproj_vis": [_PTR] * 3 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
     "az_sum4": [_PTR] * 5 + [_LL, _PTR],
-    "az_costconv_assemble_fwd": [_PTR] * 3 + [_INT] * 4 + [_PTR],
-    "az_costconv_assemble_bwd": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_costconv_edge_width": [_INT, _INT],
+    "az_costconv_assemble_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
+    "az_costconv_assemble_bwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_bn3d_stats_tiles": [_LL, _INT],
     "az_bn3d_stats": [_PTR] * 3 + [_LL, _INT, _PTR],
     "az_bn2d_workspace": [_INT, _LL, _INT],

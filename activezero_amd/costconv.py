@@ -46,26 +46,27 @@ def _masks(device):
 
 class _Assemble(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f, g, ndisp):
-        f, g = _chk(f, "F"), _chk(g, "G")  # [B,H,W,640], [B,H,W+2,256] channels-last rows
-        b, h, w, _ = f.shape
-        out = f.new_empty(b, ndisp, h, w, 32)
-        with torch.cuda.device(f.device):
+    def forward(ctx, fb, fe, g, ndisp):
+        fb, fe, g = _chk(fb, "F_bulk"), _chk(fe, "F_edge"), _chk(g, "G")  # channels-last rows
+        b, h, w, _ = fb.shape
+        out = fb.new_empty(b, ndisp, h, w, 32)
+        with torch.cuda.device(fb.device):
             with profiler.scope("costconv_assemble", bytes=4.0 * out.numel(), bound="hbm"):
-                _call("az_costconv_assemble_fwd", _p(out), _p(f), _p(g), b, ndisp, h, w, _stream())
-        ctx.dims = (b, ndisp, h, w)
+                _call("az_costconv_assemble_fwd", _p(out), _p(fb), _p(fe), _p(g), b, ndisp, h, w, _stream())
+        ctx.dims = (b, ndisp, h, w, fe.shape[2])
         return out
 
     @staticmethod
     def backward(ctx, gy):
-        b, d, h, w = ctx.dims
+        b, d, h, w, xe = ctx.dims
         gy = _chk(gy.contiguous(), "grad_out")
-        df = gy.new_empty(b, h, w, NCLS * NDL * 32)
+        dfb = gy.new_empty(b, h, w, NCLS * 32)
+        dfe = gy.new_empty(b, h, xe, NCLS * 4 * 32)
         dg = gy.new_empty(b, h, w + 2, NCLS * 2 * 32)
         with torch.cuda.device(gy.device):
             with profiler.scope("costconv_assemble_bwd", bytes=8.0 * gy.numel(), bound="hbm"):
-                _call("az_costconv_assemble_bwd", _p(df), _p(dg), _p(gy), b, d, h, w, _stream())
-        return df, dg, None
+                _call("az_costconv_assemble_bwd", _p(dfb), _p(dfe), _p(dg), _p(gy), b, d, h, w, _stream())
+        return dfb, dfe, dg, None
 
 
 def costvol_conv(feat_l, feat_r, ndisp, weight):
@@ -73,12 +74,21 @@ def costvol_conv(feat_l, feat_r, ndisp, weight):
     feat_*: [B,32,h,w] (channels_last preferred); weight: [32,64,3,3,3]."""
     if tuple(weight.shape) != (32, 64, 3, 3, 3) or feat_l.shape[1] != 32 or feat_l.shape != feat_r.shape:
         raise RuntimeError("costvol_conv expects two [B,32,h,w] feature maps and a [32,64,3,3,3] weight")
+    from . import _lib
+    w = feat_l.shape[-1]
+    xe = _lib.lib().az_costconv_edge_width(int(ndisp), w)
     ml, mr = _masks(weight.device)
-    kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml).reshape(NCLS * NDL * 32, 32, 3, 3)
+    kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml)          # [cls, dl, o, i, 3, 3]
+    kl_bulk = kl[:, 4].reshape(NCLS * 32, 32, 3, 3)
+    kl_edge = kl[:, :4].reshape(NCLS * 4 * 32, 32, 3, 3)
     kr = torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(NCLS * 2 * 32, 32, 3, 5)
     cl = torch.channels_last
-    f = F_.conv2d(feat_l.contiguous(memory_format=cl), kl.contiguous(memory_format=cl), padding=1)
+    fl = feat_l.contiguous(memory_format=cl)
+    fb = F_.conv2d(fl, kl_bulk.contiguous(memory_format=cl), padding=1)
+    # the delta < 2 maps are read at x = d + delta <= ndisp only: convolve the first xe (+1 halo) columns
+    fe = F_.conv2d(fl[..., :min(w, xe + 1)].contiguous(memory_format=cl), kl_edge.contiguous(memory_format=cl),
+                   padding=1)[..., :xe]
     rp = F_.pad(feat_r, (2, 0)).contiguous(memory_format=cl)
     g = F_.conv2d(rp, kr.contiguous(memory_format=cl), padding=(1, 2))
-    # [B,C,h,w] channels_last -> rows [B,h,w,C]
-    return _Assemble.apply(f.permute(0, 2, 3, 1).contiguous(), g.permute(0, 2, 3, 1).contiguous(), int(ndisp))
+    rows = lambda t: t.permute(0, 2, 3, 1).contiguous()  # [B,C,h,w] -> [B,h,w,C]
+    return _Assemble.apply(rows(fb), rows(fe), rows(g), int(ndisp))

@@ -4,6 +4,8 @@
 //
 // V is constant along d in its left half and a pure x-shift in its right half, so
 //   conv3d(V)[d,y,x] = F_{c(d), min(x-d,2)}[y,x] + G_{c(d), [x = W-1]}[y, x-d]          (x - d >= -2, else 0)
+// (the F variants with x - d < 2 are only ever read at x = d + delta <= D: they are computed on the
+//  first D+1 columns only -- "edge" maps -- and the four x - d >= 2 maps -- "bulk" -- on the full width)
 // where the F are 2-D 3x3 convolutions of L with the 3-D kernel summed over the depth taps that exist
 // for depth class c (first / middle / last plane) and that the staircase mask x' >= d' admits at offset
 // delta = x - d (only delta < 2 cuts taps), and the G are 2-D 3x5 convolutions of R whose horizontal
@@ -18,15 +20,17 @@
 
 #define CC_NCLS 4
 #define CC_NDL 5   // delta variants: -2, -1, 0, 1, >= 2
-#define CC_CF (CC_NCLS * CC_NDL * 32)
+#define CC_CFB (CC_NCLS * 32)        // bulk maps (delta >= 2): full width
+#define CC_CFE (CC_NCLS * 4 * 32)    // edge maps (delta = -2..1): only columns x <= D exist (x = d + delta)
 #define CC_CG (CC_NCLS * 2 * 32)
 
 __device__ __forceinline__ int cc_class(int d, int D) { return (d >= 1 ? 1 : 0) + (d <= D - 2 ? 2 : 0); }
 
 // one thread = 4 channels of one output voxel
 __global__ void __launch_bounds__(256)
-costconv_assemble_fwd_kernel(float4 *__restrict__ out, const float4 *__restrict__ F,
-                             const float4 *__restrict__ G, int D, int H, int W, long long total) {
+costconv_assemble_fwd_kernel(float4 *__restrict__ out, const float4 *__restrict__ Fb,
+                             const float4 *__restrict__ Fe, const float4 *__restrict__ G, int D, int H, int W,
+                             int XE, long long total) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int cq = (int)(i & 7);
         long long v = i >> 3;
@@ -38,8 +42,9 @@ costconv_assemble_fwd_kernel(float4 *__restrict__ out, const float4 *__restrict_
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (delta >= -2) {
             const int cls = cc_class(d, D);
-            const int dl = min(delta, 2) + 2;
-            const float4 f = F[(((b * H + y) * W + x) * (CC_CF / 4)) + (cls * CC_NDL + dl) * 8 + cq];
+            const float4 f = (delta >= 2)
+                ? Fb[(((b * H + y) * W + x) * (CC_CFB / 4)) + cls * 8 + cq]
+                : Fe[(((b * H + y) * XE + x) * (CC_CFE / 4)) + (cls * 4 + (delta + 2)) * 8 + cq];  // x = d + delta < XE
             const int xb = (x == W - 1) ? 1 : 0;
             const float4 g = G[(((b * H + y) * (W + 2) + (delta + 2)) * (CC_CG / 4)) + (cls * 2 + xb) * 8 + cq];
             o = make_float4(f.x + g.x, f.y + g.y, f.z + g.z, f.w + g.w);
@@ -50,8 +55,8 @@ costconv_assemble_fwd_kernel(float4 *__restrict__ out, const float4 *__restrict_
 
 // dF[b,y,x,(cls,dl),:]: dl = 4 (delta >= 2): sum over d <= x-2 of class cls; dl < 4: the single plane d = x - (dl-2)
 __global__ void __launch_bounds__(256)
-costconv_grad_f_kernel(float4 *__restrict__ dF, const float4 *__restrict__ gy, int D, int H, int W,
-                       long long total) {
+costconv_grad_f_kernel(float4 *__restrict__ dFb, float4 *__restrict__ dFe, const float4 *__restrict__ gy,
+                       int D, int H, int W, int XE, long long total) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int cq = (int)(i & 7);
         long long v = i >> 3;
@@ -71,17 +76,20 @@ costconv_grad_f_kernel(float4 *__restrict__ dF, const float4 *__restrict__ gy, i
             for (int c = 0; c < CC_NCLS; ++c)
                 if (c == cls) { bulk[c].x += g.x; bulk[c].y += g.y; bulk[c].z += g.z; bulk[c].w += g.w; }
         }
-        float4 *o = dF + (((size_t)b * H + y) * W + x) * (CC_CF / 4) + cq;
+        float4 *ob = dFb + (((size_t)b * H + y) * W + x) * (CC_CFB / 4) + cq;
 #pragma unroll
-        for (int c = 0; c < CC_NCLS; ++c) {
+        for (int c = 0; c < CC_NCLS; ++c) ob[c * 8] = bulk[c];
+        if (x < XE) {
+            float4 *oe = dFe + (((size_t)b * H + y) * XE + x) * (CC_CFE / 4) + cq;
 #pragma unroll
-            for (int dl = 0; dl < 4; ++dl) {  // delta = dl - 2 in {-2,-1,0,1}: plane d = x - delta
-                const int d = x - (dl - 2);
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (d >= 0 && d < D && cc_class(d, D) == c) g = g0[(size_t)d * plane];
-                o[(c * CC_NDL + dl) * 8] = g;
-            }
-            o[(c * CC_NDL + 4) * 8] = bulk[c];
+            for (int c = 0; c < CC_NCLS; ++c)
+#pragma unroll
+                for (int dl = 0; dl < 4; ++dl) {  // delta = dl - 2 in {-2,-1,0,1}: plane d = x - delta
+                    const int d = x - (dl - 2);
+                    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (d >= 0 && d < D && cc_class(d, D) == c) g = g0[(size_t)d * plane];
+                    oe[(c * 4 + dl) * 8] = g;
+                }
         }
     }
 }
@@ -119,23 +127,27 @@ costconv_grad_g_kernel(float4 *__restrict__ dG, const float4 *__restrict__ gy, i
     }
 }
 
-extern "C" int az_costconv_assemble_fwd(float *out, const float *F, const float *G, int B, int D, int H, int W,
-                                        void *stream) {
-    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(F); AZ_REQUIRE_PTR(G);
+extern "C" int az_costconv_edge_width(int D, int W) { return D + 1 < W ? D + 1 : W; }
+
+extern "C" int az_costconv_assemble_fwd(float *out, const float *F_bulk, const float *F_edge, const float *G, int B,
+                                        int D, int H, int W, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(F_bulk); AZ_REQUIRE_PTR(F_edge); AZ_REQUIRE_PTR(G);
     AZ_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0);
     const long long total = (long long)B * D * H * W * 8;
     hipLaunchKernelGGL(costconv_assemble_fwd_kernel, dim3(az_grid_for(total, 256)), dim3(256), 0, az_stream(stream),
-                       (float4 *)out, (const float4 *)F, (const float4 *)G, D, H, W, total);
+                       (float4 *)out, (const float4 *)F_bulk, (const float4 *)F_edge, (const float4 *)G, D, H, W,
+                       az_costconv_edge_width(D, W), total);
     return az_launch_status();
 }
 
-extern "C" int az_costconv_assemble_bwd(float *dF, float *dG, const float *grad_out, int B, int D, int H, int W,
-                                        void *stream) {
-    AZ_REQUIRE_PTR(dF); AZ_REQUIRE_PTR(dG); AZ_REQUIRE_PTR(grad_out);
+extern "C" int az_costconv_assemble_bwd(float *dF_bulk, float *dF_edge, float *dG, const float *grad_out, int B,
+                                        int D, int H, int W, void *stream) {
+    AZ_REQUIRE_PTR(dF_bulk); AZ_REQUIRE_PTR(dF_edge); AZ_REQUIRE_PTR(dG); AZ_REQUIRE_PTR(grad_out);
     AZ_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0);
     const long long tf = (long long)B * H * W * 8, tg = (long long)B * H * (W + 2) * 8;
     hipLaunchKernelGGL(costconv_grad_f_kernel, dim3(az_grid_for(tf, 256)), dim3(256), 0, az_stream(stream),
-                       (float4 *)dF, (const float4 *)grad_out, D, H, W, tf);
+                       (float4 *)dF_bulk, (float4 *)dF_edge, (const float4 *)grad_out, D, H, W,
+                       az_costconv_edge_width(D, W), tf);
     hipLaunchKernelGGL(costconv_grad_g_kernel, dim3(az_grid_for(tg, 256)), dim3(256), 0, az_stream(stream),
                        (float4 *)dG, (const float4 *)grad_out, D, H, W, tg);
     return az_launch_status();

@@ -2,7 +2,7 @@
 """Summarise a rocprofv3 --kernel-trace CSV over bench.py's TIMED region only.
 
 rocprofv3 traces the whole process (MIOpen's find phase, warm-up steps, ...).
-The forward cost-volume convolution `conv3d_m128_kernel<64, 1, 0>`
+The cost-volume assemble kernel `costconv_assemble_fwd_kernel`
 (dres0[0], train mode) runs exactly once per step, so its (warmup+1)-th dispatch
 marks the start of the timed steps.
 
@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--marker", default="conv3d_m128_kernel<64, 1, 0>")
+    ap.add_argument("--marker", default="costconv_assemble_fwd_kernel")
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
     a = ap.parse_args()
