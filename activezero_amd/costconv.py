@@ -44,6 +44,30 @@ def _masks(device):
     return _MASKS[key]
 
 
+_MERGED_CACHE = {}
+
+
+def _merged_kernels(weight):
+    """(K_L bulk [128,32,3,3], K_L edge [512,32,3,3], K_R [256,32,3,5]) of a [32,64,3,3,3] weight; differentiable.
+    Cached between inference forwards on the weight's version (conv3d._inference_mode)."""
+    from .conv3d import _inference_mode
+    key = (weight.data_ptr(), weight._version, weight.device.index) if _inference_mode() else None
+    if key is not None and key in _MERGED_CACHE:
+        return _MERGED_CACHE[key][:3]
+    cl = torch.channels_last
+    ml, mr = _masks(weight.device)
+    kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml)          # [cls, dl, o, i, 3, 3]
+    out = (kl[:, 4].reshape(NCLS * 32, 32, 3, 3).contiguous(memory_format=cl),
+           kl[:, :4].reshape(NCLS * 4 * 32, 32, 3, 3).contiguous(memory_format=cl),
+           torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(NCLS * 2 * 32, 32, 3, 5)
+           .contiguous(memory_format=cl))
+    if key is not None:
+        if len(_MERGED_CACHE) > 16:
+            _MERGED_CACHE.clear()
+        _MERGED_CACHE[key] = out + (weight,)  # (keeps the source alive: its address stays unique)
+    return out
+
+
 class _Assemble(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fb, fe, g, ndisp):
@@ -77,18 +101,13 @@ def costvol_conv(feat_l, feat_r, ndisp, weight):
     from . import _lib
     w = feat_l.shape[-1]
     xe = _lib.lib().az_costconv_edge_width(int(ndisp), w)
-    ml, mr = _masks(weight.device)
-    kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml)          # [cls, dl, o, i, 3, 3]
-    kl_bulk = kl[:, 4].reshape(NCLS * 32, 32, 3, 3)
-    kl_edge = kl[:, :4].reshape(NCLS * 4 * 32, 32, 3, 3)
-    kr = torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(NCLS * 2 * 32, 32, 3, 5)
     cl = torch.channels_last
+    kl_bulk, kl_edge, kr = _merged_kernels(weight)
     fl = feat_l.contiguous(memory_format=cl)
-    fb = F_.conv2d(fl, kl_bulk.contiguous(memory_format=cl), padding=1)
+    fb = F_.conv2d(fl, kl_bulk, padding=1)
     # the delta < 2 maps are read at x = d + delta <= ndisp only: convolve the first xe (+1 halo) columns
-    fe = F_.conv2d(fl[..., :min(w, xe + 1)].contiguous(memory_format=cl), kl_edge.contiguous(memory_format=cl),
-                   padding=1)[..., :xe]
+    fe = F_.conv2d(fl[..., :min(w, xe + 1)].contiguous(memory_format=cl), kl_edge, padding=1)[..., :xe]
     rp = F_.pad(feat_r, (2, 0)).contiguous(memory_format=cl)
-    g = F_.conv2d(rp, kr.contiguous(memory_format=cl), padding=(1, 2))
+    g = F_.conv2d(rp, kr, padding=(1, 2))
     rows = lambda t: t.permute(0, 2, 3, 1).contiguous()  # [B,C,h,w] -> [B,h,w,C]
     return _Assemble.apply(rows(fb), rows(fe), rows(g), int(ndisp))
