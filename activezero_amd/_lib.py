@@ -34,6 +34,7 @@ _SIGS = {
     "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
     "az_sum4": [_PTR] * 5 + [_LL, _PTR],
     "az_costconv_edge_width": [_INT, _INT],
+    "az_costconv_num_classes": [_INT],
     "az_costconv_assemble_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_costconv_assemble_bwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_bn3d_stats_tiles": [_LL, _INT],

@@ -16,18 +16,26 @@ import torch.nn.functional as F_
 from . import profiler
 from .ops import _call, _chk, _p, _stream
 
-NCLS, NDL = 4, 5
+NDL = 5
 _MASKS = {}
 
 
-def _masks(device):
+def num_classes(ndisp):
+    """depth classes present (csrc/az_costconv.hip cc_class): first / middle / last plane."""
+    return min(int(ndisp), 3)
+
+
+def _masks(device, ndisp):
     """0/1 selection tensors: ML[c, dl, kd, kw], MR[c, xb, kd, kw, j]."""
-    key = str(device)
+    ncls = num_classes(ndisp)
+    key = (str(device), ncls)
     if key not in _MASKS:
-        ml = torch.zeros(NCLS, NDL, 3, 3)
-        mr = torch.zeros(NCLS, 2, 3, 3, 5)
-        for c in range(NCLS):
-            has = {0: bool(c & 1), 1: True, 2: bool(c & 2)}  # class = (d >= 1) + 2 (d <= D-2): which kd exist
+        ml = torch.zeros(ncls, NDL, 3, 3)
+        mr = torch.zeros(ncls, 2, 3, 3, 5)
+        # which depth taps exist per class: D >= 3: first {1,2}, middle {0,1,2}, last {0,1}; D = 2: first, last; D = 1: {1}
+        taps = {1: [(1,)], 2: [(1, 2), (0, 1)], 3: [(1, 2), (0, 1, 2), (0, 1)]}[ncls]
+        for c in range(ncls):
+            has = {kd: (kd in taps[c]) for kd in range(3)}
             for kd in range(3):
                 if not has[kd]:
                     continue
@@ -47,19 +55,20 @@ def _masks(device):
 _MERGED_CACHE = {}
 
 
-def _merged_kernels(weight):
+def _merged_kernels(weight, ndisp):
     """(K_L bulk [128,32,3,3], K_L edge [512,32,3,3], K_R [256,32,3,5]) of a [32,64,3,3,3] weight; differentiable.
     Cached between inference forwards on the weight's version (conv3d._inference_mode)."""
     from .conv3d import _inference_mode
-    key = (weight.data_ptr(), weight._version, weight.device.index) if _inference_mode() else None
+    ncls = num_classes(ndisp)
+    key = (weight.data_ptr(), weight._version, weight.device.index, ncls) if _inference_mode() else None
     if key is not None and key in _MERGED_CACHE:
         return _MERGED_CACHE[key][:3]
     cl = torch.channels_last
-    ml, mr = _masks(weight.device)
+    ml, mr = _masks(weight.device, ndisp)
     kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml)          # [cls, dl, o, i, 3, 3]
-    out = (kl[:, 4].reshape(NCLS * 32, 32, 3, 3).contiguous(memory_format=cl),
-           kl[:, :4].reshape(NCLS * 4 * 32, 32, 3, 3).contiguous(memory_format=cl),
-           torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(NCLS * 2 * 32, 32, 3, 5)
+    out = (kl[:, 4].reshape(ncls * 32, 32, 3, 3).contiguous(memory_format=cl),
+           kl[:, :4].reshape(ncls * 4 * 32, 32, 3, 3).contiguous(memory_format=cl),
+           torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(ncls * 2 * 32, 32, 3, 5)
            .contiguous(memory_format=cl))
     if key is not None:
         if len(_MERGED_CACHE) > 16:
@@ -77,16 +86,16 @@ class _Assemble(torch.autograd.Function):
         with torch.cuda.device(fb.device):
             with profiler.scope("costconv_assemble", bytes=4.0 * out.numel(), bound="hbm"):
                 _call("az_costconv_assemble_fwd", _p(out), _p(fb), _p(fe), _p(g), b, ndisp, h, w, _stream())
-        ctx.dims = (b, ndisp, h, w, fe.shape[2])
+        ctx.dims = (b, ndisp, h, w, fe.shape[2], fb.shape[3] // 32)
         return out
 
     @staticmethod
     def backward(ctx, gy):
-        b, d, h, w, xe = ctx.dims
+        b, d, h, w, xe, ncls = ctx.dims
         gy = _chk(gy.contiguous(), "grad_out")
-        dfb = gy.new_empty(b, h, w, NCLS * 32)
-        dfe = gy.new_empty(b, h, xe, NCLS * 4 * 32)
-        dg = gy.new_empty(b, h, w + 2, NCLS * 2 * 32)
+        dfb = gy.new_empty(b, h, w, ncls * 32)
+        dfe = gy.new_empty(b, h, xe, ncls * 4 * 32)
+        dg = gy.new_empty(b, h, w + 2, ncls * 2 * 32)
         with torch.cuda.device(gy.device):
             with profiler.scope("costconv_assemble_bwd", bytes=8.0 * gy.numel(), bound="hbm"):
                 _call("az_costconv_assemble_bwd", _p(dfb), _p(dfe), _p(dg), _p(gy), b, d, h, w, _stream())
@@ -102,7 +111,7 @@ def costvol_conv(feat_l, feat_r, ndisp, weight):
     w = feat_l.shape[-1]
     xe = _lib.lib().az_costconv_edge_width(int(ndisp), w)
     cl = torch.channels_last
-    kl_bulk, kl_edge, kr = _merged_kernels(weight)
+    kl_bulk, kl_edge, kr = _merged_kernels(weight, ndisp)
     fl = feat_l.contiguous(memory_format=cl)
     fb = F_.conv2d(fl, kl_bulk, padding=1)
     # the delta < 2 maps are read at x = d + delta <= ndisp only: convolve the first xe (+1 halo) columns

@@ -10,21 +10,22 @@
 // for depth class c (first / middle / last plane) and that the staircase mask x' >= d' admits at offset
 // delta = x - d (only delta < 2 cuts taps), and the G are 2-D 3x5 convolutions of R whose horizontal
 // tap index is kw - kd (the mask is R's own left zero padding; only the image's right edge needs its own
-// variant).  The 2-D convolutions (32 -> 640 and 32 -> 256 channels at h x w: 80 GFLOP at B=4 instead of
-// 693) run on MIOpen through autograd (activezero_amd/costconv.py builds the merged kernels with
+// variant).  The 2-D convolutions (32 -> 96 full width + 384 on D+1 columns, and 32 -> 192: ~45 GFLOP at B=4
+// instead of 693) run on MIOpen through autograd (activezero_amd/costconv.py builds the merged kernels with
 // differentiable tensor ops); this file holds the memory-bound ends:
 //   assemble_fwd : out[b,d,y,x,:] = F[...] + G[...]                 (writes the 32-channel V0 tensor once)
 //   assemble_bwd : dF, dG = the matching reductions of grad_out over d (reads it twice)
-// Depth class of plane d: c = (d >= 1) + 2 * (d <= D-2)  (which of kd = 0 / kd = 2 exist).
 #include "az_common.h"
 
-#define CC_NCLS 4
-#define CC_NDL 5   // delta variants: -2, -1, 0, 1, >= 2
-#define CC_CFB (CC_NCLS * 32)        // bulk maps (delta >= 2): full width
-#define CC_CFE (CC_NCLS * 4 * 32)    // edge maps (delta = -2..1): only columns x <= D exist (x = d + delta)
-#define CC_CG (CC_NCLS * 2 * 32)
-
-__device__ __forceinline__ int cc_class(int d, int D) { return (d >= 1 ? 1 : 0) + (d <= D - 2 ? 2 : 0); }
+#define CC_MAXCLS 3
+// Depth classes actually present: NC = min(D, 3).  D >= 3: 0 = first plane (kd in {1,2}), 1 = middle
+// ({0,1,2}), 2 = last ({0,1}); D = 2: 0 = first, 1 = last; D = 1: 0 = the only plane ({1}).
+// Channel counts of the maps: bulk NC*32 (delta >= 2, full width), edge NC*4*32 (delta = -2..1, columns
+// x <= D only, x = d + delta), G NC*2*32.
+__host__ __device__ __forceinline__ int cc_nclass(int D) { return D < 3 ? D : 3; }
+__device__ __forceinline__ int cc_class(int d, int D) {
+    return (D == 1 || d == 0) ? 0 : (d == D - 1 ? (D == 2 ? 1 : 2) : 1);
+}
 
 // one thread = 4 channels of one output voxel
 __global__ void __launch_bounds__(256)
@@ -41,12 +42,12 @@ costconv_assemble_fwd_kernel(float4 *__restrict__ out, const float4 *__restrict_
         const int delta = x - d;
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (delta >= -2) {
-            const int cls = cc_class(d, D);
+            const int cls = cc_class(d, D), nc8 = cc_nclass(D) * 8;  // float4 per 32 channels = 8
             const float4 f = (delta >= 2)
-                ? Fb[(((b * H + y) * W + x) * (CC_CFB / 4)) + cls * 8 + cq]
-                : Fe[(((b * H + y) * XE + x) * (CC_CFE / 4)) + (cls * 4 + (delta + 2)) * 8 + cq];  // x = d + delta < XE
+                ? Fb[(((b * H + y) * W + x) * nc8) + cls * 8 + cq]
+                : Fe[(((b * H + y) * XE + x) * (nc8 * 4)) + (cls * 4 + (delta + 2)) * 8 + cq];  // x = d + delta < XE
             const int xb = (x == W - 1) ? 1 : 0;
-            const float4 g = G[(((b * H + y) * (W + 2) + (delta + 2)) * (CC_CG / 4)) + (cls * 2 + xb) * 8 + cq];
+            const float4 g = G[(((b * H + y) * (W + 2) + (delta + 2)) * (nc8 * 2)) + (cls * 2 + xb) * 8 + cq];
             o = make_float4(f.x + g.x, f.y + g.y, f.z + g.z, f.w + g.w);
         }
         out[i] = o;
@@ -65,30 +66,32 @@ costconv_grad_f_kernel(float4 *__restrict__ dFb, float4 *__restrict__ dFe, const
         const long long b = v / H;
         const size_t plane = (size_t)H * W * 8;
         const float4 *g0 = gy + (size_t)b * D * plane + ((size_t)y * W + x) * 8 + cq;
-        float4 bulk[CC_NCLS];
+        const int nc = cc_nclass(D);
+        float4 bulk[CC_MAXCLS];
 #pragma unroll
-        for (int c = 0; c < CC_NCLS; ++c) bulk[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < CC_MAXCLS; ++c) bulk[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int dmax = min(D - 1, x - 2);
         for (int d = 0; d <= dmax; ++d) {
             const float4 g = g0[(size_t)d * plane];
             const int cls = cc_class(d, D);
 #pragma unroll
-            for (int c = 0; c < CC_NCLS; ++c)
+            for (int c = 0; c < CC_MAXCLS; ++c)
                 if (c == cls) { bulk[c].x += g.x; bulk[c].y += g.y; bulk[c].z += g.z; bulk[c].w += g.w; }
         }
-        float4 *ob = dFb + (((size_t)b * H + y) * W + x) * (CC_CFB / 4) + cq;
+        float4 *ob = dFb + (((size_t)b * H + y) * W + x) * (nc * 8) + cq;
 #pragma unroll
-        for (int c = 0; c < CC_NCLS; ++c) ob[c * 8] = bulk[c];
+        for (int c = 0; c < CC_MAXCLS; ++c)
+            if (c < nc) ob[c * 8] = bulk[c];
         if (x < XE) {
-            float4 *oe = dFe + (((size_t)b * H + y) * XE + x) * (CC_CFE / 4) + cq;
+            float4 *oe = dFe + (((size_t)b * H + y) * XE + x) * (nc * 32) + cq;
 #pragma unroll
-            for (int c = 0; c < CC_NCLS; ++c)
+            for (int c = 0; c < CC_MAXCLS; ++c)
 #pragma unroll
                 for (int dl = 0; dl < 4; ++dl) {  // delta = dl - 2 in {-2,-1,0,1}: plane d = x - delta
                     const int d = x - (dl - 2);
                     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (d >= 0 && d < D && cc_class(d, D) == c) g = g0[(size_t)d * plane];
-                    oe[(c * 4 + dl) * 8] = g;
+                    if (c < nc) oe[(c * 4 + dl) * 8] = g;
                 }
         }
     }
@@ -107,27 +110,30 @@ costconv_grad_g_kernel(float4 *__restrict__ dG, const float4 *__restrict__ gy, i
         const int u = t - 2;
         const size_t plane = (size_t)H * W * 8;
         const float4 *g0 = gy + (size_t)b * D * plane + (size_t)y * W * 8 + cq;
-        float4 acc[CC_NCLS][2];
+        const int nc = cc_nclass(D);
+        float4 acc[CC_MAXCLS][2];
 #pragma unroll
-        for (int c = 0; c < CC_NCLS; ++c) { acc[c][0] = make_float4(0.f, 0.f, 0.f, 0.f); acc[c][1] = acc[c][0]; }
+        for (int c = 0; c < CC_MAXCLS; ++c) { acc[c][0] = make_float4(0.f, 0.f, 0.f, 0.f); acc[c][1] = acc[c][0]; }
         const int d_lo = max(0, -u), d_hi = min(D - 1, W - 1 - u);  // 0 <= x = u + d <= W-1
         for (int d = d_lo; d <= d_hi; ++d) {
             const int x = u + d;
             const float4 g = g0[(size_t)d * plane + (size_t)x * 8];
             const int cls = cc_class(d, D), xb = (x == W - 1) ? 1 : 0;
 #pragma unroll
-            for (int c = 0; c < CC_NCLS; ++c)
+            for (int c = 0; c < CC_MAXCLS; ++c)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
                     if (c == cls && e == xb) { acc[c][e].x += g.x; acc[c][e].y += g.y; acc[c][e].z += g.z; acc[c][e].w += g.w; }
         }
-        float4 *o = dG + (((size_t)b * H + y) * (W + 2) + t) * (CC_CG / 4) + cq;
+        float4 *o = dG + (((size_t)b * H + y) * (W + 2) + t) * (nc * 16) + cq;
 #pragma unroll
-        for (int c = 0; c < CC_NCLS; ++c) { o[(c * 2 + 0) * 8] = acc[c][0]; o[(c * 2 + 1) * 8] = acc[c][1]; }
+        for (int c = 0; c < CC_MAXCLS; ++c)
+            if (c < nc) { o[(c * 2 + 0) * 8] = acc[c][0]; o[(c * 2 + 1) * 8] = acc[c][1]; }
     }
 }
 
 extern "C" int az_costconv_edge_width(int D, int W) { return D + 1 < W ? D + 1 : W; }
+extern "C" int az_costconv_num_classes(int D) { return D > 0 ? cc_nclass(D) : AZ_EINVAL; }
 
 extern "C" int az_costconv_assemble_fwd(float *out, const float *F_bulk, const float *F_edge, const float *G, int B,
                                         int D, int H, int W, void *stream) {

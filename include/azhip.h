@@ -271,13 +271,14 @@ int az_disp_metrics(double *acc8, const float *disp_gt, const float *depth_gt,
                     const unsigned char *mask, int B, long long per_batch, void *stream);
 
 /* ---- K3+K4 factored: dres0[0] applied to the concat cost volume without the volume -------------
- * (nets/psmnet/psmnet_3.py:149-166).  F = the left map convolved with the 4 x 5 depth-class /
- * staircase-offset variants of the depth-summed 3x3 kernels (bulk + edge maps, below); G: [B,H,W+2,256] = the right map (two zero
- * columns on the left) convolved with the 4 x 2 variants of the 3x5 kernels indexed by kw - kd
+ * (nets/psmnet/psmnet_3.py:149-166).  F = the left map convolved with the NC x 5 depth-class /
+ * staircase-offset variants of the depth-summed 3x3 kernels (bulk + edge maps, below); G: [B,H,W+2,NC*64] = the right map (two zero
+ * columns on the left) convolved with the NC x 2 variants of the 3x5 kernels indexed by kw - kd
  * (activezero_amd/costconv.py builds them).  out [B,D,H,W,32] = F[c(d), min(x-d,2)][y,x] + G[c(d), x=W-1][y,x-d]
  * for x - d >= -2, else 0.  The backward writes the matching reductions of grad_out over d. */
 int az_costconv_edge_width(int D, int W); /* XE = min(W, D+1): columns on which the delta < 2 maps exist */
-/* F_bulk [B,H,W,128] (x - d >= 2, per depth class), F_edge [B,H,XE,512] (x - d = -2..1), G [B,H,W+2,256] */
+int az_costconv_num_classes(int D);       /* NC = min(D, 3) depth classes: first / middle / last plane */
+/* F_bulk [B,H,W,NC*32] (x - d >= 2, per depth class), F_edge [B,H,XE,NC*128] (x - d = -2..1), G [B,H,W+2,NC*64] */
 int az_costconv_assemble_fwd(float *out, const float *F_bulk, const float *F_edge, const float *G, int B,
                              int D, int H, int W, void *stream);
 int az_costconv_assemble_bwd(float *dF_bulk, float *dF_edge, float *dG, const float *grad_out, int B, int D,
