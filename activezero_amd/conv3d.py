@@ -399,7 +399,7 @@ class _Lift2d(torch.autograd.Function):
 
 
 # AZ_FE2D_CH: channel counts of the 2-D layers routed to the 3-D kernels when AZ_FE2D=hip
-_FE2D_CH = tuple(int(c) for c in os.environ.get("AZ_FE2D_CH", "32,64").split(","))
+_FE2D_CH = tuple(int(c) for c in os.environ.get("AZ_FE2D_CH", "64").split(","))
 
 
 def supports_2d(conv):
@@ -445,7 +445,7 @@ class _Conv2dS1(torch.autograd.Function):
             pk = _pack(w3, cout, cin, 27, cin * 27, True)
             gx = _as_image(_run_gather(gv, pk, CONV_S1, cout, cin, tag="fe2d_dgrad"))
         if ctx.needs_input_grad[1]:
-            if os.environ.get("AZ_FE2D_WGRAD", "hip") == "miopen":
+            if os.environ.get("AZ_FE2D_WGRAD", "miopen") == "miopen":
                 gw = torch.ops.aten.convolution_backward(
                     gy, _as_image(xv), w3[:, :, 1], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                     [False, True, False])[1]

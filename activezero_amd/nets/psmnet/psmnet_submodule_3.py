@@ -26,7 +26,7 @@ from activezero_amd import bn2d, conv3d, ops
 # ONE batch of 2B, activezero_amd/bn2d.py); "miopen" = plain torch modules, two passes; "hip" = the
 # stride-1 3x3 layers on the 3-D gather kernels (experiment, slower).
 FE2D_BACKEND = os.environ.get("AZ_FE2D", "fused")
-FE2D_CONV = os.environ.get("AZ_FE2D_CONV", "miopen")
+FE2D_CONV = os.environ.get("AZ_FE2D_CONV", "hip")
 # inference experiments: "fold" = BatchNorm folded into the conv weights + bias (plain conv2d, cached);
 # "fused" = the same through MIOpen's conv+bias+ReLU fusion; "" (default) = the HIP BatchNorm apply pass.
 # Measured (eval forward): 256x512/D=64 4.35 ms -> 3.54 (fold) / 155 (fused); 540x960/D=192 12.7 ms ->
@@ -70,7 +70,9 @@ def _convbn_unit(x, unit, relu=False, residual=None):
             y = y + residual
         return F.relu_(y) if relu else y
     if FE2D_BACKEND != "miopen" and bn2d.supported(bn, x):
-        # AZ_FE2D_CONV=hip: the stride-1 3x3 32/64-channel layers on the bf16x6 gather kernels
+        # AZ_FE2D_CONV=hip (default): the stride-1 3x3 64-channel layers (layer2, a third of the extractor's
+        # FLOPs) run forward and input gradient on the bf16x6 gather kernel as depth-1 volumes; their weight
+        # gradient stays on MIOpen (AZ_FE2D_WGRAD).  AZ_FE2D_CONV=miopen: every convolution on MIOpen.
         y = conv3d.conv2d_s1(x, conv) if (FE2D_CONV == "hip" and conv3d.supports_2d(conv)) else conv(x)
         return bn2d.bn_act(y, bn, relu, residual, _STAT_GROUPS)
     if _STAT_GROUPS != 1:

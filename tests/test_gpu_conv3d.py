@@ -258,6 +258,7 @@ def test_conv2d_s1_matches_torch(ch, wgrad, monkeypatch):
     """The opt-in convolution-only 2-D route (AZ_FE2D_CONV=hip): conv2d forward, input and weight
     gradients against F.conv2d."""
     monkeypatch.setenv("AZ_FE2D_WGRAD", wgrad)
+    monkeypatch.setattr(conv3d, "_FE2D_CH", (32, 64))  # default routes the 64-channel layers only
     conv = torch.nn.Conv2d(ch, ch, 3, 1, 1, bias=False)
     with torch.no_grad():
         conv.weight.copy_(seeded((ch, ch, 3, 3), 71, -0.2, 0.2))
