@@ -146,23 +146,29 @@ def test_feature_extraction_pair_equals_two_sequential_passes():
             assert torch.equal(b, w), name  # num_batches_tracked: two updates per BatchNorm
 
 
-def test_inference_caches_follow_parameter_updates():
-    """Packed weights / folded BatchNorm maps are cached between no_grad forwards; an in-place
-    parameter update (optimizer step, load_state_dict) must invalidate them."""
-    md = 32
-    torch.manual_seed(5)
-    model = load_procedural(psm3.PSMNet(md), "g4.").to(DEV).eval()
-    il, ir = (seeded((1, 3, 256, 256), 900 + i, -2.0, 2.0).to(DEV) for i in range(2))
+def test_inference_caches_follow_parameter_updates(golden):
+    """Packed weights / folded BatchNorm maps / merged cost-volume kernels are cached between no_grad
+    forwards; an in-place parameter update (optimizer step, load_state_dict) must invalidate them.
+    (The calibrated golden model: a well-conditioned eval network, so tolerances mean something.)"""
+    g = golden("g4_psmnet3")
+    md = int(g["maxdisp"])
+    model = load_bn_buffers(load_procedural(psm3.PSMNet(md), "g4."), g).to(DEV).eval()
+    il, ir = (seeded((2, 3, 256, 256), 400 + i, -2.0, 2.0).to(DEV) for i in range(2))
     with torch.no_grad():
         out1 = model(il, ir).clone()
-        assert torch.equal(model(il, ir), out1)          # cached second pass: identical
-        model.dres0[0][0].weight.mul_(1.25)              # conv weight (packed-weight cache)
-        model.dres1[2][1].running_var.mul_(1.5)          # BatchNorm3d buffer (affine cache)
-        model.feature_extraction.layer1[0].conv1[0][1].bias.add_(0.1)   # BatchNorm2d parameter
+        # cached second pass: the same result (not bit-compared: MIOpen may settle on another
+        # algorithm for the extractor's convolutions between its first and second call)
+        assert torch.allclose(model(il, ir), out1, rtol=0, atol=1e-4)
+        model.dres0[0][0].weight.mul_(1.05)              # Conv3d weight (merged cost-volume kernels)
+        model.dres0[2][0].weight.mul_(1.05)              # Conv3d weight (packed-weight cache)
+        model.dres1[2][1].running_var.mul_(1.2)          # BatchNorm3d buffer (affine cache)
+        model.feature_extraction.layer1[0].conv1[0][1].bias.add_(0.05)   # BatchNorm2d parameter
         out2 = model(il, ir).clone()
     fresh = psm3.PSMNet(md).to(DEV).eval()
     fresh.load_state_dict(model.state_dict())
     with torch.no_grad():
         out3 = fresh(il, ir)
-    assert not torch.allclose(out1, out2)
-    assert torch.allclose(out2, out3, rtol=0, atol=1e-5), float((out2 - out3).abs().max())
+    # stale caches would leave out2 at out1; a fresh module agrees with out2 to the usual parity bar
+    d12, d23 = float((out1 - out2).abs().max()), float((out2 - out3).abs().max())
+    assert d23 < 1e-3, d23
+    assert d12 > 1e-2 and d12 > 10 * d23, (d12, d23)
