@@ -61,6 +61,13 @@ _SIGS = {
     "az_bn3d_bwd_workspace": [_LL, _INT],
     "az_bn3d_bwd": [_PTR] * 6 + [_LL] + [_PTR] * 8 + [_INT, _LL, _INT, _PTR],
     "az_add_relu": [_PTR] * 3 + [_INT, _LL, _PTR],
+    "az_conv2d_packed_floats": [_INT] * 4,
+    "az_conv2d_pack_weights": [_PTR, _PTR] + [_INT] * 4 + [_LL, _LL] + [_INT] * 3 + [_PTR],
+    "az_conv2d_fwd": [_PTR] * 6 + [_INT] * 12 + [_PTR],
+    "az_conv2d_wgrad_workspace": [_INT] * 4,
+    "az_conv2d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 12 + [_PTR],
+    "az_im2col_s2k3": [_PTR, _PTR] + [_INT] * 5 + [_PTR],
+    "az_col2im_s2k3": [_PTR, _PTR] + [_INT] * 5 + [_PTR],
     "az_corr1d_volume": [_PTR] * 3 + [_INT] * 5 + [_PTR],
     "az_corr1d_volume_bwd": [_PTR] * 5 + [_INT] * 5 + [_PTR],
     "az_corr1d_pool": [_PTR, _PTR, _LL, _INT, _PTR],
@@ -70,7 +77,8 @@ _SIGS = {
 }
 _RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_packed_floats": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL,
-            "az_bn3d_stats_tiles": _LL, "az_bn2d_workspace": _LL}
+            "az_bn3d_stats_tiles": _LL, "az_bn2d_workspace": _LL,
+            "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL}
 
 
 def declared_symbols():

@@ -28,7 +28,7 @@ def _rows(t):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu, groups):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, groups, cache):
         n, c, h, w = x.shape
         if n % groups:
             raise RuntimeError("batch must divide into the statistic groups")
@@ -43,9 +43,10 @@ class _BNAct(torch.autograd.Function):
         with torch.cuda.device(x.device):
             if not training:  # running statistics: one affine map for the whole batch
                 from .conv3d import eval_affine
-                scale, shift = eval_affine(bn, xr)
+                scale, shift = eval_affine(bn, xr, cache=cache)
                 _call("az_bn3d_apply", _p(yr), _p(xr), _p(scale), _p(shift), _p(rr), int(relu), nvox * groups, c,
                       _stream())
+                ctx.save_for_backward(xr, yr if relu else None, gamma, scale, bn.running_mean.clone())
                 ctx.cfg = (False, relu, residual is not None, groups, (n, c, h, w))
                 return yr.permute(0, 3, 1, 2)
             ws_bytes = lib.az_bn2d_workspace(groups, nvox, c)
@@ -68,11 +69,19 @@ class _BNAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         training, relu, has_res, groups, (n, c, h, w) = ctx.cfg
-        if not training:
-            raise NotImplementedError("eval-mode BatchNorm backward is not implemented on the HIP path; "
-                                      "run validation under torch.no_grad() as the reference does")
-        xr, yr, gamma, stats = ctx.saved_tensors
         gr = _chk(_rows(gy), "grad_y")
+        if not training:
+            # frozen statistics (fine-tuning in eval mode): y = relu?(x*s + t + res), s = gamma*rinv,
+            # t = beta - running_mean*s.  A rarely used path: plain tensor ops.
+            xr, yr, gamma, scale, rm = ctx.saved_tensors
+            dz = gr * (yr > 0).to(gr.dtype) if relu else gr
+            g_ = gamma.detach()
+            rinv = torch.where(g_ != 0, scale / g_, torch.zeros_like(scale))
+            dgamma = (dz * (xr - rm)).sum(dim=(0, 1, 2)) * rinv
+            dbeta = dz.sum(dim=(0, 1, 2))
+            g_res = dz.permute(0, 3, 1, 2) if has_res else None
+            return (dz * scale).permute(0, 3, 1, 2), dgamma, dbeta, g_res, None, None, None, None
+        xr, yr, gamma, stats = ctx.saved_tensors
         nvox = (n // groups) * h * w
         lib = _lib.lib()
         dxr = torch.empty_like(xr)
@@ -89,9 +98,9 @@ class _BNAct(torch.autograd.Function):
         g_res = None
         if has_res:
             g_res = (dzr if relu else gr).permute(0, 3, 1, 2)
-        return dxr.permute(0, 3, 1, 2), dgb[0], dgb[1], g_res, None, None, None
+        return dxr.permute(0, 3, 1, 2), dgb[0], dgb[1], g_res, None, None, None, None
 
 
 def bn_act(x, bn, relu=False, residual=None, groups=1):
     """relu?(BatchNorm2d(x) + residual), x [N,C,H,W] (channels_last preferred), statistics per batch group."""
-    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu, groups)
+    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu, groups, not torch.is_grad_enabled())

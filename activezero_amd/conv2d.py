@@ -1,0 +1,235 @@
+"""Autograd wrappers of the 2-D convolution family (include/azhip.h K13): every Conv2d of the feature
+extractor (reference nets/psmnet/psmnet_submodule_3.py:13-41, 92-220) and the 2-D convolutions of the
+factored cost-volume convolution (costconv.py) on hand-written gfx950 kernels -- forward, input gradient
+and weight gradient.  There is no vendor-library path and no fallback: an unsupported geometry raises.
+
+Tensors are NCHW-shaped in torch.channels_last memory, i.e. contiguous [B,H,W,C] rows; weights stay in
+PyTorch's [Cout,Cin,KH,KW] layout (reference checkpoints load unchanged), the kernels read a packed bf16
+triplet image made per call (memoised between no_grad forwards).
+
+    layer geometry                         forward                     input gradient            weight gradient
+    3x3 / 1x1 / 3x5, stride 1, "same"      az_conv2d_fwd               az_conv2d_fwd, flipped    az_conv2d_wgrad
+    3x3 stride 2, 32/64 channels           3-D gather kernel, mode 1   mode 2 (transposed)       3-D wgrad kernel, stride 2
+       (layer2.0.conv1; the image is a depth-1 volume)
+    3x3 stride 2 on a 3/6-channel image    az_im2col_s2k3 + 1x1        1x1 flipped + az_col2im   1x1 wgrad on the patches
+       (firstconv.0)
+    1x1 stride 2 (layer2.0.downsample)     subsample + 1x1             (autograd of the slice)   1x1 wgrad
+"""
+import torch
+
+from . import _lib, conv3d, profiler
+from .conv3d import _cache_get, _cache_key, _cache_put
+from .ops import _call, _chk, _p, _stream
+
+_SAME = {(3, 3, 1), (3, 3, 2), (1, 1, 1), (3, 5, 1)}
+_PACK2D_CACHE = {}
+PEAK_X6 = (2500.0 / 6.0, "bf16x6: bf16 MFMA peak / 6")
+
+
+def rows(t):
+    """[N,C,H,W] (channels_last memory) -> the same storage as contiguous [N,H,W,C] (a copy otherwise)."""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def image(r):
+    """[N,H,W,C] rows -> [N,C,H,W] view in channels_last memory."""
+    return r.permute(0, 3, 1, 2)
+
+
+def _pack(weight, cin, cout, ci_real, co_real, s_out, s_in, kh, kw, flip, cache=False):
+    w = _chk(weight.detach().contiguous(), "weight")
+    key = None
+    if cache:
+        key = (_cache_key(weight), cin, cout, ci_real, co_real, s_out, s_in, kh, kw, bool(flip))
+        hit = _cache_get(_PACK2D_CACHE, key)
+        if hit is not None:
+            return hit[0]
+    n = _lib.lib().az_conv2d_packed_floats(cin, cout, kh, kw)
+    if n < 0:
+        raise RuntimeError(f"conv2d: unsupported channel counts cin={cin} cout={cout}")
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    _call("az_conv2d_pack_weights", _p(packed), _p(w), cin, cout, ci_real, co_real, s_out, s_in, kh, kw,
+          int(flip), _stream())
+    if key is not None:
+        _cache_put(_PACK2D_CACHE, key, (packed, weight), 256)
+    return packed
+
+
+def _up(n, m):
+    return (n + m - 1) // m * m
+
+
+def _run(xr, packed, cin, cout, kh, kw, dil, scale=None, shift=None, res=None, relu=False, tag="conv2d"):
+    """xr: [B,H,W,Cx] rows with Cx >= cin; returns [B,H,W,cout] rows."""
+    b, h, w, cx = xr.shape
+    out = xr.new_empty(b, h, w, cout)
+    with profiler.scope(f"{tag}_{kh}x{kw}d{dil}_{cin}_{cout}", flops=2.0 * kh * kw * cin * cout * b * h * w,
+                        peak=PEAK_X6):
+        _call("az_conv2d_fwd", _p(out), _p(xr), _p(packed), _p(scale), _p(shift), _p(res), int(relu), b, h, w,
+              cin, cout, cx, cout, res.shape[-1] if res is not None else 0, kh, kw, dil, _stream())
+    return out
+
+
+def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d"):
+    """gr: [B,H,W,>=cm] grad rows, xr: [B,H,W,>=cn] input rows -> [cm_real, cn_real, kh, kw]."""
+    b, h, w, _ = xr.shape
+    gw = xr.new_empty(cm_real, cn_real, kh, kw)
+    ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cm, cn, kh, kw)
+    if ws_bytes < 0:
+        raise RuntimeError(f"conv2d wgrad: unsupported channel counts {cm} x {cn}")
+    ws = xr.new_empty(ws_bytes // 4)
+    with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
+                        peak=PEAK_X6):
+        _call("az_conv2d_wgrad", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w, cm, cn, cm_real, cn_real,
+              gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
+    return gw
+
+
+class _ConvSame(torch.autograd.Function):
+    """conv2d(x, w, stride 1, "same" padding, dilation) for the geometries of _SAME."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dil):
+        cout, cin, kh, kw = weight.shape
+        xr = _chk(rows(x), "x")
+        with torch.cuda.device(x.device):
+            pk = _pack(weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False)
+            y = _run(xr, pk, cin, cout, kh, kw, dil)
+        ctx.save_for_backward(xr, weight)
+        ctx.dil = dil
+        return image(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, weight = ctx.saved_tensors
+        cout, cin, kh, kw = weight.shape
+        dil = ctx.dil
+        gr = _chk(rows(gy), "grad_y")
+        gx = gw = None
+        with torch.cuda.device(gy.device):
+            if ctx.needs_input_grad[0]:  # the same convolution, taps flipped, channel roles swapped
+                pk = _pack(weight, cout, cin, cout, cin, kh * kw, cin * kh * kw, kh, kw, True)
+                gx = image(_run(gr, pk, cout, cin, kh, kw, dil, tag="dgrad2d"))
+            if ctx.needs_input_grad[1]:
+                gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil)
+        return gx, gw, None
+
+
+def conv_same(x, weight, dilation=1):
+    """F.conv2d(x, weight, padding="same", dilation=dilation) for [B,C,H,W] x (channels_last preferred)."""
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw, dilation if kh > 1 else 1) not in _SAME or cin % 32 or cout % 32:
+        raise RuntimeError(f"conv_same: unsupported geometry {tuple(weight.shape)}, dilation {dilation}")
+    return _ConvSame.apply(x, weight, 1 if kh == 1 else dilation)
+
+
+class _ConvS2Vol(torch.autograd.Function):
+    """3x3, stride 2, pad 1 with 32/64 channels (layer2.0.conv1): the image as a depth-1 volume on the 3-D
+    gather kernels -- forward = stride-2 mode, input gradient = transposed mode (its second output
+    plane, the kd = 2 taps, is discarded), weight gradient = the stride-2 3-D wgrad kernel's centre slice."""
+
+    @staticmethod
+    def forward(ctx, x, weight, arith):
+        cout, cin = weight.shape[:2]
+        xv = _chk(rows(x).unsqueeze(1), "x")
+        w3 = weight.detach().new_zeros(cout, cin, 3, 3, 3)
+        w3[:, :, 1] = weight.detach()
+        with torch.cuda.device(x.device):
+            pk, _, _ = conv3d._pack_forward(w3, conv3d.CONV_S2, arith.conv)
+            y = conv3d._run_gather(xv, pk, conv3d.CONV_S2, cin, cout, arith.conv, tag="fe2d_s2")
+        ctx.save_for_backward(xv, w3)
+        ctx.arith = arith
+        return image(y.squeeze(1))
+
+    @staticmethod
+    def backward(ctx, gy):
+        xv, w3 = ctx.saved_tensors
+        cout, cin = w3.shape[:2]
+        arith = ctx.arith
+        gv = _chk(rows(gy).unsqueeze(1), "grad_y")
+        gx = gw = None
+        with torch.cuda.device(gy.device):
+            if ctx.needs_input_grad[0]:
+                g2 = conv3d._input_grad(gv, w3, conv3d.CONV_S2, cin, cout, arith.conv)  # [B,2,H,W,cin]
+                gx = image(g2[:, 0, :xv.shape[2], :xv.shape[3]])
+            if ctx.needs_input_grad[1]:
+                gw = conv3d._weight_grad(xv, gv, conv3d.CONV_S2, cin, cout, arith.wgrad)[:, :, 1].contiguous()
+        return gx, gw, None
+
+
+class _ConvS2Patches(torch.autograd.Function):
+    """3x3, stride 2, pad 1 on a thin image (C = 3 or 6 -> 32): patch extraction + 1x1 convolution."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        cout, cin = weight.shape[:2]
+        xr = _chk(rows(x), "x")
+        b, h, w, _ = xr.shape
+        kp = _up(9 * cin, 32)
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        patches = xr.new_empty(b, ho, wo, kp)
+        # [cout, cin, 3, 3] -> [cout, (tap, cin)] as the patches are laid out
+        w2 = weight.detach().permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+        with torch.cuda.device(x.device):
+            _call("az_im2col_s2k3", _p(patches), _p(xr), b, cin, h, w, kp, _stream())
+            pk = _pack(w2, kp, cout, 9 * cin, cout, 9 * cin, 1, 1, 1, False)
+            y = _run(patches, pk, kp, cout, 1, 1, 1, tag="fe2d_first")
+        ctx.save_for_backward(patches, w2)
+        ctx.dims = (b, cin, h, w, kp)
+        return image(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        patches, w2 = ctx.saved_tensors
+        b, cin, h, w, kp = ctx.dims
+        cout = w2.shape[0]
+        gr = _chk(rows(gy), "grad_y")
+        gx = gw = None
+        with torch.cuda.device(gy.device):
+            if ctx.needs_input_grad[0]:
+                pk = _pack(w2, cout, kp, cout, 9 * cin, 1, 9 * cin, 1, 1, True)
+                gp = _run(gr, pk, cout, kp, 1, 1, 1, tag="dgrad2d_first")
+                gxr = gr.new_empty(b, h, w, cin)
+                _call("az_col2im_s2k3", _p(gxr), _p(gp), b, cin, h, w, kp, _stream())
+                gx = image(gxr)
+            if ctx.needs_input_grad[1]:
+                g2 = _wgrad(gr, patches, cout, kp, cout, 9 * cin, 1, 1, 1, tag="fe2d_first")  # [cout, 9cin,1,1]
+                gw = g2.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+        return gx, gw
+
+
+def conv(x, m, arith=None):
+    """m(x) for an nn.Conv2d of the extractor (bias-free, groups 1), differentiable, on the HIP kernels."""
+    arith = conv3d._arith(arith)
+    if not isinstance(m, torch.nn.Conv2d) or m.bias is not None or m.groups != 1:
+        raise RuntimeError("conv2d.conv: expects a bias-free nn.Conv2d")
+    k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
+    cin, cout = m.in_channels, m.out_channels
+    if s == (1, 1) and k[0] == k[1] and p[0] == p[1] == d[0] * (k[0] - 1) // 2 and d[0] == d[1]:
+        return conv_same(x, m.weight, d[0])
+    if s == (2, 2) and k == (3, 3) and p == (1, 1) and d == (1, 1):
+        if cin in (32, 64) and cout in (32, 64) and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
+            return _ConvS2Vol.apply(x, m.weight, arith)
+        if 9 * cin <= 64 and cout % 32 == 0:
+            return _ConvS2Patches.apply(x, m.weight)
+    if s == (2, 2) and k == (1, 1) and p == (0, 0):
+        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), m.weight, 1)
+    raise RuntimeError(f"conv2d.conv: unsupported layer {m}")
+
+
+def conv_bn_eval(x, m, bn, relu=False, residual=None):
+    """Inference: relu?(BatchNorm2d(conv(x)) + residual) with the running-statistics affine map, the
+    residual sum and the ReLU folded into the convolution's epilogue (one pass, no normalisation
+    kernel).  Only for the stride-1 geometries; returns None when the layer needs the generic route."""
+    k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
+    cin, cout = m.in_channels, m.out_channels
+    if not (s == (1, 1) and k[0] == k[1] and p[0] == p[1] == d[0] * (k[0] - 1) // 2 and cin % 32 == 0
+            and cout % 32 == 0 and (k[0], k[1], d[0] if k[0] > 1 else 1) in _SAME):
+        return None
+    kh, kw = k
+    xr = _chk(rows(x), "x")
+    rr = _chk(rows(residual), "residual") if residual is not None else None
+    with torch.cuda.device(x.device):
+        pk = _pack(m.weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False, cache=True)
+        scale, shift = conv3d.eval_affine(bn, xr, cache=True)
+        return image(_run(xr, pk, cin, cout, kh, kw, d[0] if kh > 1 else 1, scale, shift, rr, relu, tag="conv2d_eval"))

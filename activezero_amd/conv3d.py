@@ -13,7 +13,9 @@ conv, stride-2 conv, stride-2 transposed conv) with differently packed weights:
     Conv3d stride 2       mode 1       mode 2, swapped           wgrad(dy, x, 2)
     ConvTranspose3d s2    mode 2       mode 1, as stored         wgrad(x, dy, 2)
 """
+import collections
 import os
+import threading
 
 import torch
 
@@ -22,21 +24,37 @@ from .ops import _call, _chk, _p, _stream
 
 CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
 FP32, BF16X6 = 0, 1
-# arithmetic of the gather kernels (forward, input gradients, transposed convs):
-#   fp32   -- v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chain (157 TFLOP/s peak)
-#   bf16x6 -- exact 3-way bf16 split of both operands, six bf16 MFMAs per product, fp32
-#             accumulate: fp32-class accuracy (measured ~1e-7 relative) at 2.7x the rate
-PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[os.environ.get("AZ_CONV_PRECISION", "bf16x6")]
+_PREC = {"fp32": FP32, "bf16x6": BF16X6}
 
 
-WGRAD_PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[os.environ.get("AZ_WGRAD_PRECISION", "bf16x6")]
+class Arith(collections.namedtuple("Arith", "conv wgrad")):
+    """Arithmetic of the MFMA kernels, passed with every call (no process-wide switch):
+      fp32   -- v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chain (157 TFLOP/s peak)
+      bf16x6 -- exact 3-way bf16 split of both operands, six bf16 MFMAs per product, fp32
+                accumulate: fp32-class accuracy (measured ~1e-7 relative) at 2.7x the rate
+    `conv` covers forward / input-gradient / transposed kernels, `wgrad` the weight gradients."""
+    __slots__ = ()
+
+    @classmethod
+    def of(cls, conv="bf16x6", wgrad=None):
+        return cls(_PREC[conv], _PREC[wgrad if wgrad is not None else conv])
+
+    @property
+    def names(self):
+        inv = {v: k for k, v in _PREC.items()}
+        return inv[self.conv], inv[self.wgrad]
 
 
-def set_precision(name, wgrad=None):
-    global PRECISION, WGRAD_PRECISION
-    PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[name]
-    if wgrad is not None:
-        WGRAD_PRECISION = {"fp32": FP32, "bf16x6": BF16X6}[wgrad]
+# the default is read ONCE from the environment and never mutated afterwards
+DEFAULT_ARITH = Arith.of(os.environ.get("AZ_CONV_PRECISION", "bf16x6"), os.environ.get("AZ_WGRAD_PRECISION"))
+
+
+def _arith(a):
+    if a is None:
+        return DEFAULT_ARITH
+    if isinstance(a, str):
+        return Arith.of(a)
+    return a
 
 
 def _dims(x):
@@ -52,68 +70,77 @@ def _out_dims(mode, d, h, w):
     return 2 * d, 2 * h, 2 * w
 
 
-# Inference-time caches (used only while autograd is off): packed weights and folded BatchNorm
-# affine maps are functions of parameters that do not change between forward passes.  Entries
-# are keyed on the tensors' storage address AND version counter, so an optimizer step or a
-# load_state_dict (both write in place) invalidates them; each entry also holds its source tensors,
-# so their addresses cannot be recycled for other data while the entry lives.
+# Inference-time memo of packed weights and folded BatchNorm affine maps (pure functions of parameters
+# that do not change between no_grad forwards).  Whether a call may use it is decided by the CALLER
+# (`cache=` = "autograd is off at the call site", conv_bn / conv_plain), never inside an autograd
+# Function.  Keys hold the tensors' storage address AND version counter, so an optimizer step or a
+# load_state_dict (both write in place) invalidates them; a BatchNorm's key also holds
+# num_batches_tracked, because this library's own train kernels update running_mean / running_var
+# through raw pointers, which no version counter sees.  Each entry keeps its source tensors alive, so
+# their addresses cannot be recycled for other data.  A lock makes the dicts safe under the threads of
+# nn.DataParallel (train.py:540-541).
 _PACK_CACHE, _AFFINE_CACHE = {}, {}
+_CACHE_LOCK = threading.Lock()
 
 
 def _cache_key(*tensors):
-    return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors)
+    return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
 
 
-def _inference_mode():
-    """autograd off AND not inside a backward pass (autograd also switches grad mode off while it runs
-    Function.backward; caching there would only churn: the weights change every step)."""
-    return not torch.is_grad_enabled() and torch._C._current_graph_task_id() == -1
+def _cache_get(cache, key):
+    with _CACHE_LOCK:
+        return cache.get(key)
 
 
-def _pack(weight, op_cin, op_cout, stride_out, stride_in, flip):
+def _cache_put(cache, key, value, limit):
+    with _CACHE_LOCK:
+        if len(cache) > limit:
+            cache.clear()
+        cache[key] = value
+
+
+def _pack(weight, op_cin, op_cout, stride_out, stride_in, flip, precision, cache=False):
     w = _chk(weight.detach().contiguous(), "weight")
     key = None
-    if _inference_mode():
-        key = (_cache_key(weight), op_cin, op_cout, stride_out, stride_in, bool(flip), PRECISION)
-        hit = _PACK_CACHE.get(key)
+    if cache:
+        key = (_cache_key(weight), op_cin, op_cout, stride_out, stride_in, bool(flip), precision)
+        hit = _cache_get(_PACK_CACHE, key)
         if hit is not None:
             return hit[0]
-    n = _lib.lib().az_conv3d_packed_floats(op_cin, op_cout, PRECISION)
+    n = _lib.lib().az_conv3d_packed_floats(op_cin, op_cout, precision)
     packed = torch.empty(n, dtype=torch.float32, device=w.device)
     _call("az_conv3d_pack_weights", _p(packed), _p(w), op_cin, op_cout, stride_out, stride_in,
-          int(flip), PRECISION, _stream())
+          int(flip), precision, _stream())
     if key is not None:
-        if len(_PACK_CACHE) > 256:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (packed, weight)
+        _cache_put(_PACK_CACHE, key, (packed, weight), 256)
     return packed
 
 
-def eval_affine(bn, like):
+def eval_affine(bn, like, cache=False):
     """(scale, shift) of an eval-mode BatchNorm: gamma/sqrt(running_var+eps), beta - running_mean*scale."""
     c = bn.num_features
     key = None
-    if _inference_mode():
-        key = (_cache_key(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps))
-        hit = _AFFINE_CACHE.get(key)
+    if cache:
+        key = (_cache_key(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked),
+               float(bn.eps))
+        hit = _cache_get(_AFFINE_CACHE, key)
         if hit is not None:
             return hit[0], hit[1]
     scale, shift = like.new_empty(c), like.new_empty(c)
     _call("az_bn3d_eval_affine", _p(scale), _p(shift), _p(bn.weight.detach()), _p(bn.bias.detach()),
           _p(bn.running_mean), _p(bn.running_var), float(bn.eps), c, _stream())
     if key is not None:
-        if len(_AFFINE_CACHE) > 512:
-            _AFFINE_CACHE.clear()
-        _AFFINE_CACHE[key] = (scale, shift, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        _cache_put(_AFFINE_CACHE, key, (scale, shift, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                        bn.num_batches_tracked), 512)
     return scale, shift
 
 
-def _pack_forward(weight, mode):
+def _pack_forward(weight, mode, precision, cache=False):
     if mode == DECONV_S2:  # [Cin, Cout, 27]
         cin, cout = weight.shape[0], weight.shape[1]
-        return _pack(weight, cin, cout, 27, cout * 27, False), cin, cout
+        return _pack(weight, cin, cout, 27, cout * 27, False, precision, cache), cin, cout
     cout, cin = weight.shape[0], weight.shape[1]
-    return _pack(weight, cin, cout, cin * 27, 27, False), cin, cout
+    return _pack(weight, cin, cout, cin * 27, 27, False, precision, cache), cin, cout
 
 
 def _peak(precision):
@@ -138,7 +165,7 @@ class LazyCostVolume:
             raise RuntimeError("fused cost volume expects two [B,h,w,32] feature maps")
 
 
-def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=None, relu=False,
+def _run_gather(x, packed, mode, cin, cout, precision, scale=None, shift=None, residual=None, relu=False,
                 stats=False, tag="conv3d"):
     if isinstance(x, LazyCostVolume):
         if stats or mode != CONV_S1 or cin != 64:
@@ -147,68 +174,88 @@ def _run_gather(x, packed, mode, cin, cout, scale=None, shift=None, residual=Non
         d = x.ndisp
         out = x.fl.new_empty(b, d, h, w, cout)
         with profiler.scope(f"{tag}_costvol_m0_{cin}_{cout}", flops=_conv_flops(b, d * h * w, cin, cout, mode),
-                            peak=_peak(PRECISION)):
+                            peak=_peak(precision)):
             _call("az_conv3d_fwd", _p(out), _p(x.fl), _p(x.fr), _p(packed), _p(scale), _p(shift),
-                  _p(residual), int(relu), mode, 1, PRECISION, b, cin, cout, d, h, w, _stream())
+                  _p(residual), int(relu), mode, 1, precision, b, cin, cout, d, h, w, _stream())
         return out
     b, d, h, w, c = _dims(x)
     assert c == cin, (c, cin)
-    if mode == CONV_S2 and (d % 2 or h % 2 or w % 2):
-        raise RuntimeError("stride-2 layers need even D/H/W (as PSMNet's hourglass does)")
+    if mode == CONV_S2 and ((d % 2 and d != 1) or h % 2 or w % 2):
+        raise RuntimeError("stride-2 layers need even D/H/W (as PSMNet's hourglass does; D = 1: a 2-D layer)")
     do, ho, wo = _out_dims(mode, d, h, w)
     out = x.new_empty(b, do, ho, wo, cout)
     flops = _conv_flops(b, do * ho * wo, cin, cout, mode)
-    if d == 1 and mode == CONV_S1:
-        flops /= 3.0  # a depth-1 volume (2-D layer): only the 9 taps of the centre depth slice exist
     name = f"{tag}_m{mode}_{cin}_{cout}"
     if stats:
         ntiles = _lib.lib().az_conv3d_num_tiles(mode, b, d, h, w)
         part = x.new_empty(cout, ntiles, 2)
         cnt = x.new_empty(ntiles)
-        with profiler.scope(name, flops=flops, peak=_peak(PRECISION)):
+        with profiler.scope(name, flops=flops, peak=_peak(precision)):
             _call("az_conv3d_fwd_stats", _p(out), _p(part), _p(cnt), _p(x), None, _p(packed), mode, 0,
-                  PRECISION, b, cin, cout, d, h, w, _stream())
+                  precision, b, cin, cout, d, h, w, _stream())
         return out, part, cnt, ntiles
-    with profiler.scope(name, flops=flops, peak=_peak(PRECISION)):
+    with profiler.scope(name, flops=flops, peak=_peak(precision)):
         _call("az_conv3d_fwd", _p(out), _p(x), None, _p(packed), _p(scale), _p(shift), _p(residual),
-              int(relu), mode, 0, PRECISION, b, cin, cout, d, h, w, _stream())
+              int(relu), mode, 0, precision, b, cin, cout, d, h, w, _stream())
     return out
 
 
-def _wgrad(coarse, fine, stride, cm, cn, tag):
+def _wgrad(coarse, fine, stride, cm, cn, tag, precision):
     b, dc, hc, wc, _ = _dims(coarse)
     _, df, hf, wf, _ = _dims(fine)
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
     ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
     ws = coarse.new_empty(ws_bytes // 4)
-    taps = 9 if (dc == 1 and df == 1) else 27  # depth-1 volumes: the 2-D layers
-    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * taps * cm * cn * b * dc * hc * wc,
-                        peak=_peak(WGRAD_PRECISION)):
-        _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, WGRAD_PRECISION,
+    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
+                        peak=_peak(precision)):
+        _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, precision,
               b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
     return gw
+
+
+def _input_grad(dy, weight, mode, cin, cout, precision):
+    """gradient of the layer's input from the gradient dy of its (raw) convolution output"""
+    if mode == CONV_S1:    # flipped taps, channels swapped
+        pk = _pack(weight, cout, cin, 27, cin * 27, True, precision)
+        return _run_gather(dy, pk, CONV_S1, cout, cin, precision, tag="dgrad")
+    if mode == CONV_S2:    # transposed conv of dy with W[co][ci][k]
+        pk = _pack(weight, cout, cin, 27, cin * 27, False, precision)
+        return _run_gather(dy, pk, DECONV_S2, cout, cin, precision, tag="dgrad")
+    pk = _pack(weight, cout, cin, cout * 27, 27, False, precision)  # stride-2 conv of dy with Wt[ci][co][k]
+    return _run_gather(dy, pk, CONV_S2, cout, cin, precision, tag="dgrad")
+
+
+def _weight_grad(x, dy, mode, cin, cout, precision):
+    if mode == DECONV_S2:
+        return _wgrad(x, dy, 2, cin, cout, "deconv", precision)
+    return _wgrad(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", precision)
 
 
 class _ConvBN(torch.autograd.Function):
     """y = relu?( BN(conv(x, weight)) + residual ), one autograd node per convbn_3d unit."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, want_grad):
+    def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, arith):
         x = _chk(x, "x")  # (LazyCostVolume never reaches autograd: see conv_bn)
         if residual is not None:
             residual = _chk(residual, "residual")
         training = bn.training or not bn.track_running_stats
         eps = float(bn.eps)
         with torch.cuda.device(x.device):
-            packed, cin, cout = _pack_forward(weight, mode)
+            packed, cin, cout = _pack_forward(weight, mode, arith.conv)
             if not training:
+                # eval-mode BatchNorm under autograd (fine-tuning with frozen statistics): the same
+                # kernels, with the running-statistics affine map; backward below
                 scale, shift = eval_affine(bn, x)
-                if want_grad and any(ctx.needs_input_grad):
-                    raise NotImplementedError(
-                        "eval-mode BatchNorm backward is not implemented on the HIP path; "
-                        "run validation under torch.no_grad() as the reference does")
-                return _run_gather(x, packed, mode, cin, cout, scale, shift, residual, relu)
-            raw, part, cnt, ntiles = _run_gather(x, packed, mode, cin, cout, stats=True)
+                raw = _run_gather(x, packed, mode, cin, cout, arith.conv)
+                y = torch.empty_like(raw)
+                _call("az_bn3d_apply", _p(y), _p(raw), _p(scale), _p(shift), _p(residual), int(relu),
+                      raw.numel() // cout, cout, _stream())
+                ctx.save_for_backward(x, weight, gamma, raw, y if relu else None, bn.running_mean.clone(),
+                                      scale, None, None)
+                ctx.cfg = (mode, relu, residual is not None, cin, cout, arith, False)
+                return y
+            raw, part, cnt, ntiles = _run_gather(x, packed, mode, cin, cout, arith.conv, stats=True)
             scale, shift = x.new_empty(cout), x.new_empty(cout)
             mean, invstd = x.new_empty(cout), x.new_empty(cout)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -229,57 +276,67 @@ class _ConvBN(torch.autograd.Function):
         remask = relu and residual is None
         ctx.save_for_backward(x, weight, gamma, raw, y if (relu and not remask) else None, mean, invstd,
                               scale if remask else None, shift if remask else None)
-        ctx.cfg = (mode, relu, residual is not None, cin, cout)
+        ctx.cfg = (mode, relu, residual is not None, cin, cout, arith, True)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, gamma, raw, y, mean, invstd, scale, shift = ctx.saved_tensors
-        mode, relu, has_res, cin, cout = ctx.cfg
+        mode, relu, has_res, cin, cout, arith, training = ctx.cfg
         gy = _chk(gy.contiguous(), "grad_y")
         nvox = raw.numel() // cout
         with torch.cuda.device(gy.device):
-            lib = _lib.lib()
-            dx_raw = torch.empty_like(raw)
-            dz = torch.empty_like(raw) if (has_res and relu) else None
-            dgamma, dbeta = gy.new_empty(cout), gy.new_empty(cout)
-            coef = gy.new_empty(cout, 3)
-            ws_bytes = lib.az_bn3d_bwd_workspace(nvox, cout)
-            ws = gy.new_empty(ws_bytes // 4)
-            with profiler.scope(f"bn3d_bwd_{cout}", bytes=4.0 * raw.numel() * (7 if (relu and y is not None) else 5), bound="hbm"):
-                _call("az_bn3d_bwd", _p(dx_raw), _p(dz), _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes,
-                      _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), _p(scale), _p(shift),
-                      int(relu), nvox, cout, _stream())
-            g_res = (dz if relu else gy) if has_res else None
+            if not training:
+                # y = relu?(raw * s + t + res) with s = gamma * rinv, t = beta - running_mean * s (constants
+                # of the running statistics): dz = gy * [y > 0]; d raw = dz * s; d gamma = sum dz (raw - rm) rinv;
+                # d beta = sum dz.  A rarely used path (frozen-BN fine-tuning): plain tensor ops.
+                s_, rm = invstd, mean  # saved slots: (running_mean copy, scale)
+                dz = gy * (y > 0).to(gy.dtype) if relu else gy
+                dbeta = dz.sum(dim=(0, 1, 2, 3))
+                rinv = torch.where(gamma.detach() != 0, s_ / gamma.detach(), torch.zeros_like(s_))
+                dgamma = (dz * (raw - rm)).sum(dim=(0, 1, 2, 3)) * rinv
+                dx_raw = (dz * s_).contiguous()
+                g_res = dz if has_res else None
+            else:
+                lib = _lib.lib()
+                dx_raw = torch.empty_like(raw)
+                dz = torch.empty_like(raw) if (has_res and relu) else None
+                dgamma, dbeta = gy.new_empty(cout), gy.new_empty(cout)
+                coef = gy.new_empty(cout, 3)
+                ws_bytes = lib.az_bn3d_bwd_workspace(nvox, cout)
+                ws = gy.new_empty(ws_bytes // 4)
+                with profiler.scope(f"bn3d_bwd_{cout}", bytes=4.0 * raw.numel() * (7 if (relu and y is not None) else 5), bound="hbm"):
+                    _call("az_bn3d_bwd", _p(dx_raw), _p(dz), _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes,
+                          _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), _p(scale), _p(shift),
+                          int(relu), nvox, cout, _stream())
+                g_res = (dz if relu else gy) if has_res else None
             gx = gw = None
             if ctx.needs_input_grad[0]:
-                if mode == CONV_S1:    # flipped taps, channels swapped
-                    pk = _pack(weight, cout, cin, 27, cin * 27, True)
-                    gx = _run_gather(dx_raw, pk, CONV_S1, cout, cin, tag="dgrad")
-                elif mode == CONV_S2:  # transposed conv of dy with W[co][ci][k]
-                    pk = _pack(weight, cout, cin, 27, cin * 27, False)
-                    gx = _run_gather(dx_raw, pk, DECONV_S2, cout, cin, tag="dgrad")
-                else:                  # stride-2 conv of dy with Wt[ci][co][k]
-                    pk = _pack(weight, cout, cin, cout * 27, 27, False)
-                    gx = _run_gather(dx_raw, pk, CONV_S2, cout, cin, tag="dgrad")
+                gx = _input_grad(dx_raw, weight, mode, cin, cout, arith.conv)
             if ctx.needs_input_grad[1]:
-                if mode == DECONV_S2:
-                    gw = _wgrad(x, dx_raw, 2, cin, cout, "deconv")
-                else:
-                    gw = _wgrad(dx_raw, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv")
+                gw = _weight_grad(x, dx_raw, mode, cin, cout, arith.wgrad)
         return gx, gw, dgamma, dbeta, g_res, None, None, None, None
 
 
-def conv_bn(x, conv, bn, mode, relu=False, residual=None):
+def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None):
+    arith = _arith(arith)
     if isinstance(x, LazyCostVolume):  # inference: BN folded, operand synthesised in-kernel
         if torch.is_grad_enabled() or bn.training:
             raise RuntimeError("LazyCostVolume is an inference-only operand")
         with torch.cuda.device(x.fl.device):
-            packed, cin, cout = _pack_forward(conv.weight, mode)
-            scale, shift = eval_affine(bn, x.fl)
-            return _run_gather(x, packed, mode, cin, cout, scale, shift, residual, relu)
-    return _ConvBN.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, mode, relu,
-                         torch.is_grad_enabled())
+            packed, cin, cout = _pack_forward(conv.weight, mode, arith.conv, cache=True)
+            scale, shift = eval_affine(bn, x.fl, cache=True)
+            return _run_gather(x, packed, mode, cin, cout, arith.conv, scale, shift, residual, relu)
+    training = bn.training or not bn.track_running_stats
+    if not training and not torch.is_grad_enabled():
+        # inference: BatchNorm folded into the conv epilogue, packed weights / affine maps memoised
+        x = _chk(x, "x")
+        with torch.cuda.device(x.device):
+            packed, cin, cout = _pack_forward(conv.weight, mode, arith.conv, cache=True)
+            scale, shift = eval_affine(bn, x, cache=True)
+            return _run_gather(x, packed, mode, cin, cout, arith.conv, scale, shift,
+                               _chk(residual, "residual") if residual is not None else None, relu)
+    return _ConvBN.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, mode, relu, arith)
 
 
 class _ConvLogits(torch.autograd.Function):
@@ -372,98 +429,8 @@ def fanout(x, n):
     return _FanOut.apply(x, n)
 
 
-def conv_plain(x, weight, mode):
+def conv_plain(x, weight, mode, arith=None):
     """Bare convolution (no BN), forward only -- used by parity tests and tools."""
-    packed, cin, cout = _pack_forward(weight, mode)
-    return _run_gather(_chk(x, "x"), packed, mode, cin, cout)
-
-
-# ----------------------------------------------------------------------------
-# 2-D layers of the adjacent feature extractor on the same kernels (SURVEY.md 8f-1)
-# ----------------------------------------------------------------------------
-class _Lift2d(torch.autograd.Function):
-    """[Cout,Cin,3,3] -> [Cout,Cin,3,3,3] with the 2-D kernel in the centre depth slice.
-    A [B,C,H,W] channels-last image is a [B,1,H,W,C] volume; with D = 1 the kd = 0 / kd = 2
-    planes are zero padding and the gather / wgrad kernels skip them, so a 3x3 stride-1 conv2d
-    costs exactly its own 9 taps."""
-
-    @staticmethod
-    def forward(ctx, w2d):
-        w3 = w2d.new_zeros(*w2d.shape[:2], 3, 3, 3)
-        w3[:, :, 1] = w2d
-        return w3
-
-    @staticmethod
-    def backward(ctx, g3):
-        return g3[:, :, 1].contiguous()
-
-
-# AZ_FE2D_CH: channel counts of the 2-D layers routed to the 3-D kernels when AZ_FE2D=hip
-_FE2D_CH = tuple(int(c) for c in os.environ.get("AZ_FE2D_CH", "64").split(","))
-
-
-def supports_2d(conv):
-    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.dilation == (1, 1) and conv.padding == (1, 1) and conv.groups == 1 and conv.bias is None
-            and conv.in_channels in _FE2D_CH and conv.out_channels in _FE2D_CH)
-
-
-def _as_volume(x):
-    """[B,C,H,W] (any strides) -> contiguous channels-last volume [B,1,H,W,C]; zero-copy when
-    the tensor already is torch.channels_last."""
-    return x.permute(0, 2, 3, 1).contiguous().unsqueeze(1)
-
-
-def _as_image(v):
-    """[B,1,H,W,C] volume -> [B,C,H,W] tensor in channels_last memory format (a view)."""
-    return v.squeeze(1).permute(0, 3, 1, 2)
-
-
-class _Conv2dS1(torch.autograd.Function):
-    """conv2d(x, w) for a 3x3, stride-1, pad-1, dilation-1 layer with 32 or 64 channels on the bf16x6 gather
-    kernels (the image is a depth-1 volume).  Backward: input gradient on the same kernels; weight
-    gradient on the bf16x6 wgrad kernel or, with AZ_FE2D_WGRAD=miopen, through ATen."""
-
-    @staticmethod
-    def forward(ctx, x, w2d):
-        xv = _chk(_as_volume(x), "x")
-        w3 = w2d.detach().new_zeros(*w2d.shape[:2], 3, 3, 3)
-        w3[:, :, 1] = w2d.detach()
-        packed, cin, cout = _pack_forward(w3, CONV_S1)
-        y = _run_gather(xv, packed, CONV_S1, cin, cout, tag="fe2d")
-        ctx.save_for_backward(xv, w3)
-        ctx.cfg = (cin, cout)
-        return _as_image(y)
-
-    @staticmethod
-    def backward(ctx, gy):
-        xv, w3 = ctx.saved_tensors
-        cin, cout = ctx.cfg
-        gv = _chk(_as_volume(gy), "grad_y")
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            pk = _pack(w3, cout, cin, 27, cin * 27, True)
-            gx = _as_image(_run_gather(gv, pk, CONV_S1, cout, cin, tag="fe2d_dgrad"))
-        if ctx.needs_input_grad[1]:
-            if os.environ.get("AZ_FE2D_WGRAD", "miopen") == "miopen":
-                gw = torch.ops.aten.convolution_backward(
-                    gy, _as_image(xv), w3[:, :, 1], None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                    [False, True, False])[1]
-            else:
-                gw = _wgrad(gv, xv, 1, cout, cin, "fe2d")[:, :, 1].contiguous()
-        return gx, gw
-
-
-def conv2d_s1(x, conv):
-    """conv(x) for a supports_2d() layer, differentiable; BatchNorm is applied by the caller (bn2d)."""
-    return _Conv2dS1.apply(x, conv.weight)
-
-
-def conv_bn_2d(x, conv, bn, relu=False, residual=None):
-    """relu?(BatchNorm2d(Conv2d 3x3 s1 p1 (x)) + residual) on the MFMA gather kernels."""
-    if not supports_2d(conv):
-        raise RuntimeError("conv_bn_2d: unsupported layer")
-    res = _as_volume(residual) if residual is not None else None
-    y = _ConvBN.apply(_as_volume(x), _Lift2d.apply(conv.weight), bn.weight, bn.bias, res, bn, CONV_S1,
-                      relu, torch.is_grad_enabled())
-    return _as_image(y)
+    arith = _arith(arith)
+    packed, cin, cout = _pack_forward(weight, mode, arith.conv)
+    return _run_gather(_chk(x, "x"), packed, mode, cin, cout, arith.conv)

@@ -7,13 +7,13 @@ in the other half, so its 3x3x3 convolution factors into 2-D convolutions of the
   merged kernels (differentiable tensor ops on the Conv3d weight)
     K_L[c, dl][o, i, kh, kw] = sum over kd in class c with kd - kw <= delta(dl) of W[o, i, kd, kh, kw]
     K_R[c, xb][o, i, kh, j]  = sum over kd in class c, kw with kw - kd = j - 2 (and kw <= 1 if xb) of W[o, 32+i, kd, kh, kw]
-  F = conv2d(L, K_L, pad 1), G = conv2d(pad_left2(R), K_R, pad (1,2))        (MIOpen, autograd)
+  F = conv2d(L, K_L, pad 1), G = conv2d(pad_left2(R), K_R, pad (1,2))        (conv2d.py: az_conv2d_fwd / _wgrad)
   raw = assemble(F, G)                                                       (az_costconv_assemble_*)
 """
 import torch
 import torch.nn.functional as F_
 
-from . import profiler
+from . import conv2d, profiler
 from .ops import _call, _chk, _p, _stream
 
 NDL = 5
@@ -56,13 +56,15 @@ _MERGED_CACHE = {}
 
 
 def _merged_kernels(weight, ndisp):
-    """(K_L bulk [128,32,3,3], K_L edge [512,32,3,3], K_R [256,32,3,5]) of a [32,64,3,3,3] weight; differentiable.
-    Cached between inference forwards on the weight's version (conv3d._inference_mode)."""
-    from .conv3d import _inference_mode
+    """(K_L bulk [ncls*32,32,3,3], K_L edge [ncls*128,32,3,3], K_R [ncls*64,32,3,5]) of a [32,64,3,3,3] weight;
+    differentiable.  Memoised between no_grad forwards on the weight's version counter."""
+    from .conv3d import _cache_get, _cache_put
     ncls = num_classes(ndisp)
-    key = (weight.data_ptr(), weight._version, weight.device.index, ncls) if _inference_mode() else None
-    if key is not None and key in _MERGED_CACHE:
-        return _MERGED_CACHE[key][:3]
+    key = (weight.data_ptr(), weight._version, weight.device.index, ncls) if not torch.is_grad_enabled() else None
+    if key is not None:
+        hit = _cache_get(_MERGED_CACHE, key)
+        if hit is not None:
+            return hit[:3]
     cl = torch.channels_last
     ml, mr = _masks(weight.device, ndisp)
     kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml)          # [cls, dl, o, i, 3, 3]
@@ -71,9 +73,7 @@ def _merged_kernels(weight, ndisp):
            torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(ncls * 2 * 32, 32, 3, 5)
            .contiguous(memory_format=cl))
     if key is not None:
-        if len(_MERGED_CACHE) > 16:
-            _MERGED_CACHE.clear()
-        _MERGED_CACHE[key] = out + (weight,)  # (keeps the source alive: its address stays unique)
+        _cache_put(_MERGED_CACHE, key, out + (weight,), 16)  # (keeps the source alive: its address stays unique)
     return out
 
 
@@ -102,7 +102,7 @@ class _Assemble(torch.autograd.Function):
         return dfb, dfe, dg, None
 
 
-def costvol_conv(feat_l, feat_r, ndisp, weight):
+def costvol_conv(feat_l, feat_r, ndisp, weight, arith=None):
     """conv3d(concat_cost_volume(feat_l, feat_r, ndisp), weight, padding=1) as [B,ndisp,h,w,32] (NDHWC).
     feat_*: [B,32,h,w] (channels_last preferred); weight: [32,64,3,3,3]."""
     if tuple(weight.shape) != (32, 64, 3, 3, 3) or feat_l.shape[1] != 32 or feat_l.shape != feat_r.shape:
@@ -113,10 +113,10 @@ def costvol_conv(feat_l, feat_r, ndisp, weight):
     cl = torch.channels_last
     kl_bulk, kl_edge, kr = _merged_kernels(weight, ndisp)
     fl = feat_l.contiguous(memory_format=cl)
-    fb = F_.conv2d(fl, kl_bulk, padding=1)
+    fb = conv2d.conv_same(fl, kl_bulk)
     # the delta < 2 maps are read at x = d + delta <= ndisp only: convolve the first xe (+1 halo) columns
-    fe = F_.conv2d(fl[..., :min(w, xe + 1)].contiguous(memory_format=cl), kl_edge, padding=1)[..., :xe]
+    fe = conv2d.conv_same(fl[..., :min(w, xe + 1)].contiguous(memory_format=cl), kl_edge)[..., :xe]
     rp = F_.pad(feat_r, (2, 0)).contiguous(memory_format=cl)
-    g = F_.conv2d(rp, kr, padding=(1, 2))
+    g = conv2d.conv_same(rp, kr)
     rows = lambda t: t.permute(0, 2, 3, 1).contiguous()  # [B,C,h,w] -> [B,h,w,C]
     return _Assemble.apply(rows(fb), rows(fe), rows(g), int(ndisp))

@@ -44,21 +44,119 @@ __device__ __forceinline__ float4 az_ld16_or_zero(const float *base, size_t offs
     return r;
 }
 
-// Exact 3-way split of four fp32 values into bf16 parts (truncation: 8+8+8 significand bits,
-// x == hi + mid + lo exactly), packed 4 x bf16 = 8 bytes per part.  v_perm_b32 picks the high
-// halves of two registers, so no masking is needed for packing; only the two remainders are.
+// Exact 3-way split of fp32 values into bf16 parts, ROUND-TO-NEAREST-EVEN at every level:
+//   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid);   x == hi + mid + lo exactly
+// (8 + 8 + 8 signed significand bits cover fp32's 24).  The three partial products the bf16x6 arithmetic
+// drops (mid*lo', lo*mid', lo*lo') are then <= 2^-26 |x y| and of either sign.  A TRUNCATING split
+// (mask the low 16 bits) costs the same instructions but leaves residuals that all carry the sign of x:
+// the dropped terms become a one-sided 2^-24 |x y| bias, which random-walk tolerances hide but anything that
+// averages many outputs (the 64x64 SPP pooling in front of a high-gain BatchNorm, measured: the extractor's
+// output error was 10x the fp32 reference's although every single layer matched it) turns into the
+// dominant error.  v_cvt_pk_bf16_f32 converts two values per instruction.
+typedef __bf16 az_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned az_pk_bf16(float a, float b) {
+    az_bf16x2 p;
+    p[0] = (__bf16)a;  // -O3: one v_cvt_pk_bf16_f32 (RNE) for the pair
+    p[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void az_split3_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    hi = az_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = az_pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(mid << 16), q1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    lo = az_pk_bf16(q0, q1);
+}
+// four values -> three 8-byte pieces (4 x bf16 each)
 __device__ __forceinline__ void az_split3_bf16x4(const float4 &v, uint2 &hi, uint2 &mid, uint2 &lo) {
-    const float xs[4] = {v.x, v.y, v.z, v.w};
-    float r1[4], r2[4];
+    az_split3_pair(v.x, v.y, hi.x, mid.x, lo.x);
+    az_split3_pair(v.z, v.w, hi.y, mid.y, lo.y);
+}
+// one value, host-or-device scalar form for the weight packers: part p of x as a bf16 bit pattern
+__device__ __forceinline__ unsigned short az_split3_part(float x, int p) {
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    return __builtin_bit_cast(unsigned short, p == 0 ? h : p == 1 ? m : l);
+}
+
+// ---- one 32x32x16 block of the bf16x6 arithmetic ------------------------------------------------------
+// fp32-class product on the bf16 pipe: (ah+am+al)(bh+bm+bl) without the three terms below 2^-26, six
+// v_mfma_f32_32x32x16_bf16.  aq/bq: the hi, mid, lo parts' 8-element fragments.  Two measured properties of
+// the instruction shape how the six are combined (tools/parity_probe*.py, tools/rz_probe.py):
+//
+// (1) An MFMA rounds its fp32 accumulator after every instruction, at the accumulator's magnitude.  Chaining
+//     all six into the RUNNING accumulator costs six such roundings per 16-deep K block, five of which only
+//     add terms <= 2^-8 of the block's value: the extractor's layers then sat at 2.7x (K = 1152) to 3.6x
+//     (K = 2880) the error of torch's own fp32 convolution.  So the six partial products of a block are summed
+//     in a ZERO-initialised temporary (the MFMA takes the inline constant 0 as C) and the accumulator receives
+//     the finished temporary with plain VALU adds: one rounding of the accumulator per K block.
+// (2) When the addend C is much smaller than the products (or the reverse) the MFMA aligns the small operand
+//     to the large one and FLOORS the bits it shifts out -- towards minus infinity, for either sign.  With the
+//     customary "smallest terms first" order the last instruction adds the hi*hi products to a C that holds
+//     the 2^-8 / 2^-16 terms: every block result came out low by ~2^-28 of sum|a b| (signed mean relative error
+//     -1.2e-7 on mixed-sign data, 8 times the -1.5e-8 of the order below; hi*hi alone from zero: -1.4e-10).  A bias
+//     of that size is invisible per layer, but it survives averaging: through the 64x64 SPP pooling in front of a
+//     high-gain BatchNorm it made the extractor's output error 5x the fp32 reference's and the D = 192 disparity
+//     error 4x.  LARGEST TERMS FIRST costs nothing and removes it: hi*hi starts from zero, each later group is
+//     added to a C at least as large as its products, whose own low bits stay inside the adder.
+//
+// az_mfma6_step overlaps the adds with the next block's MFMAs (two temporaries in flight = 32 registers);
+// az_mfma6_now is the single-temporary form for kernels at their register limit; az_mfma6 is the plain chain
+// into a running accumulator (weight-gradient kernels).
+typedef float az_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 az_bf16x8 __attribute__((ext_vector_type(8)));
+#define AZ_X6(ACC, A, B) __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
+        __builtin_bit_cast(az_bf16x8, aq[A]), __builtin_bit_cast(az_bf16x8, bq[B]), ACC, 0, 0, 0)
+__device__ __forceinline__ void az_mfma6(az_f32x16 &c, const float4 (&aq)[3], const float4 (&bq)[3]) {
+    c = AZ_X6(c, 0, 0); c = AZ_X6(c, 0, 1); c = AZ_X6(c, 1, 0); c = AZ_X6(c, 1, 1); c = AZ_X6(c, 0, 2);
+    c = AZ_X6(c, 2, 0);
+}
+// c += (block product summed from zero).  The adds wait for the block's last MFMA; the SIMD's other wave
+// covers the gap.
+__device__ __forceinline__ void az_mfma6_now(az_f32x16 &c, const float4 (&aq)[3], const float4 (&bq)[3]) {
+    az_f32x16 t;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        r1[e] = xs[e] - __uint_as_float(__float_as_uint(xs[e]) & 0xffff0000u);
-        r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
-    }
-    // perm(S0, S1, sel): bytes 0-3 of the pool are S1, 4-7 are S0 -> {S1.hi16, S0.hi16}
-#define AZ_HI2(a, b) __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u)
-    hi = make_uint2(AZ_HI2(xs[0], xs[1]), AZ_HI2(xs[2], xs[3]));
-    mid = make_uint2(AZ_HI2(r1[0], r1[1]), AZ_HI2(r1[2], r1[3]));
-    lo = make_uint2(AZ_HI2(r2[0], r2[1]), AZ_HI2(r2[2], r2[3]));
-#undef AZ_HI2
+    for (int e = 0; e < 16; ++e) t[e] = 0.f;
+    t = AZ_X6(t, 0, 0); t = AZ_X6(t, 0, 1); t = AZ_X6(t, 1, 0); t = AZ_X6(t, 1, 1); t = AZ_X6(t, 0, 2);
+    t = AZ_X6(t, 2, 0);
+    c += t;
+    asm volatile("" : "+v"(c));  // keeps the adds here (see az_mfma6_step)
+}
+// tnew = block product (from zero);  cprev += tprev  (tprev: the temporary of the block before), the adds
+// interleaved between this block's MFMAs: the matrix pipe never waits for them
+__device__ __forceinline__ void az_mfma6_step(az_f32x16 &tnew, const float4 (&aq)[3], const float4 (&bq)[3],
+                                              az_f32x16 &cprev, const az_f32x16 &tprev) {
+    az_f32x16 t;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) t[e] = 0.f;
+    t = AZ_X6(t, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) cprev[e] += tprev[e];
+    t = AZ_X6(t, 0, 1);
+#pragma unroll
+    for (int e = 3; e < 6; ++e) cprev[e] += tprev[e];
+    t = AZ_X6(t, 1, 0);
+#pragma unroll
+    for (int e = 6; e < 9; ++e) cprev[e] += tprev[e];
+    t = AZ_X6(t, 1, 1);
+#pragma unroll
+    for (int e = 9; e < 12; ++e) cprev[e] += tprev[e];
+    t = AZ_X6(t, 0, 2);
+#pragma unroll
+    for (int e = 12; e < 16; ++e) cprev[e] += tprev[e];
+    t = AZ_X6(t, 2, 0);
+    tnew = t;
+    // the adds must stay HERE: without a use at this point LLVM sinks each add down to the next add of the
+    // same accumulator (a whole tap later), every temporary stays live and the kernel spills ~600 registers
+    asm volatile("" : "+v"(cprev));
+    // pin the interleave: one MFMA, then three (four) of the independent adds, six times
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
 }

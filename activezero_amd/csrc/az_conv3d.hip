@@ -307,15 +307,22 @@ conv3d_gather_kernel(const ConvArgs a) {
                     c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
                 }
             } else {
-                // fp32 product on the bf16 pipe: (ah+am+al)(bh+bm+bl) without the three
-                // terms below 2^-24: six v_mfma_f32_32x32x16_bf16 per 16-deep K block,
-                // smallest terms first
+                // fp32 product on the bf16 pipe: six v_mfma_f32_32x32x16_bf16 per 16-deep K block, summed in a
+                // zero-initialised temporary so that the accumulator is rounded once per block
+                // (az_common.h az_mfma6_step); the second block's MFMAs cover the first block's adds
+                const float4 a0q[3] = {aq[0], aq[2], aq[4]}, a1q[3] = {aq[1], aq[3], aq[5]};
+                const float4 b0q[3] = {bw[n][0], bw[n][2], bw[n][4]}, b1q[3] = {bw[n][1], bw[n][3], bw[n][5]};
+                if (X6_WIDE(COUT, MODE, PREC)) {  // one wave per SIMD, registers to spare: overlap adds and MFMAs
+                    f32x16 ta, tb;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-#define X6(A, B) c[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
-                    __builtin_bit_cast(bf16x8, aq[(A) * 2 + kb]), __builtin_bit_cast(bf16x8, bw[n][(B) * 2 + kb]), c[n], 0, 0, 0)
-                    X6(2, 0); X6(0, 2); X6(1, 1); X6(1, 0); X6(0, 1); X6(0, 0);
-#undef X6
+                    for (int e = 0; e < 16; ++e) ta[e] = 0.f;
+                    az_mfma6_step(tb, a0q, b0q, c[n], ta);   // block kb = 0 (adds zeros: keeps one code shape)
+                    az_mfma6_step(ta, a1q, b1q, c[n], tb);   // block kb = 1, c += block 0
+                    c[n] += ta;                              // block 1: waits for its last MFMA
+                    asm volatile("" : "+v"(c[n]));
+                } else {  // two waves per SIMD at the register limit: one temporary, the partner wave fills the gap
+                    az_mfma6_now(c[n], a0q, b0q);
+                    az_mfma6_now(c[n], a1q, b1q);
                 }
             }
         }
@@ -547,12 +554,7 @@ conv3d_pack_x6_kernel(unsigned short *__restrict__ dst, const float *__restrict_
     const int co = n * 32 + (lane & 31);
     const int ci = cc * 32 + 16 * kb + 8 * (lane >> 5) + j;
     const float x = src[co * sn + ci * sk + (flip ? 26 - tap : tap)];
-    const unsigned hi = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(hi);
-    const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(mid);
-    const unsigned lo = __float_as_uint(r2) & 0xffff0000u;
-    dst[idx] = (unsigned short)((p == 0 ? hi : p == 1 ? mid : lo) >> 16);
+    dst[idx] = az_split3_part(x, p);  // round-to-nearest split, as the activations' (az_common.h)
 }
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>

@@ -163,12 +163,19 @@ conv3d_m128_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) aq[p] = *reinterpret_cast<const float4 *>(ap + 8 * p);
     };
-    // fp32 product on the bf16 pipe: (ah+am+al)(bh+bm+bl) without the three terms below 2^-24
-    auto mfma6 = [&](f32x16 &c, const float4 (&aq)[3], const float4 (&bq)[3]) {
-#define X6(A, B) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16( \
-        __builtin_bit_cast(bf16x8, aq[A]), __builtin_bit_cast(bf16x8, bq[B]), c, 0, 0, 0)
-        X6(2, 0); X6(0, 2); X6(1, 1); X6(1, 0); X6(0, 1); X6(0, 0);
-#undef X6
+    // fp32 product on the bf16 pipe, one accumulator rounding per K16 block (az_common.h az_mfma6_step)
+    // (M1_PIPE 1 = two alternating temporaries, adds one block late: needs 32 more registers than the
+    //  2-waves/SIMD budget has left here; 0 = one temporary, added at once: the adds wait for the block's
+    //  last MFMA and the SIMD's other wave fills the gap)
+#ifndef M1_PIPE
+#define M1_PIPE 0
+#endif
+    f32x16 t0, t1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { t0[e] = 0.f; t1[e] = 0.f; }
+    auto step = [&](int cur, f32x16 &tn, const f32x16 &tp, const float4 (&aq)[3], const float4 (&bq)[3]) {
+        if (M1_PIPE) az_mfma6_step(tn, aq, bq, acc[(cur + 3) & 3], tp);
+        else az_mfma6_now(acc[cur], aq, bq);
     };
 
     // ---- software pipeline ------------------------------------------------------------------
@@ -204,23 +211,24 @@ conv3d_m128_kernel(const ConvArgs a) {
                 issue(min(s + 1, NS - 1));
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma6(acc[0], a0, ring[t % 3]);
+            step(0, t0, t1, a0, ring[t % 3]);
             __builtin_amdgcn_sched_barrier(0);
             load_a(a0, 2, eh, ew);
             __builtin_amdgcn_sched_barrier(0);
-            mfma6(acc[1], a1, ring[t % 3]);
+            step(1, t1, t0, a1, ring[t % 3]);
             __builtin_amdgcn_sched_barrier(0);
             load_a(a1, 3, eh, ew);
             __builtin_amdgcn_sched_barrier(0);
-            mfma6(acc[2], a0, ring[t % 3]);
+            step(2, t0, t1, a0, ring[t % 3]);
             __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < 9) load_a(a0, 0, (t + 1) / 3, (t + 1) % 3);
             __builtin_amdgcn_sched_barrier(0);
-            mfma6(acc[3], a1, ring[t % 3]);
+            step(3, t1, t0, a1, ring[t % 3]);
         }
         bcur = bnext;
     }
 
+    if (M1_PIPE) acc[3] += t1;  // the last block's temporary
     // ---- epilogue -----------------------------------------------------------------------------
     // C/D map of the 32x32 MFMA: column (out channel) = lane & 31, row (voxel of the 4x8 tile) =
     // (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); M-tile m covers rows 4(m>>1).., cols 8(m&1)..

@@ -14,7 +14,7 @@ hard-codes .cuda(); this path has no CPU fallback).
 """
 import math
 
-from activezero_amd import agg3d, ops
+from activezero_amd import agg3d, conv3d, ops
 from activezero_amd.nets.psmnet.psmnet_submodule_3 import *  # noqa: F401,F403
 from activezero_amd.nets.psmnet import psmnet_submodule_3 as _sub
 
@@ -42,17 +42,19 @@ class hourglass(nn.Module):
         self.conv5 = _up_unit(c2, c2)
         self.conv6 = _up_unit(c2, inplanes)
 
-    def forward(self, x, presqu, postqu, out_add=None):
+    def forward(self, x, presqu, postqu, out_add=None, arith=None):
         """Reference signature (psmnet_3.py:36) plus `out_add`: a tensor added to `out` inside conv6's
         BatchNorm pass -- PSMNet.forward adds cost0 to every hourglass output (psmnet_3.py:166-175),
-        which otherwise is one more read+write of the 32-channel V0 tensor per hourglass."""
-        down = agg3d.conv_bn(x, self.conv1[0], relu=True)
-        pre = agg3d.conv_bn(down, self.conv2, relu=True, add=postqu)
-        deep = agg3d.conv_bn(pre, self.conv3[0], relu=True)
-        deep = agg3d.conv_bn(deep, self.conv4[0], relu=True)
+        which otherwise is one more read+write of the 32-channel V0 tensor per hourglass -- and
+        `arith`: the MFMA arithmetic (conv3d.Arith; None = the library default)."""
+        a = arith
+        down = agg3d.conv_bn(x, self.conv1[0], relu=True, arith=a)
+        pre = agg3d.conv_bn(down, self.conv2, relu=True, add=postqu, arith=a)
+        deep = agg3d.conv_bn(pre, self.conv3[0], relu=True, arith=a)
+        deep = agg3d.conv_bn(deep, self.conv4[0], relu=True, arith=a)
         post = agg3d.deconv_bn(deep, self.conv5, relu=True,
-                               add=pre if presqu is None else presqu)
-        out = agg3d.deconv_bn(post, self.conv6, add=out_add)
+                               add=pre if presqu is None else presqu, arith=a)
+        out = agg3d.deconv_bn(post, self.conv6, add=out_add, arith=a)
         return out, pre, post
 
 
@@ -79,10 +81,14 @@ class PSMNet(nn.Module):
         self.classif2 = _classifier()
         self.classif3 = _classifier()
         self._reference_init()
-        # adjacent 2-D stage: NHWC parameters/activations let MIOpen skip its layout
-        # transposes and hand the features to the 3-D kernels already channels-last
-        # (shapes and state-dict keys are unchanged; -4 % step time on MI355X)
-        self.feature_extraction.to(memory_format=torch.channels_last)
+        # arithmetic of the MFMA kernels of THIS module (conv3d.Arith): an attribute, not a
+        # process-wide switch -- two models with different arithmetic can run side by side
+        self.arith = conv3d.DEFAULT_ARITH
+
+    def set_arithmetic(self, conv="bf16x6", wgrad=None):
+        """'bf16x6' (default: exact 3-way bf16 split, six MFMAs per product) or 'fp32' (fp32 MFMA)."""
+        self.arith = conv3d.Arith.of(conv, wgrad)
+        return self
 
     def _reference_init(self):
         # reference psmnet_3.py:123-142
@@ -98,20 +104,21 @@ class PSMNet(nn.Module):
 
     # -- hot path ------------------------------------------------------------
     def _aggregate(self, vol, first=None):
+        a = self.arith
         # `first`: dres0[0]'s activation when it was computed straight from the feature maps
-        c0 = first if first is not None else agg3d.conv_bn(vol, self.dres0[0], relu=True)
-        c0 = agg3d.conv_bn(c0, self.dres0[2], relu=True)
-        t = agg3d.conv_bn(c0, self.dres1[0], relu=True)
-        c0 = agg3d.conv_bn(t, self.dres1[2], add=c0)
+        c0 = first if first is not None else agg3d.conv_bn(vol, self.dres0[0], relu=True, arith=a)
+        c0 = agg3d.conv_bn(c0, self.dres0[2], relu=True, arith=a)
+        t = agg3d.conv_bn(c0, self.dres1[0], relu=True, arith=a)
+        c0 = agg3d.conv_bn(t, self.dres1[2], add=c0, arith=a)
 
         # cost0 has four consumers (first hourglass + three residual sums): one fused gradient sum
         c0a, c0b, c0c, c0d = agg3d.fanout(c0, 4)
-        out1, pre1, post1 = self.dres2(c0a, None, None, out_add=c0b)   # out_k + cost0 fused
-        out2, _pre2, post2 = self.dres3(out1, pre1, post1, out_add=c0c)
-        out3, _pre3, _post3 = self.dres4(out2, pre1, post2, out_add=c0d)
+        out1, pre1, post1 = self.dres2(c0a, None, None, out_add=c0b, arith=a)   # out_k + cost0 fused
+        out2, _pre2, post2 = self.dres3(out1, pre1, post1, out_add=c0c, arith=a)
+        out3, _pre3, _post3 = self.dres4(out2, pre1, post2, out_add=c0d, arith=a)
 
         def head(cls, v, running):
-            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True), cls[2], running)
+            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True, arith=a), cls[2], running)
 
         cost1 = head(self.classif1, out1, None)
         cost2 = head(self.classif2, out2, cost1)
@@ -119,14 +126,11 @@ class PSMNet(nn.Module):
         return cost1, cost2, cost3
 
     def _from_features(self, feat_l, feat_r):
-        if agg3d.use_costconv(feat_l):
-            # cost volume + dres0[0] factored into 2-D convolutions of the two feature maps: the
-            # [B,64,D/4,h,w] volume (psmnet_3.py:149-163) and its gradient are never formed
-            first = agg3d.costvol_conv_bn(feat_l, feat_r, self.maxdisp // 4, self.dres0[0], relu=True)
-            cost1, cost2, cost3 = self._aggregate(None, first)
-        else:
-            vol = agg3d.volume_from_features(feat_l, feat_r, self.maxdisp // 4)
-            cost1, cost2, cost3 = self._aggregate(vol)
+        # cost volume + dres0[0] factored into 2-D convolutions of the two feature maps: the
+        # [B,64,D/4,h,w] volume (psmnet_3.py:149-163) and its gradient are never formed
+        first = agg3d.costvol_conv_bn(feat_l, feat_r, self.maxdisp // 4, self.dres0[0], relu=True,
+                                      arith=self.arith)
+        cost1, cost2, cost3 = self._aggregate(None, first)
         pred3 = ops.softargmin(cost3)
         if self.training:
             return pred3, ops.softargmin(cost2), ops.softargmin(cost1)

@@ -13,4 +13,4 @@ class FeatureExtraction(_base.FeatureExtraction):
 
     def forward(self, x, x_transformed):
         """([B,3,H,W], [B,3,H,W]) -> [B,32,H/4,W/4]"""
-        return self._trunk(torch.cat((x, x_transformed), 1))
+        return self._trunk(torch.cat((x, x_transformed), 1).contiguous(memory_format=torch.channels_last))

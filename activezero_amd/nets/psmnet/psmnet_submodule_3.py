@@ -1,86 +1,39 @@
 """2-D feature extractor + building blocks of PSMNet (3-channel input).
 
-Mirrors the public names of the reference module
-nets/psmnet/psmnet_submodule_3.py (convbn, conv, convbn_3d, BasicBlock,
-DisparityRegression, FeatureExtraction) and its parameter/buffer names, so
-reference checkpoints load unchanged.  The 2-D ResNet+SPP extractor is the
-"adjacent" stage of SURVEY.md 8f: ordinary PyTorch-ROCm (MIOpen) modules.
-The 3-D blocks built from convbn_3d are executed by activezero_amd.agg3d.
+Mirrors the public names of the reference module nets/psmnet/psmnet_submodule_3.py (convbn, conv,
+convbn_3d, BasicBlock, DisparityRegression, FeatureExtraction) and its parameter/buffer names, so
+reference checkpoints load unchanged.  The modules are parameter containers: forward() runs every
+convolution on the hand-written 2-D MFMA kernels (activezero_amd/conv2d.py) and every
+BatchNorm (+ReLU, +residual) on the HIP BatchNorm kernels (activezero_amd/bn2d.py); there is no
+vendor-library convolution and no fallback.  The 3-D blocks built from convbn_3d are executed by
+activezero_amd.agg3d.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-import os
-
-from activezero_amd import bn2d, conv3d, ops
-
-# 2-D stage backend.  "miopen" (default): PyTorch-ROCm/MIOpen modules, channels-last.
-# "hip" (opt-in experiment): the 3x3 stride-1 32/64-channel conv+BN(+ReLU)(+residual) units of
-# the extractor run on the MFMA gather kernels as D=1 volumes (conv3d.conv_bn_2d).  Measured on
-# MI355X at B=4, 544x960: 190.2 ms/step vs 184.9 ms with MIOpen -- the 2-D layers are small
-# (<= 10 GFLOP each) and launch/occupancy bound on the 3-D tiling, so MIOpen stays the default
-# until the 2-D stage gets its own tiling.
-# AZ_FE2D: "fused" (default) = MIOpen convolutions + the HIP BatchNorm kernels with ReLU / residual
-# folded into the normalisation pass and per-group batch statistics (left and right images run as
-# ONE batch of 2B, activezero_amd/bn2d.py); "miopen" = plain torch modules, two passes; "hip" = the
-# stride-1 3x3 layers on the 3-D gather kernels (experiment, slower).
-FE2D_BACKEND = os.environ.get("AZ_FE2D", "fused")
-FE2D_CONV = os.environ.get("AZ_FE2D_CONV", "hip")
-# inference experiments: "fold" = BatchNorm folded into the conv weights + bias (plain conv2d, cached);
-# "fused" = the same through MIOpen's conv+bias+ReLU fusion; "" (default) = the HIP BatchNorm apply pass.
-# Measured (eval forward): 256x512/D=64 4.35 ms -> 3.54 (fold) / 155 (fused); 540x960/D=192 12.7 ms ->
-# 13.3 (fold) / 540 (fused): the fused apply(+ReLU+residual) pass wins at the sizes that matter.
-FE2D_EVAL_FOLD = os.environ.get("AZ_FE2D_EVAL_FOLD", "")
-_STAT_GROUPS = 1  # batch-statistic groups of the pass in flight (2 inside forward_pair)
+from activezero_amd import bn2d, conv2d
 
 
-_FOLD_CACHE = {}
-
-
-def _folded(conv, bn):
-    """(weight * scale[c_out], shift) of an eval-mode conv+BN unit, cached on the parameters' versions."""
-    ts = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t.data_ptr(), t._version) for t in ts)
-    hit = _FOLD_CACHE.get(key)
-    if hit is None:
-        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        w_f = (conv.weight * scale.view(-1, 1, 1, 1)).contiguous(memory_format=torch.channels_last)
-        b_f = bn.bias - bn.running_mean * scale
-        if len(_FOLD_CACHE) > 256:
-            _FOLD_CACHE.clear()
-        hit = _FOLD_CACHE[key] = (w_f, b_f) + ts  # (holds its sources: their addresses stay unique)
-    return hit[0], hit[1]
-
-
-def _convbn_unit(x, unit, relu=False, residual=None):
-    """unit = Sequential(Conv2d, BatchNorm2d): y = relu?(bn(conv(x)) + residual)"""
+def _convbn_unit(x, unit, relu=False, residual=None, groups=1):
+    """unit = Sequential(Conv2d, BatchNorm2d): y = relu?(bn(conv(x)) + residual).
+    `groups`: consecutive equal parts of the batch that take their OWN batch statistics (2 when the left
+    and right images run as one stacked batch, FeatureExtraction.forward_pair); passed down explicitly --
+    no module-level state, so replicas on several threads (nn.DataParallel, train.py:540-541) cannot
+    disturb each other."""
     conv, bn = unit[0], unit[1]
-    if FE2D_BACKEND == "hip" and x.is_cuda and conv3d.supports_2d(conv) and _STAT_GROUPS == 1:
-        return conv3d.conv_bn_2d(x, conv, bn, relu, residual)
-    if (FE2D_EVAL_FOLD and FE2D_BACKEND != "miopen" and x.is_cuda and not bn.training
-            and not torch.is_grad_enabled() and bn.track_running_stats):
-        # inference: BatchNorm folded into the convolution's weights and bias (cached), ReLU fused by
-        # MIOpen where the layer has one -- no separate normalisation pass
-        w_f, b_f = _folded(conv, bn)
-        if relu and residual is None and FE2D_EVAL_FOLD == "fused":
-            return torch.ops.aten.miopen_convolution_relu(x, w_f, b_f, conv.stride, conv.padding, conv.dilation, 1)
-        y = F.conv2d(x, w_f, b_f, conv.stride, conv.padding, conv.dilation)
-        if residual is not None:
-            y = y + residual
-        return F.relu_(y) if relu else y
-    if FE2D_BACKEND != "miopen" and bn2d.supported(bn, x):
-        # AZ_FE2D_CONV=hip (default): the stride-1 3x3 64-channel layers (layer2, a third of the extractor's
-        # FLOPs) run forward and input gradient on the bf16x6 gather kernel as depth-1 volumes; their weight
-        # gradient stays on MIOpen (AZ_FE2D_WGRAD).  AZ_FE2D_CONV=miopen: every convolution on MIOpen.
-        y = conv3d.conv2d_s1(x, conv) if (FE2D_CONV == "hip" and conv3d.supports_2d(conv)) else conv(x)
-        return bn2d.bn_act(y, bn, relu, residual, _STAT_GROUPS)
-    if _STAT_GROUPS != 1:
-        raise RuntimeError("grouped batch statistics need the fused BatchNorm path")
-    y = unit(x)
-    if residual is not None:
-        y = y + residual
-    return F.relu(y) if relu else y
+    if not x.is_cuda:
+        raise RuntimeError("the feature extractor runs on the GPU only (no CPU fallback)")
+    if not bn2d.supported(bn, x):
+        raise RuntimeError(f"unsupported BatchNorm2d for the HIP path: {bn}")
+    training = bn.training or not bn.track_running_stats
+    if not training and not torch.is_grad_enabled():
+        # inference: BatchNorm (running statistics), residual sum and ReLU ride on the conv epilogue
+        y = conv2d.conv_bn_eval(x, conv, bn, relu, residual)
+        if y is not None:
+            return y
+    return bn2d.bn_act(conv2d.conv(x, conv), bn, relu, residual, groups)
+
 
 __all__ = ["convbn", "conv", "convbn_3d", "BasicBlock", "DisparityRegression",
            "FeatureExtraction", "torch", "nn", "F"]
@@ -120,10 +73,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        shortcut = x if self.downsample is None else _convbn_unit(x, self.downsample)
-        y = _convbn_unit(x, self.conv1[0], relu=True)
-        return _convbn_unit(y, self.conv2, relu=False, residual=shortcut)
+    def forward(self, x, groups=1):
+        shortcut = x if self.downsample is None else _convbn_unit(x, self.downsample, groups=groups)
+        y = _convbn_unit(x, self.conv1[0], relu=True, groups=groups)
+        return _convbn_unit(y, self.conv2, relu=False, residual=shortcut, groups=groups)
 
 
 class DisparityRegression(nn.Module):
@@ -209,12 +162,21 @@ class FeatureExtraction(nn.Module):
         layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def _trunk(self, x):
-        y = _convbn_unit(x, self.firstconv[0], relu=True)
-        y = _convbn_unit(y, self.firstconv[2], relu=True)
-        y = _convbn_unit(y, self.firstconv[4], relu=True)
-        raw = self.layer2(self.layer1(y))
-        skip = self.layer4(self.layer3(raw))
+    def _trunk(self, x, groups=1):
+        g = groups
+        y = _convbn_unit(x, self.firstconv[0], relu=True, groups=g)
+        y = _convbn_unit(y, self.firstconv[2], relu=True, groups=g)
+        y = _convbn_unit(y, self.firstconv[4], relu=True, groups=g)
+        for blk in self.layer1:
+            y = blk(y, g)
+        for blk in self.layer2:
+            y = blk(y, g)
+        raw = y
+        for blk in self.layer3:
+            y = blk(y, g)
+        for blk in self.layer4:
+            y = blk(y, g)
+        skip = y
         size = skip.shape[-2:]
         # SPP pooling as a hierarchy: the 16/32/64 windows are 2x2 means of the previous level
         # (floor division composes, so sizes and covered pixels equal AvgPool2d(win, win)); the
@@ -225,27 +187,23 @@ class FeatureExtraction(nn.Module):
             pooled[win] = p
         assert sorted(pooled) == [8, 16, 32, 64]
         win_of = dict(_SPP_WINDOWS)
-        pyramid = [upsample_bilinear_ac(_convbn_unit(pooled[win_of[i]], getattr(self, f"branch{i}")[1], relu=True),
-                                        size) for i in (4, 3, 2, 1)]
-        y = _convbn_unit(torch.cat([raw, skip] + pyramid, 1), self.lastconv[0], relu=True)
-        return self.lastconv[2](y)
+        pyramid = [upsample_bilinear_ac(
+            _convbn_unit(pooled[win_of[i]].contiguous(memory_format=torch.channels_last),
+                         getattr(self, f"branch{i}")[1], relu=True, groups=g), size) for i in (4, 3, 2, 1)]
+        y = _convbn_unit(torch.cat([raw, skip] + pyramid, 1), self.lastconv[0], relu=True, groups=g)
+        return conv2d.conv(y, self.lastconv[2])
 
     def forward(self, x):
         """[B,3,H,W] -> [B,32,H/4,W/4]"""
-        return self._trunk(x)
+        return self._trunk(x.contiguous(memory_format=torch.channels_last))
 
     def forward_pair(self, left, right):
         """(feature_extraction(left), feature_extraction(right)) of psmnet_3.py:145-146 in ONE pass
         over the stacked batch: every BatchNorm takes its statistics per image set and updates its
         running statistics left first, then right, exactly as the two sequential calls do."""
-        global _STAT_GROUPS
-        if FE2D_BACKEND == "miopen" or not left.is_cuda or left.shape != right.shape:
-            return self._trunk(left), self._trunk(right)
+        if left.shape != right.shape:
+            return self.forward(left), self.forward(right)
         x = torch.cat([left, right], 0).contiguous(memory_format=torch.channels_last)
-        _STAT_GROUPS = 2
-        try:
-            y = self._trunk(x)
-        finally:
-            _STAT_GROUPS = 1
+        y = self._trunk(x, groups=2)
         b = left.shape[0]
         return y[:b], y[b:]

@@ -40,12 +40,15 @@ def parse():
     ap.add_argument("--height", type=int, default=H_IMG)
     ap.add_argument("--width", type=int, default=W_IMG)
     ap.add_argument("--maxdisp", type=int, default=MAXDISP)
+    ap.add_argument("--workload", choices=["supervised", "mixed"], default="supervised",
+                    help="supervised = BASELINE configs[1] (the headline metric); mixed = configs[2]/[3]: the "
+                         "default.yaml iteration (train.py:220-432): sim step (disparity + temporal-IR patch "
+                         "reprojection loss) then real step (reprojection loss only), 6-channel PSMNet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", choices=["hip", "miopen"], default=None,
-                    help="3-D aggregation backend (miopen = PyTorch-eager A/B baseline)")
+    ap.add_argument("--eager-steps", type=int, default=1,
+                    help="timed steps of the same workload on stock PyTorch-ROCm operators (tools/eager_psmnet.py) "
+                         "after the measurement, rank 0 at N=1 only: the 'PyTorch-eager' denominator; 0 = skip")
     ap.add_argument("--cpu-sample", choices=["full", "crop"], default="crop")
-    ap.add_argument("--no-miopen-find", action="store_true",
-                    help="do not set torch.backends.cudnn.benchmark (the reference sets it, train.py:38)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --single-device)")
     ap.add_argument("--single-device", action="store_true",
@@ -78,13 +81,26 @@ def disp_loss(preds, gt, maxdisp):
     return disp_losses.psmnet_disp_range(preds, gt, maxdisp)
 
 
+def synth_patterns(b, h_img, w_img, gt, device, seed):
+    """Temporal-IR pattern pair (SURVEY.md 8d): binary dots, Bernoulli(0.25) (datasets/dataset_utils.py:43-46);
+    the right pattern is the left one moved by the ground-truth disparity with the scatter warp (K1), so
+    that the reprojection loss has signal."""
+    from activezero_amd.utils import warp_ops
+    g = torch.Generator(device=device).manual_seed(seed)
+    pad = (-h_img) % 32
+    pl = (torch.rand(b, 1, h_img + pad, w_img, device=device, generator=g) < 0.25).float()
+    pr = warp_ops.apply_disparity_cu(pl.contiguous(), (-gt).round().int().contiguous())  # left -> right: x - d
+    return pl.contiguous(), pr.contiguous()
+
+
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference's eager op sequence) timed on this
-    box's host cores on a BOUNDED sample of the same workload: one pair, fwd+loss+bwd, on
-    the reference's own training crop (256x512, configs/config.py:9-10) at the full D=192,
-    scaled to the metric's 544x960 pairs by the pixel ratio (every stage of the path is
-    linear in H*W).  A full-size pair takes > 6 min on 16 cores, too long for a default run
-    (use --cpu-sample full to time it anyway)."""
+    """The oracle (CPU restatement of the reference's eager op sequence) timed on this box's host cores on
+    BOUNDED samples of the workload.  Two legs, both reported:
+      config1 -- BASELINE.json configs[0] exactly: one 256x512 pair, D=64, eval forward (SURVEY.md 8d);
+      value   -- the metric's unit: one pair, fwd+loss+bwd, on the reference's training crop (256x512,
+                 configs/config.py:9-10) at the full D=192, scaled to 544x960 pairs by the pixel ratio
+                 (every stage of the path is linear in H*W).  A full-size pair takes > 6 min on 16 cores,
+                 too long for a default run (--cpu-sample full times it anyway)."""
     from oracle import psmnet_oracle as po
 
     # the GPU box exposes every host CPU (256) but one GPU's share is 16 cores; more
@@ -93,6 +109,16 @@ def cpu_baseline(args):
     torch.set_num_threads(cores)
     md = args.maxdisp
     hp = args.height + (-args.height) % 32
+    torch.manual_seed(1)
+    m1 = po.PSMNetOracle(64, 3).eval()
+    il, ir, _ = synth_batch(1, 256, 512, 64, "cpu", 98)
+    with torch.no_grad():
+        m1(il, ir)  # warm the allocator / thread pool
+        t0 = time.perf_counter()
+        m1(il, ir)
+        dt1 = time.perf_counter() - t0
+    config1 = {"value": 1.0 / dt1, "unit": "pairs/s", "seconds": dt1,
+               "sample": "BASELINE configs[0] exactly: 1 pair 256x512, D=64, eval forward, unscaled"}
     if args.cpu_sample == "full":
         h, w, scale = args.height, args.width, 1.0
         sample = f"1 pair {h}x{w} (padded to {hp}), D={md}, fwd+loss+bwd, 1 step, unscaled"
@@ -110,7 +136,34 @@ def cpu_baseline(args):
     loss.backward()
     dt = time.perf_counter() - t0
     return {"value": 1.0 / (dt * scale), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": sample, "sample_seconds": dt}
+            "sample": sample, "sample_seconds": dt, "config1": config1}
+
+
+def eager_gpu(args, model, il, ir, gt, device):
+    """The same supervised step on stock PyTorch-ROCm operators over the same module (tools/eager_psmnet.py):
+    the 'PyTorch-eager' denominator of the north-star target.  MIOpen find mode stays off (an exhaustive
+    search for the 3-D convolutions takes minutes; the reference would amortise it over an epoch)."""
+    from tools import eager_psmnet
+
+    torch.backends.cudnn.benchmark = False
+    opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = eager_psmnet.eager_loss(eager_psmnet.eager_forward(model, il, ir), gt, args.maxdisp)
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up (kernel selection, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.eager_steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.eager_steps
+    return {"value": args.batch / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "steps": args.eager_steps,
+            "what": "same model/data/step through stock PyTorch-ROCm operators (MIOpen conv2d/conv3d, ATen "
+                    "batch_norm/interpolate/softmax), cudnn.benchmark off, 1 warm-up step"}
 
 
 def main():
@@ -127,28 +180,64 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     azdist.init(args.dist_backend)  # "nccl" = RCCL on ROCm
+    if world > 1:
+        import torch.distributed as dist
+        # self-describing multi-GPU runs: one rank per GPU over RCCL unless a rehearsal was asked for
+        assert dist.get_world_size() == args.gpus
+        assert dist.get_backend() == args.dist_backend, (dist.get_backend(), args.dist_backend)
+        if not args.single_device:
+            assert args.dist_backend == "nccl", "multi-GPU measurements run over RCCL (backend 'nccl')"
+            assert torch.cuda.device_count() >= world, "one GPU per rank"
 
-    from activezero_amd import agg3d, conv3d, profiler
-    from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
+    from activezero_amd import profiler
+    from activezero_amd.utils import reprojection
 
-    if args.backend:
-        agg3d.set_backend(args.backend)
-    # the reference enables cudnn.benchmark (train.py:38); on ROCm this is MIOpen's
-    # exhaustive find for the adjacent 2-D convolutions (paid once, during warm-up)
-    torch.backends.cudnn.benchmark = not args.no_miopen_find
+    mixed = args.workload == "mixed"
+    if mixed:
+        from activezero_amd.nets.psmnet.psmnet import PSMNet
+    else:
+        from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
     torch.manual_seed(1)  # configs/config.py:100
     model = PSMNet(args.maxdisp).to(device).train()
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
     net = azdist.wrap(model, device)
-    il, ir, gt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device,
-                             azdist.rank_seed(1234, rank))
+    seed = azdist.rank_seed(1234, rank)
+    il, ir, gt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device, seed)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = disp_loss(net(il, ir), gt, args.maxdisp)
-        loss.backward()
-        opt.step()
-        return loss
+    if not mixed:
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = disp_loss(net(il, ir), gt, args.maxdisp)
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        # default.yaml iteration (train.py:220-432, utils/losses.py:81-156): ADAPTER=True -> 6-channel PSMNet
+        # (the adapter itself is outside the path: its outputs are synthetic tanh(randn) images);
+        # sim: psmnet_disp + 1.0 * patch reprojection (ps = 11, masked) on the sim IR patterns;
+        # real: 1.0 * patch reprojection (no mask) on the real pair; each with its own backward + Adam step.
+        g = torch.Generator(device=device).manual_seed(seed + 7)
+        tl, tr = (torch.tanh(torch.randn(il.shape, device=device, generator=g)) for _ in range(2))
+        rl, rr, rgt = synth_batch(args.batch, args.height, args.width, args.maxdisp, device, seed + 1000)
+        rtl, rtr = (torch.tanh(torch.randn(il.shape, device=device, generator=g)) for _ in range(2))
+        spl, spr = synth_patterns(args.batch, args.height, args.width, gt, device, seed + 11)
+        rpl, rpr = synth_patterns(args.batch, args.height, args.width, rgt, device, seed + 12)
+        mask = (gt < args.maxdisp) & (gt > 0)  # train.py:272
+        ps = 11  # configs/config.py:41
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = net(il, ir, tl, tr)
+            loss = disp_loss(out, gt, args.maxdisp)
+            loss = loss + reprojection.get_reproj_error_patch(spl, spr, out[0], mask, ps)[0]
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out = net(rl, rr, rtl, rtr)
+            real = reprojection.get_reproj_error_patch(rpl, rpr, out[0], None, ps)[0]
+            real.backward()
+            opt.step()
+            return loss + real.detach()
 
     fence = azdist.fence
 
@@ -171,30 +260,49 @@ def main():
     dt = azdist.max_over_ranks(dt, device)
 
     if rank == 0:
-        pairs = args.batch * world * args.steps
+        pairs_per_step = args.batch * (2 if mixed else 1)  # mixed: one sim pair + one real pair per sample slot
+        pairs = pairs_per_step * world * args.steps
+        hp = args.height + (-args.height) % 32
+        cname, wname = model.arith.names
+        if mixed:
+            workload = (f"configs[2]: default.yaml mixed-domain iteration, PSMNet(6-ch) {args.height}x{args.width} "
+                        f"(padded to {hp} rows) D={args.maxdisp}: sim step (disparity + temporal-IR patch "
+                        f"reprojection loss, ps=11) + real step (reprojection loss), 2 x (fwd+bwd+Adam), "
+                        f"batch {args.batch} per GPU and domain")
+            metric = "stereo pairs/sec (540x960, D=192) fwd+bwd, mixed-domain iteration (sim + real pairs)"
+        else:
+            workload = (f"configs[1]: PSMNet {args.height}x{args.width} (padded to {hp} rows) D={args.maxdisp} "
+                        f"fwd+bwd+Adam, supervised disparity loss, batch {args.batch} per GPU")
+            metric = "stereo pairs/sec (540x960, D=192) fwd+bwd"
         out = {
-            "metric": "stereo pairs/sec (540x960, D=192) fwd+bwd",
+            "metric": metric,
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: PSMNet {args.height}x{args.width} (padded to "
-                                   f"{args.height + (-args.height) % 32} rows) D={args.maxdisp} fwd+bwd+Adam, "
-                                   f"supervised disparity loss, batch {args.batch} per GPU",
+            "config": {"workload": workload,
                        "global_batch": args.batch * world, "height": args.height,
                        "width": args.width, "maxdisp": args.maxdisp,
-                       "parallelism": f"dp{world}", "agg3d_backend": agg3d.BACKEND,
-                       "arithmetic": "fp32 results; conv/deconv/dgrad on "
-                                     + ("bf16x6 split MFMA" if conv3d.PRECISION else "fp32 MFMA")
-                                     + ", wgrad on " + ("bf16x6 split MFMA" if conv3d.WGRAD_PRECISION else "fp32 MFMA")
-                                     + ", fp32 accumulation everywhere"},
+                       "parallelism": f"dp{world}",
+                       "dist_backend": (args.dist_backend + " (RCCL)" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None,
+                       "arithmetic": f"fp32 results; conv/deconv/dgrad MFMA arithmetic {cname}, wgrad {wname} "
+                                     "(bf16x6 = exact 3-way bf16 split, six MFMAs per product), fp32 accumulation "
+                                     "everywhere; every convolution on this library's kernels"},
             "loss": float(loss.item()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
             "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "pmc_traffic_b4.json")),
             "cpu_baseline": None,
+            "eager_gpu": None,
         }
+        if world == 1 and not mixed and args.eager_steps > 0:
+            note(f"{1e3 * dt / args.steps:.1f} ms/step; timing {args.eager_steps} PyTorch-eager step(s) on the GPU")
+            del opt
+            out["eager_gpu"] = eager_gpu(args, model, il, ir, gt, device)
+            out["vs_baseline"] = out["value"] / out["eager_gpu"]["value"]
+            out["vs_baseline_basis"] = ("BASELINE.md holds no published number; ratio to the PyTorch-eager step "
+                                        "measured in this process (eager_gpu)")
         if not args.no_cpu_baseline and world == 1:
-            note(f"{1e3 * dt / args.steps:.1f} ms/step; timing the CPU baseline sample ({args.cpu_sample})")
+            note("timing the CPU baseline samples")
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     azdist.shutdown()

@@ -226,6 +226,44 @@ int az_add_relu(float *y, const float *a, const float *b, int relu, long long n,
 int az_sum4(float *y, const float *a, const float *b, const float *c, const float *d, long long n,
             void *stream);
 
+/* ---- K13: stride-1 "same" 2-D convolution family (bf16x6 MFMA, channels-last) ----------------------
+ * replaces the cuDNN/ATen calls behind nn.Conv2d in the 2-D feature extractor,
+ * nets/psmnet/psmnet_submodule_3.py:13-41 (convbn / conv), :59-77 (BasicBlock), :92-220
+ * (FeatureExtraction) -- forward and, through autograd, input and weight gradients -- and the three
+ * F.conv2d calls of the factored cost-volume convolution (nets/psmnet/psmnet_3.py:149-166).
+ * Geometries: (kh,kw,dilation) in {(3,3,1), (3,3,2), (1,1,*), (3,5,1)}, stride 1, padding such that
+ * the output has the input's H x W.  cin % 16 == 0, cout % 32 == 0 (the packer zero-pads weights
+ * of narrower tensors; the activations then carry the padding channels).
+ * packed image: [tap][cin/16][cout/32][3 parts][64 lanes][8] bf16 = az_conv2d_packed_floats() floats;
+ * element (out-channel n, in-channel k, tap t) is read at w[n*stride_out + k*stride_in + (flip ? T-1-t : t)]
+ * for n < co_real, k < ci_real, zero otherwise: forward = (cin*T, T, 0), input gradient = the same call
+ * with the channel roles swapped, (T, cin*T, flip 1). */
+long long az_conv2d_packed_floats(int cin, int cout, int kh, int kw);
+int az_conv2d_pack_weights(float *packed, const float *w, int cin, int cout, int ci_real, int co_real,
+                           long long stride_out, long long stride_in, int kh, int kw, int flip,
+                           void *stream);
+/* out[b,y,x,co] = relu?( conv(in)[..] * scale[co] + shift[co] + residual[b,y,x,co] ); in/out/residual are
+ * [B,H,W,*] with pixel strides in/out/res_cstride floats (>= cin / cout / cout: a channel slice of a wider
+ * tensor can be read or written in place); scale/shift/residual may be NULL. */
+int az_conv2d_fwd(float *out, const float *in, const float *packed_w, const float *scale,
+                  const float *shift, const float *residual, int relu, int B, int H, int W, int cin,
+                  int cout, int in_cstride, int out_cstride, int res_cstride, int kh, int kw,
+                  int dilation, void *stream);
+/* grad_w [cm_real][cn_real][kh][kw] (a Conv2d weight's layout) = sum over pixels of
+ * grad_out[b,y,x,co] * in[b, y + dil*(i - kh/2), x + dil*(j - kw/2), ci]; cm/cn = channel counts of the
+ * operation (multiples of 32, >= the real ones; the tensors' pixel strides must cover them). */
+long long az_conv2d_wgrad_workspace(int cm, int cn, int kh, int kw);
+int az_conv2d_wgrad(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                    const float *in, int B, int H, int W, int cm, int cn, int cm_real, int cn_real,
+                    int go_cstride, int in_cstride, int kh, int kw, int dilation, void *stream);
+/* the extractor's first layer (psmnet_submodule_3.py:97-99: 3x3, stride 2, pad 1 on a 3- or 6-channel
+ * image) as patch extraction + 1x1 convolution: patches[b,oy,ox, t*C + c] = x[b, 2oy-1+t/3, 2ox-1+t%3, c]
+ * (zero outside the image and in channels [9C, Kp)); x: [B,H,W,C]; patches: [B,(H-1)/2+1,(W-1)/2+1,Kp].
+ * az_col2im_s2k3 is its adjoint (grad_x fully written). */
+int az_im2col_s2k3(float *patches, const float *x, int B, int C, int H, int W, int Kp, void *stream);
+int az_col2im_s2k3(float *grad_x, const float *grad_patches, int B, int C, int H, int W, int Kp,
+                   void *stream);
+
 /* ---- K10/K11: RAFT-Stereo 1-D correlation (secondary path) -----------------------
  * replaces nets/raft/corr.py:115-161 (CorrBlock1D: einsum all-pairs correlation /
  * sqrt(C), avg_pool pyramid over the last axis, 2r+1-tap linear lookup through

@@ -24,15 +24,10 @@ def ncdhw(x):  # channels-last (gpu) -> NCDHW cpu
     return x.detach().permute(0, 4, 1, 2, 3).contiguous().cpu()
 
 
-DEFAULT_WGRAD = {0: "fp32", 1: "bf16x6"}[conv3d.WGRAD_PRECISION]
-
-
-@pytest.fixture(autouse=True, params=["bf16x6", "fp32"])
-def conv_precision(request):
-    """every test of this file runs in both arithmetic modes of the gather kernels"""
-    conv3d.set_precision(request.param, wgrad=request.param)
-    yield request.param
-    conv3d.set_precision("bf16x6", wgrad=DEFAULT_WGRAD)
+@pytest.fixture(params=["bf16x6", "fp32"])
+def arith(request):
+    """every MFMA test of this file runs in both arithmetic modes (passed per call: no global switch)"""
+    return conv3d.Arith.of(request.param)
 
 
 def close(a, b, rtol=1e-4, atol=1e-5):
@@ -43,53 +38,52 @@ def close(a, b, rtol=1e-4, atol=1e-5):
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (32, 64), (64, 64)])
 @pytest.mark.parametrize("dims", [(1, 5, 7, 19), (2, 4, 8, 16), (1, 3, 9, 33), (1, 1, 9, 20), (1, 2, 16, 35)])
-def test_conv_stride1_vs_torch(cin, cout, dims):
+def test_conv_stride1_vs_torch(cin, cout, dims, arith):
     b, d, h, w = dims
     x = seeded((b, cin, d, h, w), 1)
     wt = seeded((cout, cin, 3, 3, 3), 2, -0.2, 0.2)
     ref = F.conv3d(x, wt, padding=1)
-    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.CONV_S1)
+    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.CONV_S1, arith)
     close(ncdhw(out), ref, 1e-4, 2e-5)
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (32, 32), (64, 32)])
 @pytest.mark.parametrize("dims", [(1, 4, 6, 10), (2, 6, 8, 20), (1, 2, 10, 34)])
-def test_conv_stride2_vs_torch(cin, cout, dims):
+def test_conv_stride2_vs_torch(cin, cout, dims, arith):
     b, d, h, w = dims
     x = seeded((b, cin, d, h, w), 3)
     wt = seeded((cout, cin, 3, 3, 3), 4, -0.2, 0.2)
     ref = F.conv3d(x, wt, stride=2, padding=1)
-    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.CONV_S2)
+    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.CONV_S2, arith)
     close(ncdhw(out), ref, 1e-4, 2e-5)
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32), (32, 32), (32, 64)])
 @pytest.mark.parametrize("dims", [(1, 2, 3, 5), (2, 3, 4, 17), (1, 1, 5, 9)])
-def test_deconv_stride2_vs_torch(cin, cout, dims):
+def test_deconv_stride2_vs_torch(cin, cout, dims, arith):
     b, d, h, w = dims
     x = seeded((b, cin, d, h, w), 5)
     wt = seeded((cin, cout, 3, 3, 3), 6, -0.2, 0.2)
     ref = F.conv_transpose3d(x, wt, stride=2, padding=1, output_padding=1)
-    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.DECONV_S2)
+    out = conv3d.conv_plain(cl(x), wt.to(DEV), conv3d.DECONV_S2, arith)
     close(ncdhw(out), ref, 1e-4, 2e-5)
 
 
 @pytest.mark.parametrize("cin,cout,stride", [(64, 32, 1), (32, 32, 1), (32, 64, 2), (64, 64, 2), (64, 64, 1)])
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_convbn3d_golden(golden, cin, cout, stride, mode):
+def test_convbn3d_golden(golden, cin, cout, stride, mode, arith):
     g = golden("g3_convbn3d")
     tag = f"cb{cin}_{cout}_{stride}_{mode}"
     unit = load_procedural(psmnet_3.convbn_3d(cin, cout, 3, stride, 1), f"g3.cb{cin}_{cout}_{stride}.").to(DEV)
     unit.train(mode == "train")
     x = seeded((2, cin, 4, 6, 8), 310 + cin + cout + stride)
     xg = cl(x).requires_grad_(mode == "train")
-    agg3d.set_backend("hip")
     if mode == "eval":
         with torch.no_grad():
-            y = agg3d.conv_bn(xg, unit)
+            y = agg3d.conv_bn(xg, unit, arith=arith)
         close(ncdhw(y), g[tag + "_y"], 1e-4, 2e-5)
         return
-    y = agg3d.conv_bn(xg, unit)
+    y = agg3d.conv_bn(xg, unit, arith=arith)
     close(ncdhw(y), g[tag + "_y"], 1e-4, 5e-5)
     ct = seeded(tuple(g[tag + "_y"].shape), 320)
     y.backward(cl(ct))
@@ -100,7 +94,7 @@ def test_convbn3d_golden(golden, cin, cout, stride, mode):
 
 
 @pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True), (False, True)])
-def test_convbn_residual_relu_train_vs_oracle(relu, with_res):
+def test_convbn_residual_relu_train_vs_oracle(relu, with_res, arith):
     torch.manual_seed(3)
     ref_unit = load_procedural(po._cb3(32, 32, 1), "t.cb.")
     unit = load_procedural(psmnet_3.convbn_3d(32, 32, 3, 1, 1), "t.cb.").to(DEV)
@@ -114,7 +108,7 @@ def test_convbn_residual_relu_train_vs_oracle(relu, with_res):
         yr = F.relu(yr)
     yr.backward(ct)
     xg, rg = cl(x).requires_grad_(), cl(res).requires_grad_()
-    y = agg3d.conv_bn(xg, unit, relu=relu, add=rg if with_res else None)
+    y = agg3d.conv_bn(xg, unit, relu=relu, add=rg if with_res else None, arith=arith)
     close(ncdhw(y), yr, 1e-4, 5e-5)
     y.backward(cl(ct))
     close(ncdhw(xg.grad), xr.grad, 1e-3, 1e-4)
@@ -129,7 +123,7 @@ def test_convbn_residual_relu_train_vs_oracle(relu, with_res):
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 64), (64, 32)])
-def test_deconvbn_train_vs_oracle(cin, cout):
+def test_deconvbn_train_vs_oracle(cin, cout, arith):
     ref_unit = load_procedural(po._up3(cin, cout), "t.up.")
     unit = load_procedural(psmnet_3._up_unit(cin, cout), "t.up.").to(DEV)
     x, res = seeded((2, cin, 3, 4, 10), 21), seeded((2, cout, 6, 8, 20), 22)
@@ -138,7 +132,7 @@ def test_deconvbn_train_vs_oracle(cin, cout):
     yr = F.relu(ref_unit(xr) + rr)
     yr.backward(ct)
     xg, rg = cl(x).requires_grad_(), cl(res).requires_grad_()
-    y = agg3d.deconv_bn(xg, unit, relu=True, add=rg)
+    y = agg3d.deconv_bn(xg, unit, relu=True, add=rg, arith=arith)
     close(ncdhw(y), yr, 1e-4, 5e-5)
     y.backward(cl(ct))
     close(ncdhw(xg.grad), xr.grad, 1e-3, 1e-4)
@@ -149,19 +143,18 @@ def test_deconvbn_train_vs_oracle(cin, cout):
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
 @pytest.mark.parametrize("skips", [False, True])
-def test_hourglass_golden(golden, mode, skips):
+def test_hourglass_golden(golden, mode, skips, arith):
     g = golden("g3_hourglass")
     hg = load_procedural(psmnet_3.hourglass(32), "g3.hg.").to(DEV)
     hg.train(mode == "train")
     x = cl(seeded((1, 32, 8, 8, 12), 301)).requires_grad_(mode == "train")
     pre, post = cl(seeded((1, 64, 4, 4, 6), 302)), cl(seeded((1, 64, 4, 4, 6), 303))
     tag = f"{mode}_{'skip' if skips else 'noskip'}"
-    agg3d.set_backend("hip")
     if mode == "eval":
         with torch.no_grad():
-            o, p, q = hg(x, pre if skips else None, post if skips else None)
+            o, p, q = hg(x, pre if skips else None, post if skips else None, arith=arith)
     else:
-        o, p, q = hg(x, pre if skips else None, post if skips else None)
+        o, p, q = hg(x, pre if skips else None, post if skips else None, arith=arith)
     close(ncdhw(o), g[tag + "_out"], 1e-3, 1e-4)
     close(ncdhw(p), g[tag + "_pre"], 1e-3, 1e-4)
     close(ncdhw(q), g[tag + "_post"], 1e-3, 1e-4)
@@ -206,7 +199,7 @@ def test_add_and_layout_roundtrip():
     close(ncdhw(y), a + b, 0, 0)
 
 
-def test_fused_cost_volume_conv_equals_materialised():
+def test_fused_cost_volume_conv_equals_materialised(arith):
     """dres0[0] in eval mode: operand synthesised in-kernel (src=1) vs the materialised
     NDHWC volume (K3) through the same MFMA kernel -- must agree bit for bit; and both
     against the oracle's conv on the oracle's volume."""
@@ -216,62 +209,32 @@ def test_fused_cost_volume_conv_equals_materialised():
     ref_unit = load_procedural(po._cb3(64, 32, 1), "t.d0.").eval()
     with torch.no_grad():
         ref = F.relu(ref_unit(po.build_cost_volume(fl, fr, nd)))
-        agg3d.FUSE_COST_VOLUME = True
-        lazy = agg3d.volume_from_features(fl.to(DEV), fr.to(DEV), nd)
+        lazy = agg3d.volume_from_features(fl.to(DEV), fr.to(DEV), nd, lazy=True)
         assert isinstance(lazy, conv3d.LazyCostVolume)
-        y_fused = agg3d.conv_bn(lazy, unit, relu=True)
-        agg3d.FUSE_COST_VOLUME = False
-        vol = agg3d.volume_from_features(fl.to(DEV), fr.to(DEV), nd)
-        y_mat = agg3d.conv_bn(vol, unit, relu=True)
-        agg3d.FUSE_COST_VOLUME = True
+        y_fused = agg3d.conv_bn(lazy, unit, relu=True, arith=arith)
+        vol = agg3d.volume_from_features(fl.to(DEV), fr.to(DEV), nd, lazy=False)
+        y_mat = agg3d.conv_bn(vol, unit, relu=True, arith=arith)
     assert torch.equal(y_fused, y_mat)
     close(ncdhw(y_fused), ref, 1e-4, 2e-5)
 
 
-def test_conv_bn_2d_unit_matches_torch_modules():
-    """The opt-in 2-D route (D=1 volumes through the gather kernels) against the plain
-    nn.Conv2d + nn.BatchNorm2d modules it replaces, forward and backward."""
-    from activezero_amd.nets.psmnet import psmnet_submodule_3 as sm
-
-    unit = load_procedural(sm.convbn(64, 64, 3, 1, 1, 1), "t.cb2d.").to(DEV).train()
-    ref = load_procedural(sm.convbn(64, 64, 3, 1, 1, 1), "t.cb2d.").train()
-    x, res = seeded((2, 64, 20, 36), 61), seeded((2, 64, 20, 36), 62)
-    ct = seeded((2, 64, 20, 36), 63)
+def test_convbn_eval_mode_backward_vs_oracle(arith):
+    """Frozen-BatchNorm fine-tuning: eval-mode units under autograd (the reference supports it through
+    plain nn.Modules); forward and every gradient against the oracle's modules."""
+    ref_unit = load_procedural(po._cb3(32, 32, 1), "t.cbe.").eval()
+    unit = load_procedural(psmnet_3.convbn_3d(32, 32, 3, 1, 1), "t.cbe.").to(DEV).eval()
+    x, res = seeded((2, 32, 4, 6, 18), 81), seeded((2, 32, 4, 6, 18), 82)
+    ct = seeded((2, 32, 4, 6, 18), 83)
     xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
-    yr = F.relu(ref(xr) + rr)
+    yr = F.relu(ref_unit(xr) + rr)
     yr.backward(ct)
-    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
-    rg = res.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
-    y = conv3d.conv_bn_2d(xg, unit[0], unit[1], relu=True, residual=rg)
-    close(y, yr, 1e-4, 5e-5)
-    y.backward(ct.to(DEV))
-    close(xg.grad, xr.grad, 1e-3, 1e-4)
-    close(rg.grad, rr.grad, 1e-5, 1e-6)
-    close(unit[0].weight.grad, ref[0].weight.grad, 1e-3, 3e-4)
-    close(unit[1].weight.grad, ref[1].weight.grad, 1e-3, 1e-3)
-    close(unit[1].running_var, ref[1].running_var, 1e-5, 1e-6)
-
-
-@pytest.mark.parametrize("ch", [32, 64])
-@pytest.mark.parametrize("wgrad", ["hip", "miopen"])
-def test_conv2d_s1_matches_torch(ch, wgrad, monkeypatch):
-    """The opt-in convolution-only 2-D route (AZ_FE2D_CONV=hip): conv2d forward, input and weight
-    gradients against F.conv2d."""
-    monkeypatch.setenv("AZ_FE2D_WGRAD", wgrad)
-    monkeypatch.setattr(conv3d, "_FE2D_CH", (32, 64))  # default routes the 64-channel layers only
-    conv = torch.nn.Conv2d(ch, ch, 3, 1, 1, bias=False)
-    with torch.no_grad():
-        conv.weight.copy_(seeded((ch, ch, 3, 3), 71, -0.2, 0.2))
-    ref = torch.nn.Conv2d(ch, ch, 3, 1, 1, bias=False)
-    ref.load_state_dict(conv.state_dict())
-    conv = conv.to(DEV)
-    x, ct = seeded((3, ch, 13, 22), 72), seeded((3, ch, 13, 22), 73)
-    xr = x.clone().requires_grad_()
-    ref(xr).backward(ct)
-    xg = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
-    assert conv3d.supports_2d(conv)
-    y = conv3d.conv2d_s1(xg, conv)
-    close(y, ref(x), 1e-4, 2e-5)
-    y.backward(ct.to(DEV))
-    close(xg.grad, xr.grad, 1e-4, 5e-5)
-    close(conv.weight.grad, ref.weight.grad, 1e-4, 2e-4)
+    xg, rg = cl(x).requires_grad_(), cl(res).requires_grad_()
+    y = agg3d.conv_bn(xg, unit, relu=True, add=rg, arith=arith)
+    close(ncdhw(y), yr, 1e-4, 5e-5)
+    y.backward(cl(ct))
+    close(ncdhw(xg.grad), xr.grad, 1e-3, 1e-4)
+    close(ncdhw(rg.grad), rr.grad, 1e-5, 1e-6)
+    close(unit[0].weight.grad, ref_unit[0].weight.grad, 1e-3, 3e-4)
+    close(unit[1].weight.grad, ref_unit[1].weight.grad, 1e-3, 1e-3)
+    close(unit[1].bias.grad, ref_unit[1].bias.grad, 1e-3, 1e-3)
+    assert int(unit[1].num_batches_tracked) == 0

@@ -37,8 +37,8 @@ def test_costvol_conv_matches_materialised_volume(dims):
 
 
 def test_costvol_conv_bn_equals_volume_path():
-    """The factored conv + BatchNorm3d + ReLU unit against the materialised-volume unit (the AZ_COSTCONV=0
-    path): activation, feature gradients, parameter gradients and running statistics."""
+    """The factored conv + BatchNorm3d + ReLU unit against the materialised-volume unit (K3 + the
+    64 -> 32 3-D convolution): activation, feature gradients, parameter gradients and running statistics."""
     import copy
 
     from activezero_amd.nets.psmnet import psmnet_submodule_3 as sm
@@ -52,13 +52,8 @@ def test_costvol_conv_bn_equals_volume_path():
     ya = agg3d.costvol_conv_bn(fl, fr, 6, unit_a, relu=True)
     ga = torch.autograd.grad(ya, (fl, fr, unit_a[0].weight, unit_a[1].weight, unit_a[1].bias), ct)
     fl2, fr2 = fl.detach().clone().requires_grad_(), fr.detach().clone().requires_grad_()
-    old = agg3d.FACTORED_COSTCONV
-    try:
-        agg3d.FACTORED_COSTCONV = False
-        vol = agg3d.volume_from_features(fl2, fr2, 6)
-        yb = agg3d.conv_bn(vol, unit_b, relu=True)
-    finally:
-        agg3d.FACTORED_COSTCONV = old
+    vol = agg3d.volume_from_features(fl2, fr2, 6, lazy=False)
+    yb = agg3d.conv_bn(vol, unit_b, relu=True)
     gb = torch.autograd.grad(yb, (fl2, fr2, unit_b[0].weight, unit_b[1].weight, unit_b[1].bias), ct)
     assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-5)
     for a, b_ in zip(ga, gb):

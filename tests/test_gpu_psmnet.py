@@ -16,14 +16,12 @@ T = torch.from_numpy
 
 
 def disp_close(a, b):
-    """North-star tolerance: disparity maps within 1e-3 px of the reference.  The fp32
-    reference itself sits ~3e-4 px (max) from its own fp64 evaluation on this model, so
-    a different-but-valid fp32 summation order can push isolated pixels marginally over:
-    require mean <= 3e-4, 99.9 % of pixels <= 1e-3 and every pixel <= 2e-3."""
+    """North-star tolerance: every pixel of the disparity map within 1e-3 px of the reference (and the
+    mean error well below it).  test_full_model_d192_error_split splits the error against the reference's
+    own fp64 evaluation at the headline disparity range."""
     err = np.abs(a.detach().cpu().numpy().astype(np.float64) - np.asarray(b, np.float64))
-    assert err.mean() <= 3e-4, err.mean()
-    assert np.quantile(err, 0.999) <= 1e-3, np.quantile(err, 0.999)
-    assert err.max() <= 2e-3, err.max()
+    assert err.mean() <= 2e-4, err.mean()
+    assert err.max() <= 1e-3, err.max()
 
 
 def close(a, b, rtol, atol):
@@ -31,12 +29,13 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("arith", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("variant,mod,nin", [("psmnet3", psm3, 3), ("psmnet6", psm6, 6)])
-def test_full_model_matches_reference_goldens(golden, variant, mod, nin):
+def test_full_model_matches_reference_goldens(golden, variant, mod, nin, arith):
     g = golden("g4_" + variant)
     md = int(g["maxdisp"])
     # reference state-dict keys load; BN running stats = the golden's calibrated ones
-    model = load_bn_buffers(load_procedural(mod.PSMNet(md), "g4."), g).to(DEV)
+    model = load_bn_buffers(load_procedural(mod.PSMNet(md), "g4."), g).to(DEV).set_arithmetic(arith)
     imgs = [seeded((2, 3, 256, 256), 400 + i, -2.0, 2.0).to(DEV) for i in range(4)]
     args = imgs[:2] if nin == 3 else imgs
     st = int(g["pred_stride"])
@@ -97,53 +96,45 @@ def test_config0_shape_eval_forward_vs_oracle():
 
 
 def test_feature_extraction_pair_equals_two_sequential_passes():
-    """forward_pair (one pass over the stacked batch, HIP BatchNorm with per-image-set statistics,
-    ReLU / residual fused) against the reference order of operations: feature_extraction(left) then
-    feature_extraction(right) on plain torch modules (psmnet_3.py:145-146).  Features and every
-    BatchNorm's running statistics / batch counter must agree to rounding.  Gradients pass through
-    ~60 train-mode BatchNorms, some over a handful of samples (the 64-pixel SPP branch), which
-    amplifies the rounding differences between MIOpen's batch-2B and batch-B convolution algorithms
-    (two runs of the SAME torch path differ by 1e-2 at 256x320): they are checked in the L2 sense;
-    the exact BatchNorm forward/backward formulas are pinned in test_gpu_bn2d.py."""
-    import copy
-
+    """forward_pair (one pass over the stacked batch on the HIP conv / BatchNorm kernels, statistics per
+    image set) against the reference order of operations: feature_extraction(left) then
+    feature_extraction(right) on plain torch modules (psmnet_3.py:145-146; the oracle's extractor, CPU).
+    Features and every BatchNorm's running statistics / batch counter must agree to rounding.  Gradients
+    pass through ~60 train-mode BatchNorms, some over a handful of samples (the 64-pixel SPP branch), which
+    amplifies rounding differences (two runs of the SAME torch path with different conv algorithms differ
+    by 1e-2 at this size): they are checked in the L2 sense; the exact formulas are pinned per layer in
+    test_gpu_conv2d.py / test_gpu_bn2d.py."""
     from activezero_amd.nets.psmnet import psmnet_submodule_3 as sub
 
     torch.manual_seed(3)
-    fused = sub.FeatureExtraction().to(DEV).to(memory_format=torch.channels_last).train()
-    plain = copy.deepcopy(fused)
-    left = torch.randn(2, 3, 512, 640, device=DEV).contiguous(memory_format=torch.channels_last)
-    right = torch.randn(2, 3, 512, 640, device=DEV).contiguous(memory_format=torch.channels_last)
-    gl, gr = torch.randn(2, 32, 128, 160, device=DEV), torch.randn(2, 32, 128, 160, device=DEV)
-
-    def run(net, backend):
-        old = sub.FE2D_BACKEND
-        sub.FE2D_BACKEND = backend
-        try:
-            a, b = left.clone().requires_grad_(), right.clone().requires_grad_()
-            fa, fb = net.forward_pair(a, b)
-            ((fa * gl).sum() + (fb * gr).sum()).backward()
-            return fa.detach(), fb.detach(), a.grad, b.grad
-        finally:
-            sub.FE2D_BACKEND = old
-
-    got = run(fused, "fused")
-    want = run(plain, "miopen")
-    for g, w in zip(got[:2], want[:2]):
-        assert torch.allclose(g, w, rtol=1e-4, atol=2e-5 * float(w.abs().max())), float((g - w).abs().max())
-    rel = lambda g, w: float((g - w).norm() / (w.norm() + 1e-20))
-    for g, w in zip(got[2:], want[2:]):
-        assert rel(g, w) < 2e-2, rel(g, w)
+    plain = po.FeatureExtractionOracle(3).train()
+    po.reference_init_(plain)
+    fused = sub.FeatureExtraction()
+    fused.load_state_dict(plain.state_dict())
+    fused = fused.to(DEV).train()
+    left, right = torch.randn(2, 3, 256, 320), torch.randn(2, 3, 256, 320)
+    gl, gr = torch.randn(2, 32, 64, 80), torch.randn(2, 32, 64, 80)
+    a, b = left.clone().requires_grad_(), right.clone().requires_grad_()
+    wa, wb = plain(a), plain(b)
+    ((wa * gl).sum() + (wb * gr).sum()).backward()
+    ag, bg = left.to(DEV).requires_grad_(), right.to(DEV).requires_grad_()
+    fa, fb = fused.forward_pair(ag, bg)
+    ((fa * gl.to(DEV)).sum() + (fb * gr.to(DEV)).sum()).backward()
+    for g_, w_ in ((fa, wa), (fb, wb)):
+        g_ = g_.detach().cpu()
+        assert torch.allclose(g_, w_.detach(), rtol=1e-4, atol=2e-5 * float(w_.abs().max())), float((g_ - w_).abs().max())
+    rel = lambda g_, w_: float((g_.cpu() - w_).norm() / (w_.norm() + 1e-20))
+    assert rel(ag.grad, a.grad) < 2e-2 and rel(bg.grad, b.grad) < 2e-2
     want_params = dict(plain.named_parameters())
     for name, p in fused.named_parameters():
         assert rel(p.grad, want_params[name].grad) < 2e-2, (name, rel(p.grad, want_params[name].grad))
     want_buf = dict(plain.named_buffers())
-    for name, b in fused.named_buffers():
-        w = want_buf[name]
-        if b.dtype.is_floating_point:
-            assert torch.allclose(b, w, rtol=1e-5, atol=1e-6), name
+    for name, b_ in fused.named_buffers():
+        w_ = want_buf[name]
+        if b_.dtype.is_floating_point:
+            assert torch.allclose(b_.cpu(), w_, rtol=1e-5, atol=1e-6), name
         else:
-            assert torch.equal(b, w), name  # num_batches_tracked: two updates per BatchNorm
+            assert torch.equal(b_.cpu(), w_), name  # num_batches_tracked: two updates per BatchNorm
 
 
 def test_inference_caches_follow_parameter_updates(golden):
@@ -156,9 +147,8 @@ def test_inference_caches_follow_parameter_updates(golden):
     il, ir = (seeded((2, 3, 256, 256), 400 + i, -2.0, 2.0).to(DEV) for i in range(2))
     with torch.no_grad():
         out1 = model(il, ir).clone()
-        # cached second pass: the same result (not bit-compared: MIOpen may settle on another
-        # algorithm for the extractor's convolutions between its first and second call)
-        assert torch.allclose(model(il, ir), out1, rtol=0, atol=1e-4)
+        # cached second pass: the same kernels on the same operands -> the same bits
+        assert torch.equal(model(il, ir), out1)
         model.dres0[0][0].weight.mul_(1.05)              # Conv3d weight (merged cost-volume kernels)
         model.dres0[2][0].weight.mul_(1.05)              # Conv3d weight (packed-weight cache)
         model.dres1[2][1].running_var.mul_(1.2)          # BatchNorm3d buffer (affine cache)
@@ -172,3 +162,86 @@ def test_inference_caches_follow_parameter_updates(golden):
     d12, d23 = float((out1 - out2).abs().max()), float((out2 - out3).abs().max())
     assert d23 < 1e-3, d23
     assert d12 > 1e-2 and d12 > 10 * d23, (d12, d23)
+
+
+def test_inference_caches_follow_running_stat_updates_by_train_kernels(golden):
+    """The library's own train-mode kernels update running_mean / running_var through raw pointers (no
+    tensor version bump): eval (no_grad), then train-mode forwards WITHOUT an optimizer step, then eval
+    again must use the new statistics (the memo keys hold num_batches_tracked)."""
+    g = golden("g4_psmnet3")
+    md = int(g["maxdisp"])
+    model = load_bn_buffers(load_procedural(psm3.PSMNet(md), "g4."), g).to(DEV).eval()
+    il, ir = (seeded((2, 3, 256, 256), 400 + i, -2.0, 2.0).to(DEV) for i in range(2))
+    with torch.no_grad():
+        out1 = model(il, ir).clone()
+        model.train()
+        for _ in range(3):  # BN re-calibration passes: statistics move, gamma/beta do not
+            model(0.5 * il + 0.3, 0.5 * ir + 0.3)
+        model.eval()
+        out2 = model(il, ir).clone()
+    fresh = psm3.PSMNet(md).to(DEV).eval()
+    fresh.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        out3 = fresh(il, ir)
+    d12, d23 = float((out1 - out2).abs().max()), float((out2 - out3).abs().max())
+    assert d23 < 1e-3, d23
+    assert d12 > 1e-2 and d12 > 10 * d23, (d12, d23)
+
+
+# ---------------------------------------------------------------------------------------------------
+# D = 192 (the headline disparity range): reference fp32 AND fp64 goldens (tools/make_goldens.py g11)
+# ---------------------------------------------------------------------------------------------------
+def _err(a, b):
+    return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+
+
+@pytest.mark.parametrize("arith", ["bf16x6", "fp32"])
+def test_full_model_d192_error_split(golden, arith, capsys):
+    """nets/psmnet/psmnet_3.py:144-220 at maxdisp = 192 on one 256x512 pair (eval + the three train-mode
+    heads) and one 540->544x960 eval forward.  Three numbers per output and arithmetic mode:
+
+        e_hr32 = max |hip - ref32|,  e_hr64 = max |hip - ref64|,  e_rr = max |ref32 - ref64|
+
+    ref64 is the reference evaluated in fp64: e_rr is how far the reference's OWN fp32 evaluation of this
+    network sits from the exact result (0.87e-3 px here: it only just meets 1e-3 against exact arithmetic,
+    so no second fp32 evaluation order can be promised to sit within 1e-3 of it).  Asserted: the HIP path is
+    within the north-star 1e-3 px of the EXACT result, is at least as close to it as the reference's fp32 run
+    (max and mean), and 99.9 % of its pixels are within 1e-3 px of the fp32 reference."""
+    g = golden("g11_psmnet3_d192")
+    md = int(g["maxdisp"])
+    model = load_bn_buffers(load_procedural(psm3.PSMNet(md), "g11."), g).to(DEV).set_arithmetic(arith)
+    il, ir = seeded((1, 3, 256, 512), 1101, -2.0, 2.0).to(DEV), seeded((1, 3, 256, 512), 1102, -2.0, 2.0).to(DEV)
+    big = [torch.nn.functional.pad(seeded((1, 3, 540, 960), 1103 + i, -2.0, 2.0), (0, 0, 4, 0)).to(DEV)
+           for i in range(2)]
+    st, sb = int(g["pred_stride"]), int(g["big_stride"])
+    got = {}
+    with torch.no_grad():
+        model.eval()
+        got["eval"] = model(il, ir)[..., ::st, ::st].cpu().numpy()
+        got["big_eval"] = model(big[0], big[1])[..., ::sb, ::sb].cpu().numpy()
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        model.train()
+        p3, p2, p1 = model(il, ir)
+        got["pred3_"], got["pred2_"], got["pred1_"] = (p[..., ::st, ::st].cpu().numpy() for p in (p3, p2, p1))
+        model.load_state_dict(sd0)
+    report, checks = [], []
+    for k in ("eval", "big_eval", "pred3_", "pred2_", "pred1_"):
+        r32, r64 = g[k + "32"], g[k + "64"]
+        e_hr32, e_hr64, e_rr = _err(got[k], r32), _err(got[k], r64), _err(r32, r64)
+        report.append(f"{arith:7s} {k:9s} max|hip-ref32| {e_hr32.max():.2e}  max|hip-ref64| {e_hr64.max():.2e}  "
+                      f"max|ref32-ref64| {e_rr.max():.2e}   means {e_hr32.mean():.1e} {e_hr64.mean():.1e} {e_rr.mean():.1e}  "
+                      f"p99.9|hip-ref32| {np.quantile(e_hr32, 0.999):.2e}")
+        checks.append((k, e_hr32, e_hr64, e_rr))
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
+    for (k, e_hr32, e_hr64, e_rr), line in zip(checks, report):
+        # (a) the north-star tolerance against the EXACT result
+        assert e_hr64.max() <= 1e-3, line
+        # (b) no further from the exact result than the reference's own fp32 evaluation is (the max over
+        #     ~15 000 sampled pixels is a noisy statistic: 25 % margin on it, 10 % on the mean)
+        assert e_hr64.max() <= 1.25 * e_rr.max() and e_hr64.mean() <= 1.1 * e_rr.mean(), line
+        # (c) against the fp32 reference itself: two fp32 evaluations each within e of the exact result can
+        #     differ by 2e, and the reference's own e is 0.87e-3 here -- so the bar that CAN hold is the
+        #     triangle bound; 99.9 % of the pixels are within the north-star 1e-3 of ref32 anyway
+        assert e_hr32.max() <= e_hr64.max() + e_rr.max() + 1e-6, line
+        assert np.quantile(e_hr32, 0.999) <= 1e-3, line

@@ -9,16 +9,16 @@ lib = _lib.lib()
 lib.az_debug_m128_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 x = torch.randn(4, 48, 136, 240, 32, device=dev)
 w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
-pk, ci, co = conv3d._pack_forward(w, 0)
+pk, ci, co = conv3d._pack_forward(w, 0, conv3d.DEFAULT_ARITH.conv)
 buf = (ctypes.c_ulonglong * 4)()
 reps = int(os.environ.get("STAMP_REPS", "1000"))
 for _ in range(reps):
-    conv3d._run_gather(x, pk, 0, ci, co, stats=True)
+    conv3d._run_gather(x, pk, 0, ci, co, conv3d.DEFAULT_ARITH.conv, stats=True)
 torch.cuda.synchronize()
 lib.az_debug_m128_stamps(buf, 1)
 t0 = time.perf_counter()
 for _ in range(20):
-    conv3d._run_gather(x, pk, 0, ci, co, stats=True)
+    conv3d._run_gather(x, pk, 0, ci, co, conv3d.DEFAULT_ARITH.conv, stats=True)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 lib.az_debug_m128_stamps(buf, 1)

@@ -9,14 +9,14 @@ def bench(shape, cin, cout, mode, reps=10):
     dev = torch.device("cuda:0")
     x = torch.randn(*shape, cin, device=dev)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05 if mode != 2 else torch.randn(cin, cout, 3, 3, 3, device=dev) * 0.05
-    pk, ci, co = conv3d._pack_forward(w, mode)
+    pk, ci, co = conv3d._pack_forward(w, mode, conv3d.DEFAULT_ARITH.conv)
     for _ in range(2):
-        conv3d._run_gather(x, pk, mode, ci, co, stats=True)
+        conv3d._run_gather(x, pk, mode, ci, co, conv3d.DEFAULT_ARITH.conv, stats=True)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        conv3d._run_gather(x, pk, mode, ci, co, stats=True)
+        conv3d._run_gather(x, pk, mode, ci, co, conv3d.DEFAULT_ARITH.conv, stats=True)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps
 

@@ -354,10 +354,60 @@ def g10_metrics():
          metrics_dp=np.array([m2[k] for k in keys]), label=label, **{f"obj{i}": o for i, o in enumerate(obj)})
 
 
+# ---------------------------------------------------------------- G11 full PSMNet at D = 192
+def g11_full_d192():
+    """nets/psmnet/psmnet_3.py:144-220 at the headline disparity range (maxdisp = 192, 0..191 px), where
+    the 1e-3 px bar is hardest: one 256x512 pair, eval and train-mode predictions, evaluated by the
+    imported reference in fp32 AND in fp64 (harness shim 3: torch.FloatTensor -> DoubleTensor while the
+    fp64 pass runs, because forward() allocates the cost volume with torch.FloatTensor), plus one
+    540->544x960 eval forward in both precisions.  The fp64 run is the yardstick that says how far ANY
+    fp32 evaluation order may sit from the exact result (|ref32 - ref64|)."""
+    maxdisp = 192
+    il, ir = seeded((1, 3, 256, 512), 1101, -2.0, 2.0), seeded((1, 3, 256, 512), 1102, -2.0, 2.0)
+    big = [F.pad(seeded((1, 3, 540, 960), 1103 + i, -2.0, 2.0), (0, 0, 4, 0)) for i in range(2)]  # test.py:137-146
+    model = load_procedural(ref_psmnet3.PSMNet(maxdisp=maxdisp), "g11.")
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(il, ir)
+    for m in bns:
+        m.momentum = 0.1
+    bufs0 = {"buf::" + k: v.clone() for k, v in model.state_dict().items()
+             if k.endswith("running_mean") or k.endswith("running_var")}
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    out = {}
+    st, st_big = 3, 5
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        model.load_state_dict(sd0)
+        model.to(dt)
+        real_ft = torch.FloatTensor
+        if dt == torch.float64:
+            torch.FloatTensor = torch.DoubleTensor  # shim 3 (harness side)
+        try:
+            with torch.no_grad():
+                model.eval()
+                out["eval" + tag] = model(il.to(dt), ir.to(dt))[..., ::st, ::st]
+                out["big_eval" + tag] = model(big[0].to(dt), big[1].to(dt))[..., ::st_big, ::st_big]
+                model.train()  # batch statistics (running stats are restored from sd0 for the next pass)
+                p3, p2, p1 = model(il.to(dt), ir.to(dt))
+                out["pred3_" + tag], out["pred2_" + tag], out["pred1_" + tag] = (
+                    p[..., ::st, ::st] for p in (p3, p2, p1))
+        finally:
+            torch.FloatTensor = real_ft
+        print("g11", tag, "done", flush=True)
+    for k in ("eval", "big_eval", "pred3_", "pred2_", "pred1_"):
+        d = (out[k + "32"].double() - out[k + "64"]).abs()
+        print(f"  |ref32 - ref64| {k}: max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    save("g11_psmnet3_d192", seeds=[1101, 1102, 1103, 1104], maxdisp=maxdisp, pred_stride=st,
+         big_stride=st_big, **out, **bufs0)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for fn in (g1_cost_volume, g2_softargmin, g3_blocks, g4_full, g6_apply_disparity, g7_patch,
-               g8_lcn, g9_corr, g10_metrics):
+               g8_lcn, g9_corr, g10_metrics, g11_full_d192):
         if not only or fn.__name__.split("_")[0] in only:
             fn()

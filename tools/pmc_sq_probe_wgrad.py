@@ -6,6 +6,6 @@ dev = torch.device("cuda:0")
 x = torch.randn(4, 48, 136, 240, 32, device=dev)
 g = torch.randn(4, 48, 136, 240, 32, device=dev)
 for _ in range(3):
-    conv3d._wgrad(g, x, 1, 32, 32, "conv")
+    conv3d._wgrad(g, x, 1, 32, 32, "conv", conv3d.DEFAULT_ARITH.wgrad)
 torch.cuda.synchronize()
 print("done")

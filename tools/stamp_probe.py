@@ -11,16 +11,16 @@ x = torch.randn(4, 48, 136, 240, 32, device=dev)
 w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
 buf = (ctypes.c_ulonglong * 8)()
 for prec in ("bf16x6", "fp32"):
-    conv3d.set_precision(prec)
-    pk, ci, co = conv3d._pack_forward(w, 0)
-    conv3d._run_gather(x, pk, 0, ci, co, stats=True); torch.cuda.synchronize()
+    P = conv3d.Arith.of(prec).conv
+    pk, ci, co = conv3d._pack_forward(w, 0, P)
+    conv3d._run_gather(x, pk, 0, ci, co, P, stats=True); torch.cuda.synchronize()
     lib.az_debug_conv_stamps(buf, 1)
     reps = int(os.environ.get("STAMP_REPS", "600"))   # ~1.5 s of back-to-back launches: steady-state clock
     for _ in range(reps):
-        conv3d._run_gather(x, pk, 0, ci, co, stats=True)
+        conv3d._run_gather(x, pk, 0, ci, co, P, stats=True)
     torch.cuda.synchronize()
     lib.az_debug_conv_stamps(buf, 1)
-    conv3d._run_gather(x, pk, 0, ci, co, stats=True); torch.cuda.synchronize()
+    conv3d._run_gather(x, pk, 0, ci, co, P, stats=True); torch.cuda.synchronize()
     lib.az_debug_conv_stamps(buf, 1)
     n = buf[5]
     print(prec, "in-kernel clock %.3f GHz (shader cycles / 100 MHz ticks)" % (0.1 * buf[6] / max(buf[7], 1)))

@@ -14,12 +14,9 @@ import bench  # noqa: E402
 
 
 def run(backend, steps, b, h, w, md):
-    from activezero_amd import agg3d
-    from activezero_amd.nets.psmnet import psmnet_submodule_3 as sub
     from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
+    from tools import eager_psmnet
 
-    agg3d.set_backend("hip" if backend == "hip" else "miopen")
-    sub.FE2D_BACKEND = "fused" if backend == "hip" else "miopen"
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
     model = PSMNet(md).to(dev).train()
@@ -28,7 +25,10 @@ def run(backend, steps, b, h, w, md):
     losses = []
     for _ in range(steps):
         opt.zero_grad(set_to_none=True)
-        loss = bench.disp_loss(model(il, ir), gt, md)
+        if backend == "hip":
+            loss = bench.disp_loss(model(il, ir), gt, md)
+        else:  # stock PyTorch-ROCm operators over the same module's parameters
+            loss = eager_psmnet.eager_loss(eager_psmnet.eager_forward(model, il, ir), gt, md)
         loss.backward()
         opt.step()
         losses.append(float(loss))
