@@ -42,18 +42,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // stride-2 map the kernel takes the 1-wave/SIMD budget (512 registers) and prefetches the
 // weights one tap ahead; otherwise 2 waves/SIMD without weight prefetch.
 #define X6_WIDE(COUT, MODE, PREC) ((PREC) == 1 && (((COUT) == 64 && (MODE) != 2) || (MODE) == 1))
-// Experiment (-DT2Q_ENABLE=1, off): transposed conv, bf16x6, 32 output channels -- one wave owns the FOUR
-// (ph, pw) output-parity phases of its coarse patch for a given pd.  The phases read the same coarse
-// slab; with a wave per phase it is staged four times and the lightest phase runs 24 MFMAs per staged
-// slab.  Each of the nine (kh, kw) taps belongs to exactly one phase, so the stage loop is the plain
-// nine-tap loop with the accumulator chosen by the tap.  It needs 4 x MR accumulator tiles, i.e. the
-// 1-wave/SIMD register budget, and that costs what the sharing saves: 64->32 V1->V0 0.89 vs 1.00 ms
-// standalone, but 1.14 vs 1.08 ms as input gradient inside the step (156.5 vs 156.8 ms/step) and the
-// eval forward (affine + residual epilogue, nothing to overlap it with) 13.9 vs 13.3 ms.
-#ifndef T2Q_ENABLE
-#define T2Q_ENABLE 0
-#endif
-#define X6_T2Q(COUT, MODE, PREC) (T2Q_ENABLE && (PREC) == 1 && (MODE) == 2 && (COUT) == 32)
+// (Measured and dropped: one wave owning the four (ph, pw) output-parity phases of a transposed-conv patch so that
+//  their common coarse slab is staged once -- it needs the 1-wave/SIMD register budget and that costs what the
+//  sharing saves: 64->32 V1->V0 0.89 vs 1.00 ms standalone, 156.5 vs 156.8 ms per step.)
 // (Tried and dropped: a 3-deep register ring streaming the weights two taps ahead under the
 //  1-wave/SIMD budget for every shape -- 2.76 ms vs 2.2 ms on 32->32: one wave per SIMD cannot
 //  hide its own commit / epilogue phases, and the fully unrolled ring spills into AGPRs.)
@@ -78,7 +69,7 @@ __device__ unsigned long long cv_stamp_sum[8];
 #include "az_conv3d_args.h"
 
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
-__global__ void __launch_bounds__(64, (X6_WIDE(COUT, MODE, PREC) || X6_T2Q(COUT, MODE, PREC)) ? 1 : 2)
+__global__ void __launch_bounds__(64, X6_WIDE(COUT, MODE, PREC) ? 1 : 2)
 conv3d_gather_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32, NR = COUT / 32;
     constexpr int MR = (MODE == 1) ? 1 : 2;
@@ -117,12 +108,8 @@ conv3d_gather_kernel(const ConvArgs a) {
         const int nblk = gridDim.x, xcd = blockIdx.x & 7, q8 = nblk >> 3, r8 = nblk & 7;
         lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     }
-    constexpr bool T2Q = X6_T2Q(COUT, MODE, PREC);
-    constexpr int NPH = T2Q ? 4 : 1;  // output-parity phases owned by this wave
     int pd = 0, ph = 0, pw = 0;
-    if (T2Q) {
-        pd = lin & 1; lin >>= 1;       // (ph, pw) are enumerated inside
-    } else if (MODE == 2) {
+    if (MODE == 2) {
         const int phase = lin & 7; lin >>= 3;
         pd = phase >> 2; ph = (phase >> 1) & 1; pw = phase & 1;
     }
@@ -152,17 +139,17 @@ conv3d_gather_kernel(const ConvArgs a) {
     const int ih0 = (MODE == 0) ? ty0 - 1 : (MODE == 1) ? 2 * ty0 - 1 : ty0;
     const int iw0 = (MODE == 0) ? tx0 - 1 : (MODE == 1) ? 2 * tx0 - 1 : tx0;
 
-    f32x16 acc[NPH * MR][NR];  // T2Q: tiles of phase q = ph*2+pw at [q*MR, q*MR+MR)
+    f32x16 acc[MR][NR];
 #pragma unroll
-    for (int m = 0; m < NPH * MR; ++m)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int n = 0; n < NR; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
     const int nd = (MODE == 2) ? 1 + pd : 3;
-    const int nh = (MODE == 2 && !T2Q) ? 1 + ph : 3;
-    const int nw = (MODE == 2 && !T2Q) ? 1 + pw : 3;
+    const int nh = (MODE == 2) ? 1 + ph : 3;
+    const int nw = (MODE == 2) ? 1 + pw : 3;
     const int row = lane & 31, half = lane >> 5;
     const int rty = row >> 3, rtx = row & 7;
     const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
@@ -173,11 +160,8 @@ conv3d_gather_kernel(const ConvArgs a) {
     // stage s run; weights are fetched one tap ahead.
     constexpr int NQ = SY * SX * 8;          // float4 pieces of one slab
     constexpr int NLD = (NQ + 63) / 64;      // pieces per lane
-    #ifndef X6_BPIPE_NR1
-#define X6_BPIPE_NR1 0
-#endif
-    constexpr bool ASINGLE = X6_BPIPE_NR1 && PREC == 1 && NR == 1 && MR == 2 && !X6_WIDE(COUT, MODE, PREC);
-    constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : (X6_WIDE(COUT, MODE, PREC) || ASINGLE || T2Q);
+    constexpr bool WIDE = X6_WIDE(COUT, MODE, PREC);
+    constexpr bool BPIPE = (PREC == 0) ? (NR == 1) : WIDE;
     // stages cover only the input planes that exist (a contiguous sd range): a zero-padding plane
     // contributes nothing, so neither its slab nor its split / LDS traffic is spent -- matters at the
     // depth borders and, above all, for depth-1 volumes (the extractor's 2-D layers: 1 plane of 3)
@@ -265,11 +249,6 @@ conv3d_gather_kernel(const ConvArgs a) {
     const int ntaps = nh * nw;
     auto tap_of = [&](int kd, int t, int &eh, int &ew) -> int {
         const int sh = t / nw, sw = t - sh * nw;
-        if (T2Q) {  // tap (kh, kw) = (sh, sw): k = 1 -> parity 0, source offset 0; k = 2 -> parity 1, offset 0; k = 0 -> parity 1, offset 1
-            eh = (sh == 0) ? 1 : 0;
-            ew = (sw == 0) ? 1 : 0;
-            return (kd * 3 + sh) * 3 + sw;
-        }
         const int kh = (MODE == 2) ? (ph ? 2 - 2 * sh : 1) : sh;
         const int kw = (MODE == 2) ? (pw ? 2 - 2 * sw : 1) : sw;
         eh = (MODE == 2) ? (ph ? sh : 0) : sh;
@@ -295,10 +274,19 @@ conv3d_gather_kernel(const ConvArgs a) {
                 aq[f] = *reinterpret_cast<const float4 *>(((f & 1) ? ap1 : ap0) + (f >> 1) * 16);
         }
     };
+    // bf16x6: an MFMA rounds (and floors what it shifts out of) its accumulator at the accumulator's magnitude,
+    // so the running sums are kept short (az_common.h).  Two forms:
+    //   * two waves per SIMD (NR = 1): every 16-deep K block is summed in a zero-initialised temporary and added
+    //     to the accumulator with VALU adds (az_mfma6_now);
+    //   * WIDE kernels (one wave per SIMD, > 256 registers: hipcc keeps temporaries in AGPRs, which VALU adds can
+    //     only reach through v_accvgpr_read -- measured +29 % on the 64->64 layers): the MFMAs of one STAGE
+    //     (slab: 9 taps x 2 blocks) chain into a per-stage temporary `ts`, which is added to the accumulator once
+    //     per stage.  The chain inside a stage is 18 blocks long instead of the whole K (108 blocks for 64->64).
+    f32x16 ts[MR][NR];  // (dead unless WIDE)
     auto mfma16 = [&](f32x16 (&c)[NR], const float4 (&aq)[NF], const float4 (&bw)[NR][NF]) {
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
-            if (PREC == 0) {
+            if constexpr (PREC == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].x, bw[n][j].x, c[n], 0, 0, 0);
@@ -307,19 +295,11 @@ conv3d_gather_kernel(const ConvArgs a) {
                     c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
                 }
             } else {
-                // fp32 product on the bf16 pipe: six v_mfma_f32_32x32x16_bf16 per 16-deep K block, summed in a
-                // zero-initialised temporary so that the accumulator is rounded once per block
-                // (az_common.h az_mfma6_step); the second block's MFMAs cover the first block's adds
                 const float4 a0q[3] = {aq[0], aq[2], aq[4]}, a1q[3] = {aq[1], aq[3], aq[5]};
                 const float4 b0q[3] = {bw[n][0], bw[n][2], bw[n][4]}, b1q[3] = {bw[n][1], bw[n][3], bw[n][5]};
-                if (X6_WIDE(COUT, MODE, PREC)) {  // one wave per SIMD, registers to spare: overlap adds and MFMAs
-                    f32x16 ta, tb;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) ta[e] = 0.f;
-                    az_mfma6_step(tb, a0q, b0q, c[n], ta);   // block kb = 0 (adds zeros: keeps one code shape)
-                    az_mfma6_step(ta, a1q, b1q, c[n], tb);   // block kb = 1, c += block 0
-                    c[n] += ta;                              // block 1: waits for its last MFMA
-                    asm volatile("" : "+v"(c[n]));
+                if (WIDE) {  // c = the stage temporary
+                    az_mfma6(c[n], a0q, b0q);
+                    az_mfma6(c[n], a1q, b1q);
                 } else {  // two waves per SIMD at the register limit: one temporary, the partner wave fills the gap
                     az_mfma6_now(c[n], a0q, b0q);
                     az_mfma6_now(c[n], a1q, b1q);
@@ -357,24 +337,6 @@ conv3d_gather_kernel(const ConvArgs a) {
         auto tap_body = [&](int t, float4 (&cur)[NR][NF], float4 (&nxt)[NR][NF]) {
             int eh_, ew_, eh2 = 0, ew2 = 0;
             const int tap = tap_of(kd, t, eh_, ew_);
-            // T2Q: the tap's phase selects the accumulator tiles (t is a compile-time constant there)
-            const int qb = T2Q ? ((((t / 3) != 1) ? 2 : 0) + (((t % 3) != 1) ? 1 : 0)) * MR : 0;
-            if (ASINGLE) {
-                // weights double-buffered, A fragments single-buffered: the exposed LDS latency
-                // (twice per tap) is covered by the SIMD's other wave, the L2 latency of the
-                // weights (several times longer) by this wave's own MFMAs
-                if (t + 1 < ntaps) load_b(nxt, tap_of(kd, t + 1, eh2, ew2), cc);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(acc[qb], a0, cur);
-                __builtin_amdgcn_sched_barrier(0);
-                load_a(a0, 1, eh_, ew_);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma16(acc[qb + MR - 1], a0, cur);
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < ntaps) load_a(a0, 0, eh2, ew2);
-                __builtin_amdgcn_sched_barrier(0);
-                return;
-            }
             if (MR == 2) load_a(a1, 1, eh_, ew_);
             if (t + 1 < ntaps) {
                 const int tap2 = tap_of(kd, t + 1, eh2, ew2);
@@ -384,21 +346,22 @@ conv3d_gather_kernel(const ConvArgs a) {
             // hipcc otherwise sinks the LDS reads next to their consumers (register pressure)
             // and every MFMA quad then waits on a just-issued ds_read: pin the written order
             __builtin_amdgcn_sched_barrier(0);
-            mfma16(acc[qb], a0, cur);
+            if constexpr (PREC == 1 && WIDE) mfma16(ts[0], a0, cur); else mfma16(acc[0], a0, cur);
             __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < ntaps) load_a(a0, 0, eh2, ew2);
             __builtin_amdgcn_sched_barrier(0);
-            if (MR == 2) mfma16(acc[qb + MR - 1], a1, cur);
+            if constexpr (MR == 2) { if constexpr (PREC == 1 && WIDE) mfma16(ts[MR - 1], a1, cur); else mfma16(acc[MR - 1], a1, cur); }
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (T2Q) {  // nine taps, fully unrolled: the accumulator index must be static
-            float4 bq2[NR][NF];
+        if (PREC == 1 && WIDE) {
 #pragma unroll
-            for (int t = 0; t < 9; t += 2) {
-                tap_body(t, bq, bq2);
-                if (t + 1 < 9) tap_body(t + 1, bq2, bq);
-            }
-        } else if (BPIPE) {
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int n = 0; n < NR; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ts[m][n][e] = 0.f;
+        }
+        if (BPIPE) {
             float4 bq2[NR][NF];
             for (int t = 0; t < ntaps; t += 2) {
                 tap_body(t, bq, bq2);
@@ -406,6 +369,12 @@ conv3d_gather_kernel(const ConvArgs a) {
             }
         } else {
             for (int t = 0; t < ntaps; ++t) tap_body(t, bq, bq);
+        }
+        if (PREC == 1 && WIDE) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int n = 0; n < NR; ++n) acc[m][n] += ts[m][n];
         }
         CV_ACC(3);
     }
@@ -420,11 +389,10 @@ conv3d_gather_kernel(const ConvArgs a) {
     const size_t plane_el = (((size_t)b * a.Do + od) * a.Ho) * a.Wo * COUT;
     float *outp = a.out + plane_el;
     const float *resp = a.res ? a.res + plane_el : nullptr;
-#pragma unroll
-    for (int q = 0; q < NPH; ++q) {
+    {
     const int ohs = (MODE == 2) ? 2 : 1;  // output step per index-space step
-    const int phq = T2Q ? (q >> 1) : ph, pwq = T2Q ? (q & 1) : pw;  // this pass's output-parity phase
-    const int tile_q = tile_id + (T2Q ? q : 0), qb = q * MR;
+    const int phq = ph, pwq = pw;
+    const int tile_q = tile_id, qb = 0;
     const int oh_base = (MODE == 2) ? 2 * ty0 + phq : ty0, ow_base = (MODE == 2) ? 2 * tx0 + pwq : tx0;
     const bool full = (oh_base + ohs * (TY - 1) < a.Ho) && (ow_base + ohs * (TX - 1) < a.Wo);
     // offset (in floats) of accumulator register r of M-tile m, and its validity
@@ -560,7 +528,7 @@ conv3d_pack_x6_kernel(unsigned short *__restrict__ dst, const float *__restrict_
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
 static int launch_conv(const ConvArgs &a, hipStream_t s) {
     long long blocks = (long long)a.B * a.Dt * a.tiles_y * a.tiles_x *
-                       (MODE == 2 ? (X6_T2Q(COUT, MODE, PREC) ? 2 : 8) : 1);
+                       (MODE == 2 ? 8 : 1);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     hipLaunchKernelGGL((conv3d_gather_kernel<CIN, COUT, MODE, EPI, SRC, PREC>),
                        dim3((unsigned)blocks), dim3(64), 0, s, a);

