@@ -68,6 +68,8 @@ _SIGS = {
     "az_conv2d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 12 + [_PTR],
     "az_im2col_s2k3": [_PTR, _PTR] + [_INT] * 5 + [_PTR],
     "az_col2im_s2k3": [_PTR, _PTR] + [_INT] * 5 + [_PTR],
+    "az_ir_pattern_workspace": [_INT] * 4,
+    "az_ir_pattern": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 4 + [_C.c_float, _PTR],
     "az_corr1d_volume": [_PTR] * 3 + [_INT] * 5 + [_PTR],
     "az_corr1d_volume_bwd": [_PTR] * 5 + [_INT] * 5 + [_PTR],
     "az_corr1d_pool": [_PTR, _PTR, _LL, _INT, _PTR],
@@ -78,7 +80,7 @@ _SIGS = {
 _RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_packed_floats": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL,
             "az_bn3d_stats_tiles": _LL, "az_bn2d_workspace": _LL,
-            "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL}
+            "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL, "az_ir_pattern_workspace": _LL}
 
 
 def declared_symbols():

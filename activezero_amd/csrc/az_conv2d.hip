@@ -151,6 +151,8 @@ conv2d_same_kernel(const C2Args a) {
     for (int e = 0; e < 16; ++e) { t0[e] = 0.f; t1[e] = 0.f; }
     // block `cur` of the rotation 0,1,2,3: multiply into tn, complete accumulator (cur+3)%4 with tp
     auto step = [&](int cur, f32x16 &tn, const f32x16 &tp, const float4 (&aq)[3], const float4 (&bq)[3]) {
+        // (price of the temporaries, measured against the plain six-MFMA chain into acc: +2.4 % on the
+        //  extractor's forward, 10.09 vs 9.85 ms; profiles/r02_conv2d_layers_hip.txt)
         if (PIPE) az_mfma6_step(tn, aq, bq, acc[(cur + 3) & 3], tp);
         else az_mfma6_now(acc[cur], aq, bq);
     };

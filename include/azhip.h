@@ -264,6 +264,15 @@ int az_im2col_s2k3(float *patches, const float *x, int B, int C, int H, int W, i
 int az_col2im_s2k3(float *grad_x, const float *grad_patches, int B, int C, int H, int W, int Kp,
                    void *stream);
 
+/* ---- K14: IR dot-pattern extraction (data side) ------------------------------------------
+ * replaces datasets/dataset_utils.py:33-46 get_smoothed_ir_pattern2(img_ir, img, ks, threshold) as called by
+ * datasets/messytable.py:406-426: pattern = 1 where the min-max normalised |img_ir - img| exceeds its
+ * cv2 INTER_AREA shrink (by ks) / enlarge round trip by more than `threshold`, else 0.
+ * img_ir, img, pattern: [B,H,W] f32; workspace of az_ir_pattern_workspace() bytes. */
+long long az_ir_pattern_workspace(int B, int H, int W, int ks);
+int az_ir_pattern(float *pattern, float *workspace, long long workspace_bytes, const float *img_ir,
+                  const float *img, int B, int H, int W, int ks, float threshold, void *stream);
+
 /* ---- K10/K11: RAFT-Stereo 1-D correlation (secondary path) -----------------------
  * replaces nets/raft/corr.py:115-161 (CorrBlock1D: einsum all-pairs correlation /
  * sqrt(C), avg_pool pyramid over the last axis, 2r+1-tap linear lookup through
