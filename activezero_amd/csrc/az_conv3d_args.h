@@ -20,3 +20,7 @@ struct ConvArgs {
 
 // bf16x6, stride-1, 32 output channels, 8x16-voxel tile per wave (az_conv3d_m128.hip)
 int az_conv3d_m128_launch(const ConvArgs &a, int cin, int epi, int src, hipStream_t s);
+
+// bf16x6, stride-2 transposed, 32 output channels: one workgroup owns all 8 output-parity phases of a coarse
+// patch (az_conv3d_t2.hip)
+int az_conv3d_t2_launch(const ConvArgs &a, int cin, int epi, hipStream_t s);
