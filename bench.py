@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--eager-steps", type=int, default=1,
                     help="timed steps of the same workload on stock PyTorch-ROCm operators (tools/eager_psmnet.py) "
                          "after the measurement, rank 0 at N=1 only: the 'PyTorch-eager' denominator; 0 = skip")
+    ap.add_argument("--eager-batch", type=int, default=1, help="pairs per PyTorch-eager step")
     ap.add_argument("--cpu-sample", choices=["full", "crop"], default="crop")
     ap.add_argument("--dist-backend", default="nccl",
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --single-device)")
@@ -142,10 +143,15 @@ def cpu_baseline(args):
 def eager_gpu(args, model, il, ir, gt, device):
     """The same supervised step on stock PyTorch-ROCm operators over the same module (tools/eager_psmnet.py):
     the 'PyTorch-eager' denominator of the north-star target.  MIOpen find mode stays off (an exhaustive
-    search for the 3-D convolutions takes minutes; the reference would amortise it over an epoch)."""
+    search for the 3-D convolutions takes minutes; the reference would amortise it over an epoch).  ONE pair
+    per step (a step of 4 takes 11.6 s and MIOpen's first-call solver evaluation as long again: the default
+    run must finish within minutes); eager pairs/s does not depend on the batch size (measured at B = 4:
+    0.345 pairs/s, profiles/r02_bench_default_b4_eager4.json)."""
     from tools import eager_psmnet
 
     torch.backends.cudnn.benchmark = False
+    if args.eager_batch < il.shape[0]:
+        il, ir, gt = (t[:args.eager_batch].contiguous() for t in (il, ir, gt))
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
 
     def step():
@@ -161,7 +167,8 @@ def eager_gpu(args, model, il, ir, gt, device):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.eager_steps
-    return {"value": args.batch / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "steps": args.eager_steps,
+    return {"value": il.shape[0] / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "steps": args.eager_steps,
+            "batch": il.shape[0],
             "what": "same model/data/step through stock PyTorch-ROCm operators (MIOpen conv2d/conv3d, ATen "
                     "batch_norm/interpolate/softmax), cudnn.benchmark off, 1 warm-up step"}
 

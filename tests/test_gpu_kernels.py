@@ -323,3 +323,31 @@ def test_lcn_full_size_flat_and_oracle():
     close(s, rs, 1e-4, 1e-6)
     close(n, rn, 1e-3, 1e-3)
     assert s[0, 0, 110:190, 110:290].abs().max().item() == 0.0
+
+
+def test_dispatcher_ops_match_the_python_wrappers():
+    """torch.ops.azhip.* (activezero_amd/torch_ops.py) against activezero_amd.ops on the same inputs,
+    values and gradients"""
+    import activezero_amd.torch_ops  # noqa: F401
+
+    lg = (3 * seeded((2, 6, 5, 7), 901)).to(DEV)
+    a, b = lg.clone().requires_grad_(), lg.clone().requires_grad_()
+    pa, pb = torch.ops.azhip.softargmin(a), ops.softargmin(b)
+    assert torch.equal(pa, pb)
+    ct = seeded(tuple(pa.shape), 902).to(DEV)
+    pa.backward(ct); pb.backward(ct)
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-5)  # (float atomics: last-bit run-to-run differences)
+    fl, fr = seeded((2, 32, 6, 20), 903).to(DEV), seeded((2, 32, 6, 20), 904).to(DEV)
+    x, y = fl.clone().requires_grad_(), fr.clone().requires_grad_()
+    v = torch.ops.azhip.cost_volume(x, y, 5)
+    assert torch.equal(v, ops.cost_volume(fl, fr, 5))
+    v.backward(torch.ones_like(v))
+    x2, y2 = fl.clone().requires_grad_(), fr.clone().requires_grad_()
+    ops.cost_volume(x2, y2, 5).backward(torch.ones_like(v))
+    assert torch.equal(x.grad, x2.grad) and torch.equal(y.grad, y2.grad)
+    img, dsp = seeded((2, 3, 9, 17), 905).to(DEV), seeded((2, 1, 9, 17), 906, -3, 3).to(DEV)
+    d1, d2 = dsp.clone().requires_grad_(), dsp.clone().requires_grad_()
+    w1, w2 = torch.ops.azhip.warp_gather(img, d1), ops.warp_gather(img, d2)
+    assert torch.equal(w1, w2)
+    w1.sum().backward(); w2.sum().backward()
+    assert torch.equal(d1.grad, d2.grad)
