@@ -13,7 +13,7 @@
 // (dst = 4k+r): r0 -> (.375,.625) of (k-1,k), r1 -> (.125,.875), r2 -> (.875,.125)
 // of (k,k+1), r3 -> (.625,.375); border indices clamp (PyTorch
 // area_pixel_compute_source_index + min(i0+1, size-1)).
-// Algorithmic HBM bytes per head: 4*(d*h*w + H*W); the kernel is VALU/exp bound.
+// Algorithmic HBM bytes per head: 4*(d*h*w + H*W); the kernel is VALU-issue bound (see sa_stats_planes).
 //
 // Backward reads the per-pixel softmax shift / normaliser the forward saved (8 B per pixel; it
 // recomputes them when given none), forms
@@ -69,41 +69,91 @@ __device__ __forceinline__ float sa_plane(const float *tile, int k, const SaPix 
     return wy0 * (wx0 * a00 + p.wx1 * a01) + p.wy1 * (wx0 * a10 + p.wx1 * a11);
 }
 
-// softmax statistics of one pixel: M (shift), s = sum exp, t = sum D*exp
-__device__ __forceinline__ void sa_stats(const float *tile, int d, const SaPix &p, float &M,
-                                         float &s, float &t) {
-    // exact maximum of the UPSAMPLED logits (what F.softmax subtracts): the plane
-    // values at both ends and, per plane pair, the two outer lerp phases.
-    float v0 = sa_plane(tile, 0, p);
-    M = v0;
-    for (int k = 0; k + 1 < d; ++k) {
-        const float v1 = sa_plane(tile, k + 1, p);
-        M = fmaxf(M, fmaxf((1.f - 0.125f) * v0 + 0.125f * v1, (1.f - 0.875f) * v0 + 0.875f * v1));
-        v0 = v1;
-    }
-    M = fmaxf(M, v0);
-    s = 0.f;
-    t = 0.f;
-    v0 = sa_plane(tile, 0, p);
+// softmax statistics of one pixel: M (shift), s = sum exp, t = sum D*exp.
+// The counters of the first version (profiles/r02_sq_softargmin_patch_reproj.md: 5 245 VALU instructions per
+// pixel = 27 per disparity, 61 % of wave cycles in dependent-issue stalls) shaped this one:
+//   * every plane value v_k (a bilinear read of the LDS tile, ~11 instructions) is evaluated ONCE and kept in
+//     registers (48 planes at D = 192) instead of once per pass;
+//   * the shift stays the exact maximum of the upsampled logits, taken from the registers;
+//   * planes are pre-scaled once, v'_k = (v_k - M) * log2(e); the lerp is linear, so exp(u - M) = exp2(lerp(v'))
+//     is ONE v_exp_f32 (1 ulp) per disparity instead of expf's range reduction: 5 instructions per disparity;
+//   * four independent (s, t) accumulator pairs break the dependent add chain.
+template <int DP>
+__device__ __forceinline__ void sa_stats_planes(const float *tile, const SaPix &p, float &M, float &s, float &t) {
+    float v[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) v[k] = sa_plane(tile, k, p);
+    // exact maximum of the UPSAMPLED logits (what F.softmax subtracts; a plane maximum would let every
+    // upsampled level underflow when one plane towers over its neighbours): both end planes and, per plane
+    // pair, the two outer lerp phases (the lerp is linear in the phase weight)
+    M = fmaxf(v[0], v[DP - 1]);
+#pragma unroll
+    for (int k = 0; k + 1 < DP; ++k)
+        M = fmaxf(M, fmaxf(0.875f * v[k] + 0.125f * v[k + 1], 0.125f * v[k] + 0.875f * v[k + 1]));
+#pragma unroll
+    for (int k = 0; k < DP; ++k) v[k] = (v[k] - M) * 1.4426950408889634f;
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, ta[4] = {0.f, 0.f, 0.f, 0.f};
     {   // D = 0, 1 -> plane 0 (source index clamped to 0)
-        const float e = expf(v0 - M);
-        s += e + e;
-        t += e;  // 0*e + 1*e
+        const float e = __builtin_amdgcn_exp2f(v[0]);
+        sa[0] += e + e;
+        ta[0] += e;
     }
-    for (int k = 0; k + 1 < d; ++k) {
-        const float v1 = sa_plane(tile, k + 1, p);
+#pragma unroll
+    for (int k = 0; k + 1 < DP; ++k) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const float w1 = 0.125f + 0.25f * m;
-            const float u = (1.f - w1) * v0 + w1 * v1;
-            const float e = expf(u - M);
+            const float e = __builtin_amdgcn_exp2f((1.f - w1) * v[k] + w1 * v[k + 1]);
+            sa[m] += e;
+            ta[m] = fmaf((float)(4 * k + 2 + m), e, ta[m]);
+        }
+    }
+    {   // D = 4d-2, 4d-1 -> plane d-1 (upper index clamped)
+        const float e = __builtin_amdgcn_exp2f(v[DP - 1]);
+        sa[1] += e + e;
+        ta[1] += (float)(4 * DP - 2) * e + (float)(4 * DP - 1) * e;
+    }
+    s = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    t = (ta[0] + ta[1]) + (ta[2] + ta[3]);
+}
+
+// generic depth (any d): two passes over the LDS tile, same shift rule and exp2 arithmetic
+__device__ __forceinline__ void sa_stats(const float *tile, int d, const SaPix &p, float &M,
+                                         float &s, float &t) {
+    if (d == 48) { sa_stats_planes<48>(tile, p, M, s, t); return; }  // D = 192
+    if (d == 16) { sa_stats_planes<16>(tile, p, M, s, t); return; }  // D = 64 (BASELINE configs[0])
+    {
+        float a0 = sa_plane(tile, 0, p);
+        M = a0;
+        for (int k = 0; k + 1 < d; ++k) {
+            const float a1 = sa_plane(tile, k + 1, p);
+            M = fmaxf(M, fmaxf(0.875f * a0 + 0.125f * a1, 0.125f * a0 + 0.875f * a1));
+            a0 = a1;
+        }
+        M = fmaxf(M, a0);
+    }
+    const float L2E = 1.4426950408889634f;
+    s = 0.f;
+    t = 0.f;
+    float v0 = (sa_plane(tile, 0, p) - M) * L2E;
+    {
+        const float e = __builtin_amdgcn_exp2f(v0);
+        s += e + e;
+        t += e;
+    }
+    for (int k = 0; k + 1 < d; ++k) {
+        const float v1 = (sa_plane(tile, k + 1, p) - M) * L2E;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float w1 = 0.125f + 0.25f * m;
+            const float e = __builtin_amdgcn_exp2f((1.f - w1) * v0 + w1 * v1);
             s += e;
-            t += (float)(4 * k + 2 + m) * e;
+            t = fmaf((float)(4 * k + 2 + m), e, t);
         }
         v0 = v1;
     }
-    {   // D = 4d-2, 4d-1 -> plane d-1 (upper index clamped)
-        const float e = expf(v0 - M);
+    {
+        const float e = __builtin_amdgcn_exp2f(v0);
         s += e + e;
         t += (float)(4 * d - 2) * e + (float)(4 * d - 1) * e;
     }

@@ -50,7 +50,7 @@ del volc
 # K6 soft-argmin
 lg = (3 * torch.randn(B, 1, d, h, w, device=dev)).requires_grad_()
 out = ops.softargmin(lg)
-row("K6 `az_softargmin_fwd` (per head)", timeit(lambda: ops.softargmin(lg.detach())), 4.0 * B * (d * h * w + H * W), "VALU/exp bound: 192 expf per pixel")
+row("K6 `az_softargmin_fwd` (per head)", timeit(lambda: ops.softargmin(lg.detach())), 4.0 * B * (d * h * w + H * W), "VALU-issue bound: plane values in registers, one v_exp_f32 per disparity")
 go = torch.randn_like(out)
 glg = torch.empty_like(lg)
 row("K6 `az_softargmin_bwd` (per head)", timeit(lambda: ops._call("az_softargmin_bwd", glg.data_ptr(), go.data_ptr(), lg.data_ptr(), None, None, B, d, h, w, ops._stream())), 4.0 * B * (2 * d * h * w + H * W), "recompute + LDS/global float atomics")
