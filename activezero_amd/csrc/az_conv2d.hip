@@ -40,14 +40,20 @@ struct C2Args {
     const float *wp;   // packed weights
     float *out;        // [B,H,W,*] pixel stride out_cs floats, channels [0, cout) written
     const float *scale, *shift, *res;  // optional epilogue operands (res: pixel stride res_cs)
+    const float *gz, *gh;              // act 4 (GRU combine): update gate z and previous state h, strides gz_cs / gh_cs
+    int gz_cs, gh_cs;
     int B, H, W;
     int cin, cout;     // cin % 16 == 0, cout % 32 == 0
     int in_cs, out_cs, res_cs;
     int tiles_y, tiles_x, ngroups;  // patch tiles and cout groups of 32*NW
-    int relu;
+    int relu;  // epilogue activation: 0 none, 1 ReLU, 2 sigmoid, 3 tanh, 4 GRU combine (1-z)*h + z*tanh(.)
 };
 
-template <int NW, int KH, int KW, int DIL>
+// PARTS = 3: the bf16x6 arithmetic above (fp32-class).  PARTS = 1: plain bf16 operands (round-to-nearest), one
+// MFMA per 16-deep block, fp32 accumulation -- the arithmetic of the reference's autocast region around the
+// RAFT-Stereo GRU update (nets/raft/raft_stereo.py:98,142-172; nets/raft/update.py:19-41), same slab / weight
+// pipeline with the mid / lo parts left out.
+template <int NW, int KH, int KW, int DIL, int PARTS = 3>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv2d_same_kernel(const C2Args a) {
     constexpr int T = KH * KW;
@@ -117,20 +123,24 @@ conv2d_same_kernel(const C2Args a) {
             const int sy = pix / SX, sx = pix - sy * SX;
             if (!((okbits >> it) & 1u)) pre[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < NQ) {
-                uint2 hi, mid, lo;
-                az_split3_bf16x4(pre[it], hi, mid, lo);
                 unsigned *dst = sb + (sy * C2_PITCH + sx) * C2_VS + (((j >> 1) ^ (sy & 1)) * 4) + (j & 1) * 2;
-                *reinterpret_cast<uint2 *>(dst) = hi;
-                *reinterpret_cast<uint2 *>(dst + 8) = mid;
-                *reinterpret_cast<uint2 *>(dst + 16) = lo;
+                if (PARTS == 3) {
+                    uint2 hi, mid, lo;
+                    az_split3_bf16x4(pre[it], hi, mid, lo);
+                    *reinterpret_cast<uint2 *>(dst) = hi;
+                    *reinterpret_cast<uint2 *>(dst + 8) = mid;
+                    *reinterpret_cast<uint2 *>(dst + 16) = lo;
+                } else {
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(az_pk_bf16(pre[it].x, pre[it].y), az_pk_bf16(pre[it].z, pre[it].w));
+                }
             }
         }
     };
     // packed weights: [tap][chunk][ntile][part][lane] float4
     auto load_b = [&](float4 (&bq)[3], int cc, int t) {
-        const float4 *p = wp4 + (((size_t)t * NCH + cc) * NT + ntile) * 3 * 64 + lane;
+        const float4 *p = wp4 + (((size_t)t * NCH + cc) * NT + ntile) * PARTS * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bq[k] = p[k * 64];
+        for (int k = 0; k < PARTS; ++k) bq[k] = p[k * 64];
     };
     // A fragments: two per-lane bases (row parity decides the half swap), compile-time offsets otherwise
     const float *abase[2];
@@ -139,7 +149,7 @@ conv2d_same_kernel(const C2Args a) {
     auto load_a = [&](float4 (&aq)[3], int buf, int m, int oy, int ox) {
         const float *ap = abase[oy & 1] + buf * SLAB + ((4 * (m >> 1) + oy) * C2_PITCH + 8 * (m & 1) + ox) * C2_VS;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) aq[p] = *reinterpret_cast<const float4 *>(ap + 8 * p);
+        for (int p = 0; p < PARTS; ++p) aq[p] = *reinterpret_cast<const float4 *>(ap + 8 * p);
     };
     // block products are summed in two alternating temporaries; the accumulators take each finished
     // temporary one block later (az_common.h az_mfma6_step): acc[3] of a tap is completed under the next
@@ -153,7 +163,10 @@ conv2d_same_kernel(const C2Args a) {
     auto step = [&](int cur, f32x16 &tn, const f32x16 &tp, const float4 (&aq)[3], const float4 (&bq)[3]) {
         // (price of the temporaries, measured against the plain six-MFMA chain into acc: +2.4 % on the
         //  extractor's forward, 10.09 vs 9.85 ms; profiles/r02_conv2d_layers_hip.txt)
-        if (PIPE) az_mfma6_step(tn, aq, bq, acc[(cur + 3) & 3], tp);
+        if (PARTS == 1)
+            acc[cur] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(az_bf16x8, aq[0]),
+                                                               __builtin_bit_cast(az_bf16x8, bq[0]), acc[cur], 0, 0, 0);
+        else if (PIPE) az_mfma6_step(tn, aq, bq, acc[(cur + 3) & 3], tp);
         else az_mfma6_now(acc[cur], aq, bq);
     };
 
@@ -241,7 +254,7 @@ conv2d_same_kernel(const C2Args a) {
         }
     }
 
-    if (PIPE) acc[3] += t1;  // the last block's temporary
+    if (PIPE && PARTS == 3) acc[3] += t1;  // the last block's temporary
     // ---- epilogue: C/D map of the 32x32 MFMA -- column (out channel) = lane & 31, row (pixel of the 4x8
     // tile) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); M-tile m covers rows 4(m>>1).., cols 8(m&1)..
     const int co = ntile * 32 + row;
@@ -259,7 +272,18 @@ conv2d_same_kernel(const C2Args a) {
             const unsigned pix = (unsigned)(oh * a.W + ow);
             float y = acc[m][r] * sc + sf;
             if (resp) y += resp[pix * (unsigned)a.res_cs];
-            if (a.relu) y = fmaxf(y, 0.f);
+            if (a.relu == 1) y = fmaxf(y, 0.f);
+            else if (a.relu == 2) y = 1.f / (1.f + __expf(-y));
+            else if (a.relu >= 3) {
+                const float e2 = __expf(-2.f * fabsf(y));  // tanh without overflow
+                const float th = (1.f - e2) / (1.f + e2);
+                y = y < 0.f ? -th : th;
+                if (a.relu == 4) {  // GRU state update (update.py:40): h' = (1 - z) h + z q
+                    const size_t ib = (size_t)b * a.H * a.W;
+                    const float z = a.gz[(ib + pix) * a.gz_cs + co], hp = a.gh[(ib + pix) * a.gh_cs + co];
+                    y = (1.f - z) * hp + z * y;
+                }
+            }
             outp[pix * (unsigned)a.out_cs] = y;
         }
 }
@@ -271,12 +295,13 @@ conv2d_same_kernel(const C2Args a) {
 // whose channel counts are not multiples of 32 / 16 are padded here, not in the activations' producers.
 __global__ void __launch_bounds__(256)
 conv2d_pack_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, int cin, int cout,
-                   int ci_real, int co_real, long long s_co, long long s_ci, int taps, int flip, long long total) {
+                   int ci_real, int co_real, long long s_co, long long s_ci, int taps, int flip, int parts,
+                   long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
     long long r = idx >> 9;
-    const int p = (int)(r % 3); r /= 3;
+    const int p = (int)(r % parts); r /= parts;
     const int nt = cout / 32, nch = cin / 16;
     const int n = (int)(r % nt); r /= nt;
     const int cc = (int)(r % nch);
@@ -301,26 +326,38 @@ extern "C" int az_conv2d_pack_weights(float *packed, const float *w, int cin, in
     const long long total = (long long)kh * kw * cin * cout * 3;
     hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, az_stream(stream),
                        reinterpret_cast<unsigned short *>(packed), w, cin, cout, ci_real, co_real, stride_out,
-                       stride_in, kh * kw, flip, total);
+                       stride_in, kh * kw, flip, 3, total);
     return az_launch_status();
 }
 
-template <int NW, int KH, int KW, int DIL>
+// plain bf16 image (one part): [tap][cin/16][cout/32][64 lanes][8] bf16 = kh*kw*cin*cout/2 floats
+extern "C" int az_conv2d_pack_weights_bf16(float *packed, const float *w, int cin, int cout, long long stride_out,
+                                           long long stride_in, int kh, int kw, void *stream) {
+    AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w);
+    if (az_conv2d_packed_floats(cin, cout, kh, kw) < 0) return AZ_EUNSUPPORTED;
+    const long long total = (long long)kh * kw * cin * cout;
+    hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, az_stream(stream),
+                       reinterpret_cast<unsigned short *>(packed), w, cin, cout, cin, cout, stride_out, stride_in,
+                       kh * kw, 0, 1, total);
+    return az_launch_status();
+}
+
+template <int NW, int KH, int KW, int DIL, int PARTS = 3>
 static int launch_c2(C2Args a, hipStream_t s) {
     a.ngroups = (a.cout / 32) / NW;
     const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.ngroups;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv2d_same_kernel<NW, KH, KW, DIL>), dim3((unsigned)blocks), dim3(64 * NW), 0, s, a);
+    hipLaunchKernelGGL((conv2d_same_kernel<NW, KH, KW, DIL, PARTS>), dim3((unsigned)blocks), dim3(64 * NW), 0, s, a);
     return az_launch_status();
 }
 
-template <int KH, int KW, int DIL>
+template <int KH, int KW, int DIL, int PARTS = 3>
 static int dispatch_nw(const C2Args &a, hipStream_t s) {
     const int nt = a.cout / 32;
-    if (nt % 4 == 0) return launch_c2<4, KH, KW, DIL>(a, s);
-    if (nt % 3 == 0) return launch_c2<3, KH, KW, DIL>(a, s);
-    if (nt % 2 == 0) return launch_c2<2, KH, KW, DIL>(a, s);
-    return launch_c2<1, KH, KW, DIL>(a, s);
+    if (nt % 4 == 0) return launch_c2<4, KH, KW, DIL, PARTS>(a, s);
+    if (nt % 3 == 0) return launch_c2<3, KH, KW, DIL, PARTS>(a, s);
+    if (nt % 2 == 0) return launch_c2<2, KH, KW, DIL, PARTS>(a, s);
+    return launch_c2<1, KH, KW, DIL, PARTS>(a, s);
 }
 
 extern "C" int az_conv2d_fwd(float *out, const float *in, const float *packed_w, const float *scale,
@@ -347,4 +384,31 @@ extern "C" int az_conv2d_fwd(float *out, const float *in, const float *packed_w,
     if (kh == 1 && kw == 1) return dispatch_nw<1, 1, 1>(a, s);
     if (kh == 3 && kw == 5 && dilation == 1) return dispatch_nw<3, 5, 1>(a, s);
     return AZ_EUNSUPPORTED;
+}
+
+/* 3x3 stride-1 "same" convolution with plain bf16 operands (one MFMA per block, fp32 accumulation, fp32 in / out):
+ * out = act(conv(in) + bias[co] + residual); act 0 none, 1 ReLU, 2 sigmoid, 3 tanh, 4 = the GRU state update
+ * (1 - z) * h + z * tanh(.) with gate z and previous state h read at gate_z / gate_h. */
+extern "C" int az_conv2d_bf16_fwd(float *out, const float *in, const float *packed_w, const float *bias,
+                                  const float *residual, const float *gate_z, const float *gate_h, int act, int B,
+                                  int H, int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
+                                  int z_cstride, int h_cstride, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w);
+    AZ_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0 && act >= 0 && act <= 4);
+    if (cin % 16 || cout % 32) return AZ_EUNSUPPORTED;
+    AZ_REQUIRE(in_cstride >= cin && out_cstride >= cout && in_cstride % 4 == 0);
+    AZ_REQUIRE(residual == nullptr || res_cstride >= cout);
+    if (act == 4) { AZ_REQUIRE_PTR(gate_z); AZ_REQUIRE_PTR(gate_h); AZ_REQUIRE(z_cstride >= cout && h_cstride >= cout); }
+    {
+        long long cs = in_cstride > out_cstride ? in_cstride : out_cstride;
+        if (res_cstride > cs) cs = res_cstride;
+        if ((long long)H * W * cs > 0x7fffffffLL) return AZ_EUNSUPPORTED;
+    }
+    C2Args a{};
+    a.in = in; a.wp = packed_w; a.out = out; a.scale = nullptr; a.shift = bias; a.res = residual; a.relu = act;
+    a.gz = gate_z; a.gh = gate_h; a.gz_cs = z_cstride; a.gh_cs = h_cstride;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
+    a.in_cs = in_cstride; a.out_cs = out_cstride; a.res_cs = res_cstride;
+    a.tiles_y = (H + C2_TY - 1) / C2_TY; a.tiles_x = (W + C2_TX - 1) / C2_TX;
+    return dispatch_nw<3, 3, 1, 1>(a, az_stream(stream));
 }

@@ -1,0 +1,119 @@
+"""RAFT-Stereo ConvGRU update on the MI355X convolution kernels -- drop-in for the class `ConvGRU` of the
+reference module nets/raft/update.py:19-41 (same constructor, parameter names `convz / convr / convq` with
+bias, so reference checkpoints load unchanged; same forward signature `(h, cz, cr, cq, *x_list)`).
+
+The reference runs the update block under autocast (nets/raft/raft_stereo.py:142-172): convolution operands
+are rounded to 16 bits, products accumulated in fp32.  Without autograd this module does the same on the plain
+bf16 MFMA path (include/azhip.h `az_conv2d_bf16_fwd`) in TWO launches per update:
+
+    zr = sigmoid(conv_{z|r}([h, x]) + bias + [cz, cr])          one 3x3 convolution, 2*hidden output channels
+    h' = (1 - z) * h + z * tanh(conv_q([r*h, x]) + bias + cq)   gate arithmetic in the convolution's epilogue
+
+The gates, context terms and the state itself stay fp32 (the reference keeps them in 16 bits between the
+convolutions, so this path is the more accurate of the two; tests/test_gpu_raft_gru.py measures both against an
+fp64 evaluation).  With autograd enabled (training) the three convolutions run on the differentiable bf16x6
+kernels of activezero_amd.conv2d (fp32-class arithmetic) and the gates in torch.
+
+The file is deliberately not called update.py: the rest of that reference module (motion encoder, flow head,
+multi-level block) is ordinary torch code outside this path and keeps resolving from the reference tree; the
+one-line edit there is `from nets.raft.gru import ConvGRU`.
+"""
+import torch
+import torch.nn as nn
+
+from activezero_amd import _lib, conv2d, profiler
+from activezero_amd.conv3d import _cache_get, _cache_key, _cache_put
+from activezero_amd.ops import _call, _chk, _p, _stream
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GRU = range(5)
+PEAK_BF16 = (2500.0, "dense bf16 MFMA peak")
+_PACK_CACHE = {}
+
+
+def _pack_bf16(weights, cache):
+    """[Cout_i, Cin, 3, 3] weights (concatenated along Cout) -> the kernel's one-part bf16 image."""
+    key = None
+    if cache:
+        key = _cache_key(*weights)
+        hit = _cache_get(_PACK_CACHE, key)
+        if hit is not None:
+            return hit[0]
+    w = torch.cat([x.detach().float() for x in weights], 0).contiguous()
+    cout, cin, kh, kw = w.shape
+    if _lib.lib().az_conv2d_packed_floats(cin, cout, kh, kw) < 0:
+        raise RuntimeError(f"ConvGRU: unsupported channel counts cin={cin} cout={cout} (need cin % 16 == 0, cout % 32 == 0)")
+    packed = torch.empty(kh * kw * cin * cout // 2, dtype=torch.float32, device=w.device)
+    _call("az_conv2d_pack_weights_bf16", _p(packed), _p(w), cin, cout, cin * kh * kw, kh * kw, kh, kw, _stream())
+    if key is not None:
+        _cache_put(_PACK_CACHE, key, (packed, weights), 64)
+    return packed
+
+
+def conv3x3_bf16(xr, packed, cin, cout, bias=None, residual=None, act=ACT_NONE, gate_z=None, gate_h=None):
+    """xr [B,H,W,>=cin] fp32 rows -> act(conv3x3(xr[..., :cin]) + bias + residual) as [B,H,W,cout] rows."""
+    b, h, w, cx = xr.shape
+    out = xr.new_empty(b, h, w, cout)
+    with profiler.scope(f"gru_conv3x3_bf16_{cin}_{cout}", flops=18.0 * cin * cout * b * h * w, peak=PEAK_BF16):
+        _call("az_conv2d_bf16_fwd", _p(out), _p(xr), _p(packed), _p(bias), _p(residual), _p(gate_z), _p(gate_h),
+              act, b, h, w, cin, cout, cx, cout, residual.shape[-1] if residual is not None else 0,
+              gate_z.shape[-1] if gate_z is not None else 0, gate_h.shape[-1] if gate_h is not None else 0,
+              _stream())
+    return out
+
+
+def _rows(t):
+    return _chk(t.float().permute(0, 2, 3, 1).contiguous(), "ConvGRU input")
+
+
+class ConvGRU(nn.Module):
+    def __init__(self, hidden_dim, input_dim, kernel_size=3):
+        super().__init__()
+        if kernel_size != 3:
+            raise RuntimeError("ConvGRU: the reference only instantiates kernel_size=3 (update.py:119-126)")
+        self.hidden_dim, self.input_dim = hidden_dim, input_dim
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, kernel_size, padding=kernel_size // 2)
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        if h.device.type != "cuda":
+            raise RuntimeError("ConvGRU: inputs must live on the GPU; the HIP path has no CPU fallback")
+        needs_grad = torch.is_grad_enabled() and (
+            any(t.requires_grad for t in (h, cz, cr, cq, *x_list)) or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return self._forward_autograd(h, cz, cr, cq, *x_list)
+        c, ct = self.hidden_dim, self.hidden_dim + self.input_dim
+        if h.shape[1] != c or sum(x.shape[1] for x in x_list) != self.input_dim:
+            raise RuntimeError("ConvGRU: channel counts do not match the constructor's hidden_dim / input_dim")
+        with torch.cuda.device(h.device), torch.autocast("cuda", enabled=False):
+            hr = _rows(h)
+            b, hh, ww, _ = hr.shape
+            hx = hr.new_empty(b, hh, ww, ct)
+            hx[..., :c] = hr
+            at = c
+            for x in x_list:
+                hx[..., at:at + x.shape[1]] = x.permute(0, 2, 3, 1)
+                at += x.shape[1]
+            czr = torch.cat([cz.permute(0, 2, 3, 1), cr.permute(0, 2, 3, 1)], -1).float().contiguous()
+            bzr = torch.cat([self.convz.bias, self.convr.bias]).detach().float().contiguous()
+            zr = conv3x3_bf16(hx, _pack_bf16((self.convz.weight, self.convr.weight), True), ct, 2 * c, bzr, czr,
+                              ACT_SIGMOID)
+            hx[..., :c] = zr[..., c:] * hr
+            out = conv3x3_bf16(hx, _pack_bf16((self.convq.weight,), True), ct, c,
+                               self.convq.bias.detach().float().contiguous(), _rows(cq), ACT_GRU, gate_z=zr, gate_h=hr)
+        return out.permute(0, 3, 1, 2)
+
+    def _forward_autograd(self, h, cz, cr, cq, *x_list):
+        with torch.autocast("cuda", enabled=False):
+            h, cz, cr, cq = h.float(), cz.float(), cr.float(), cq.float()
+            x = torch.cat([t.float() for t in x_list], 1)
+            hx = torch.cat([h, x], 1).contiguous(memory_format=torch.channels_last)
+
+            def conv(m, t):
+                return conv2d.conv_same(t, m.weight) + m.bias.view(1, -1, 1, 1)
+
+            z = torch.sigmoid(conv(self.convz, hx) + cz)
+            r = torch.sigmoid(conv(self.convr, hx) + cr)
+            rhx = torch.cat([r * h, x], 1).contiguous(memory_format=torch.channels_last)
+            q = torch.tanh(conv(self.convq, rhx) + cq)
+            return (1 - z) * h + z * q

@@ -256,6 +256,18 @@ long long az_conv2d_wgrad_workspace(int cm, int cn, int kh, int kw);
 int az_conv2d_wgrad(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
                     const float *in, int B, int H, int W, int cm, int cn, int cm_real, int cn_real,
                     int go_cstride, int in_cstride, int kh, int kw, int dilation, void *stream);
+/* plain-bf16 twin of az_conv2d_fwd for 3x3 layers (one MFMA per 16-deep block, operands rounded to bf16,
+ * fp32 accumulation and fp32 tensors): the arithmetic of the reference's autocast region around the RAFT-Stereo
+ * GRU update (nets/raft/raft_stereo.py:142-172 calling nets/raft/update.py:19-41 ConvGRU).
+ * out = act(conv(in) + bias[co] + residual); act: 0 none, 1 ReLU, 2 sigmoid, 3 tanh,
+ * 4 = (1 - z) * h + z * tanh(.) with gate_z / gate_h [B,H,W,*] (pixel strides z_cstride / h_cstride).
+ * packed image of az_conv2d_pack_weights_bf16: kh*kw*cin*cout/2 floats. */
+int az_conv2d_pack_weights_bf16(float *packed, const float *w, int cin, int cout, long long stride_out,
+                                long long stride_in, int kh, int kw, void *stream);
+int az_conv2d_bf16_fwd(float *out, const float *in, const float *packed_w, const float *bias,
+                       const float *residual, const float *gate_z, const float *gate_h, int act, int B, int H,
+                       int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
+                       int z_cstride, int h_cstride, void *stream);
 /* the extractor's first layer (psmnet_submodule_3.py:97-99: 3x3, stride 2, pad 1 on a 3- or 6-channel
  * image) as patch extraction + 1x1 convolution: patches[b,oy,ox, t*C + c] = x[b, 2oy-1+t/3, 2ox-1+t%3, c]
  * (zero outside the image and in channels [9C, Kp)); x: [B,H,W,C]; patches: [B,(H-1)/2+1,(W-1)/2+1,Kp].

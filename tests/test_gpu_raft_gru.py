@@ -1,0 +1,133 @@
+"""the RAFT-Stereo ConvGRU update (reference nets/raft/update.py:19-41) on the
+plain-bf16 MFMA convolution with the gate arithmetic in its epilogue.
+
+There is no reference golden for this row (nets/raft/update.py imports opt_einsum and yacs, absent here, so the
+reference module cannot be executed; its 22 lines are restated below in torch).  Checked instead:
+  * the convolution kernel itself, bit-level: with operands that are exactly representable in bf16 and
+    products that sum exactly in fp32, the result equals an fp64 convolution;
+  * the GRU against an fp64 evaluation of the reference's formula, next to the error of the reference's own
+    arithmetic (the same formula under CPU autocast(bfloat16)): ours must not be worse;
+  * the autograd path (bf16x6 kernels) against torch fp32, values and gradients.
+"""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_gru(mod, h, cz, cr, cq, *x_list):
+    # nets/raft/update.py:32-41
+    x = torch.cat(x_list, dim=1)
+    hx = torch.cat([h, x], dim=1)
+    z = torch.sigmoid(mod.convz(hx) + cz)
+    r = torch.sigmoid(mod.convr(hx) + cr)
+    q = torch.tanh(mod.convq(torch.cat([r * h, x], dim=1)) + cq)
+    return (1 - z) * h + z * q
+
+
+class _TorchGRU(nn.Module):
+    def __init__(self, hidden_dim, input_dim):
+        super().__init__()
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, 3, padding=1)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, 3, padding=1)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, 3, padding=1)
+
+
+def _inputs(b, c, cx, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    hid = torch.tanh(torch.randn(b, c, h, w, generator=g))
+    ctx = [torch.randn(b, c, h, w, generator=g) * 0.5 for _ in range(3)]
+    xs = [torch.randn(b, n, h, w, generator=g) for n in cx]
+    return hid, ctx, xs
+
+
+def test_bf16_conv_exact_on_representable_operands():
+    from activezero_amd.nets.raft import gru
+    g = torch.Generator().manual_seed(3)
+    b, h, w, cin, cout = 2, 19, 37, 48, 96
+    x = torch.randint(-8, 9, (b, cin, h, w), generator=g).float()          # small integers: exact in bf16,
+    wt = torch.randint(-4, 5, (cout, cin, 3, 3), generator=g).float() / 8  # products and sums exact in fp32
+    bias = torch.randn(cout, generator=g)
+    res = torch.randn(b, cout, h, w, generator=g)
+    want = F.conv2d(x.double(), wt.double(), padding=1) + bias.double().view(1, -1, 1, 1) + res.double()
+    xr = x.permute(0, 2, 3, 1).contiguous().cuda()
+    pk = gru._pack_bf16((wt.cuda(),), False)
+    for act, fn in ((gru.ACT_NONE, lambda t: t), (gru.ACT_RELU, torch.relu), (gru.ACT_SIGMOID, torch.sigmoid),
+                    (gru.ACT_TANH, torch.tanh)):
+        got = gru.conv3x3_bf16(xr, pk, cin, cout, bias.cuda(), res.permute(0, 2, 3, 1).contiguous().cuda(), act)
+        ref = fn(want).permute(0, 2, 3, 1)
+        tol = 0 if act in (gru.ACT_NONE, gru.ACT_RELU) else 2e-6
+        err = (got.cpu().double() - ref).abs().max().item()
+        lim = tol if tol else 4e-6 * want.abs().max().item()  # bias / residual adds round once each in fp32
+        assert err <= lim, (act, err)
+
+
+@pytest.mark.parametrize("hidden,cx,hw", [(128, (128,), (34, 60)), (128, (128, 128), (17, 30)), (64, (32, 48), (9, 21))])
+def test_gru_matches_reference_formula(hidden, cx, hw):
+    from activezero_amd.nets.raft.gru import ConvGRU
+    torch.manual_seed(11)
+    ref = _TorchGRU(hidden, sum(cx))
+    mod = ConvGRU(hidden, sum(cx))
+    mod.load_state_dict(ref.state_dict())  # same parameter names as the reference class
+    hid, ctx, xs = _inputs(2, hidden, cx, *hw, seed=5)
+    with torch.no_grad():
+        exact = _reference_gru(ref.double(), hid.double(), *[c.double() for c in ctx], *[x.double() for x in xs])
+        ref.float()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            amp = _reference_gru(ref, hid, *ctx, *xs).float()
+        mod.cuda()
+        got = mod(hid.cuda(), *[c.cuda() for c in ctx], *[x.cuda() for x in xs])
+        with torch.autocast("cuda", dtype=torch.bfloat16):  # what raft_stereo.py:142 wraps the call in
+            got_amp = mod(hid.cuda(), *[c.cuda() for c in ctx], *[x.cuda() for x in xs])
+    assert got.shape == exact.shape and got.dtype == torch.float32
+    e_hip = (got.cpu().double() - exact).abs().max().item()
+    e_amp = (amp.double() - exact).abs().max().item()
+    assert torch.equal(got, got_amp)
+    assert e_hip <= 2e-2, e_hip            # bf16 operand rounding over K = 9 * (hidden + input) terms
+    assert e_hip <= e_amp, (e_hip, e_amp)  # no worse than the reference's autocast arithmetic
+    # iterating feeds the state back (raft_stereo.py:138-172): stays bounded and close after 4 updates
+    with torch.no_grad():
+        hh, he = hid.cuda(), hid.double()
+        ref.double()
+        for _ in range(4):
+            hh = mod(hh, *[c.cuda() for c in ctx], *[x.cuda() for x in xs])
+            he = _reference_gru(ref, he, *[c.double() for c in ctx], *[x.double() for x in xs])
+    assert (hh.cpu().double() - he).abs().max().item() <= 5e-2
+
+
+def test_gru_autograd_path():
+    from activezero_amd.nets.raft.gru import ConvGRU
+    torch.manual_seed(2)
+    ref = _TorchGRU(64, 64)
+    mod = ConvGRU(64, 64)
+    mod.load_state_dict(ref.state_dict())
+    mod.cuda()
+    hid, ctx, xs = _inputs(1, 64, (64,), 12, 20, seed=9)
+    cot = torch.randn(1, 64, 12, 20)
+    hr = hid.clone().requires_grad_(True)
+    (_reference_gru(ref, hr, *ctx, *xs) * cot).sum().backward()
+    hg = hid.cuda().requires_grad_(True)
+    out = mod(hg, *[c.cuda() for c in ctx], *[x.cuda() for x in xs])
+    (out * cot.cuda()).sum().backward()
+    torch.testing.assert_close(out.detach().cpu(), _reference_gru(ref, hid, *ctx, *xs).detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(hg.grad.cpu(), hr.grad, rtol=1e-4, atol=1e-5)
+    for name in ("convz", "convr", "convq"):
+        torch.testing.assert_close(getattr(mod, name).weight.grad.cpu(), getattr(ref, name).weight.grad,
+                                   rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(getattr(mod, name).bias.grad.cpu(), getattr(ref, name).bias.grad,
+                                   rtol=1e-4, atol=2e-5)
+
+
+def test_gru_rejects_cpu_and_bad_channels():
+    from activezero_amd.nets.raft.gru import ConvGRU
+    mod = ConvGRU(64, 64)
+    t = torch.zeros(1, 64, 8, 8)
+    with pytest.raises(RuntimeError):
+        mod(t, t, t, t, t)
+    mod.cuda()
+    with pytest.raises(RuntimeError), torch.no_grad():
+        mod(t.cuda(), t.cuda(), t.cuda(), t.cuda(), torch.zeros(1, 32, 8, 8).cuda())
+    with pytest.raises(RuntimeError):
+        ConvGRU(64, 64, kernel_size=5)
