@@ -86,10 +86,15 @@ def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d"):
 
 
 class _ConvSame(torch.autograd.Function):
-    """conv2d(x, w, stride 1, "same" padding, dilation) for the geometries of _SAME."""
+    """conv2d(x, w, stride 1, "same" padding, dilation) for the geometries of _SAME.
+
+    with_skip: also return x itself as a second output.  A residual block hands that alias to its shortcut
+    (psmnet_submodule_3.py:69-78: out = conv2(conv1(x)) + x), so both gradients of x arrive HERE and the
+    shortcut's is added in the input-gradient convolution's epilogue instead of by a separate elementwise
+    kernel of the autograd engine (one read + one write of the activation per block saved)."""
 
     @staticmethod
-    def forward(ctx, x, weight, dil):
+    def forward(ctx, x, weight, dil, with_skip):
         cout, cin, kh, kw = weight.shape
         xr = _chk(rows(x), "x")
         with torch.cuda.device(x.device):
@@ -97,30 +102,45 @@ class _ConvSame(torch.autograd.Function):
             y = _run(xr, pk, cin, cout, kh, kw, dil)
         ctx.save_for_backward(xr, weight)
         ctx.dil = dil
+        ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero tensor
+        if with_skip:
+            return image(y), x.view_as(x)
         return image(y)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gskip=None):
         xr, weight = ctx.saved_tensors
         cout, cin, kh, kw = weight.shape
         dil = ctx.dil
+        if gy is None:  # only the shortcut was used downstream
+            return gskip, None, None, None
         gr = _chk(rows(gy), "grad_y")
         gx = gw = None
         with torch.cuda.device(gy.device):
             if ctx.needs_input_grad[0]:  # the same convolution, taps flipped, channel roles swapped
                 pk = _pack(weight, cout, cin, cout, cin, kh * kw, cin * kh * kw, kh, kw, True)
-                gx = image(_run(gr, pk, cout, cin, kh, kw, dil, tag="dgrad2d"))
+                sk = _chk(rows(gskip), "grad_skip") if gskip is not None else None
+                gx = image(_run(gr, pk, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
             if ctx.needs_input_grad[1]:
                 gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil)
-        return gx, gw, None
+        return gx, gw, None, None
+
+
+def _check_same(weight, dilation):
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw, dilation if kh > 1 else 1) not in _SAME or cin % 32 or cout % 32:
+        raise RuntimeError(f"conv_same: unsupported geometry {tuple(weight.shape)}, dilation {dilation}")
+    return 1 if kh == 1 else dilation
 
 
 def conv_same(x, weight, dilation=1):
     """F.conv2d(x, weight, padding="same", dilation=dilation) for [B,C,H,W] x (channels_last preferred)."""
-    cout, cin, kh, kw = weight.shape
-    if (kh, kw, dilation if kh > 1 else 1) not in _SAME or cin % 32 or cout % 32:
-        raise RuntimeError(f"conv_same: unsupported geometry {tuple(weight.shape)}, dilation {dilation}")
-    return _ConvSame.apply(x, weight, 1 if kh == 1 else dilation)
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), False)
+
+
+def conv_same_skip(x, weight, dilation=1):
+    """(conv_same(x, weight, dilation), x): the second output is x for the block's shortcut (see _ConvSame)."""
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), True)
 
 
 class _ConvS2Vol(torch.autograd.Function):
@@ -198,15 +218,24 @@ class _ConvS2Patches(torch.autograd.Function):
         return gx, gw
 
 
-def conv(x, m, arith=None):
-    """m(x) for an nn.Conv2d of the extractor (bias-free, groups 1), differentiable, on the HIP kernels."""
+def is_same(m):
+    """True for the stride-1 "same"-padded layers (the route of conv_same / conv_same_skip)."""
+    k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
+    return s == (1, 1) and k[0] == k[1] and p[0] == p[1] == d[0] * (k[0] - 1) // 2 and d[0] == d[1]
+
+
+def conv(x, m, arith=None, skip=False):
+    """m(x) for an nn.Conv2d of the extractor (bias-free, groups 1), differentiable, on the HIP kernels.
+    skip=True (stride-1 layers only): returns (m(x), x), see conv_same_skip."""
     arith = conv3d._arith(arith)
     if not isinstance(m, torch.nn.Conv2d) or m.bias is not None or m.groups != 1:
         raise RuntimeError("conv2d.conv: expects a bias-free nn.Conv2d")
     k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
     cin, cout = m.in_channels, m.out_channels
-    if s == (1, 1) and k[0] == k[1] and p[0] == p[1] == d[0] * (k[0] - 1) // 2 and d[0] == d[1]:
-        return conv_same(x, m.weight, d[0])
+    if is_same(m):
+        return (conv_same_skip if skip else conv_same)(x, m.weight, d[0])
+    if skip:
+        raise RuntimeError(f"conv2d.conv: skip output needs a stride-1 layer, got {m}")
     if s == (2, 2) and k == (3, 3) and p == (1, 1) and d == (1, 1):
         if cin in (32, 64) and cout in (32, 64) and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
             return _ConvS2Vol.apply(x, m.weight, arith)

@@ -15,8 +15,10 @@ import torch.nn.functional as F
 from activezero_amd import bn2d, conv2d
 
 
-def _convbn_unit(x, unit, relu=False, residual=None, groups=1):
+def _convbn_unit(x, unit, relu=False, residual=None, groups=1, skip=False):
     """unit = Sequential(Conv2d, BatchNorm2d): y = relu?(bn(conv(x)) + residual).
+    skip=True returns (y, x'), x' = x routed through the convolution's autograd node for the caller's
+    shortcut, so that the shortcut's gradient is added inside the input-gradient kernel (conv2d._ConvSame).
     `groups`: consecutive equal parts of the batch that take their OWN batch statistics (2 when the left
     and right images run as one stacked batch, FeatureExtraction.forward_pair); passed down explicitly --
     no module-level state, so replicas on several threads (nn.DataParallel, train.py:540-541) cannot
@@ -31,8 +33,12 @@ def _convbn_unit(x, unit, relu=False, residual=None, groups=1):
         # inference: BatchNorm (running statistics), residual sum and ReLU ride on the conv epilogue
         y = conv2d.conv_bn_eval(x, conv, bn, relu, residual)
         if y is not None:
-            return y
-    return bn2d.bn_act(conv2d.conv(x, conv), bn, relu, residual, groups)
+            return (y, x) if skip else y
+    if skip and torch.is_grad_enabled() and x.requires_grad and conv2d.is_same(conv):
+        c, shortcut = conv2d.conv(x, conv, skip=True)
+        return bn2d.bn_act(c, bn, relu, residual, groups), shortcut
+    y = bn2d.bn_act(conv2d.conv(x, conv), bn, relu, residual, groups)
+    return (y, x) if skip else y
 
 
 __all__ = ["convbn", "conv", "convbn_3d", "BasicBlock", "DisparityRegression",
@@ -74,8 +80,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x, groups=1):
-        shortcut = x if self.downsample is None else _convbn_unit(x, self.downsample, groups=groups)
-        y = _convbn_unit(x, self.conv1[0], relu=True, groups=groups)
+        if self.downsample is None:
+            y, shortcut = _convbn_unit(x, self.conv1[0], relu=True, groups=groups, skip=True)
+        else:
+            shortcut = _convbn_unit(x, self.downsample, groups=groups)
+            y = _convbn_unit(x, self.conv1[0], relu=True, groups=groups)
         return _convbn_unit(y, self.conv2, relu=False, residual=shortcut, groups=groups)
 
 

@@ -82,6 +82,34 @@ def test_conv_stride2_routes_vs_torch_fp64(cin, cout, k, stride, dims):
     close(m.weight.grad, wd.grad, 1e-5, 3e-6 * float(wd.grad.abs().max()))
 
 
+@pytest.mark.parametrize("c,dil", [(32, 1), (64, 1), (128, 2)])
+def test_conv_same_skip_adds_the_shortcut_gradient_in_the_dgrad_epilogue(c, dil):
+    """(conv(x), x) with both outputs used, as a residual block does (psmnet_submodule_3.py:69-78): the
+    gradient of x is dgrad(gy) + g_shortcut, summed inside the input-gradient kernel."""
+    x, w = seeded((2, c, 21, 37), 11), seeded((c, c, 3, 3), 12) * 0.1
+    ct, cs = seeded((2, c, 21, 37), 13), seeded((2, c, 21, 37), 14)
+    xd, wd = x.double().requires_grad_(), w.double().requires_grad_()
+    yd = F.conv2d(xd, wd, None, 1, dil, dil)
+    ((yd * ct.double()).sum() + (xd * cs.double()).sum()).backward()
+    xg = x.to(DEV).contiguous(memory_format=CL).requires_grad_()
+    wg = w.to(DEV).requires_grad_()
+    y, xs = conv2d.conv_same_skip(xg, wg, dil)
+    assert xs.data_ptr() == xg.data_ptr()  # an alias, not a copy
+    ((y * ct.to(DEV)).sum() + (xs * cs.to(DEV)).sum()).backward()
+    close(y, yd, 1e-5, 3e-6 * float(yd.detach().abs().max()))
+    close(xg.grad, xd.grad, 1e-5, 3e-6 * float(xd.grad.abs().max()))
+    close(wg.grad, wd.grad, 1e-5, 3e-6 * float(wd.grad.abs().max()))
+    # one output unused: its gradient arrives as None and the other path is unchanged
+    xg.grad = None
+    y, xs = conv2d.conv_same_skip(xg, wg, dil)
+    (xs * cs.to(DEV)).sum().backward()
+    close(xg.grad, cs, 0, 0)
+    xg.grad = None
+    y, xs = conv2d.conv_same_skip(xg, wg, dil)
+    (y * ct.to(DEV)).sum().backward()
+    close(xg.grad, xd.grad - cs.double(), 1e-5, 3e-6 * float(xd.grad.abs().max()))
+
+
 def test_conv_unsupported_geometry_raises():
     m = torch.nn.Conv2d(32, 32, 5, 1, 2, bias=False).to(DEV)
     with pytest.raises(RuntimeError):

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Time the V0 (32->32, [B,48,136,240]) 3-D convolution kernels alone: forward (+BN partials), input gradient,
+weight gradient; HIP events; TFLOP/s against the bf16x6 roofline."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from activezero_amd import conv3d
+dev = torch.device("cuda:0")
+B, D, H, W, C = 4, 48, 136, 240, 32
+x = torch.randn(B, D, H, W, C, device=dev)
+g = torch.randn(B, D, H, W, C, device=dev)
+w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
+A = conv3d.DEFAULT_ARITH
+pk, ci, co = conv3d._pack_forward(w, conv3d.CONV_S1, A.conv)
+pd = conv3d._pack(w, C, C, 27, C * 27, True, A.conv)
+def timeit(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+gf = 2.0 * 27 * C * C * B * D * H * W / 1e9
+for name, fn in (("fwd+stats", lambda: conv3d._run_gather(x, pk, conv3d.CONV_S1, ci, co, A.conv, stats=True)),
+                 ("dgrad", lambda: conv3d._run_gather(g, pd, conv3d.CONV_S1, C, C, A.conv, tag="dgrad")),
+                 ("wgrad", lambda: conv3d._wgrad(g, x, 1, C, C, "conv", A.wgrad))):
+    ms = timeit(fn)
+    print(f"V0 {name:10s} {ms:7.3f} ms  {gf / ms:6.1f} TFLOP/s  ({gf / ms / 416.7:.2f} of 416.7)")

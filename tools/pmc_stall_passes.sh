@@ -11,11 +11,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS 
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES -d $out -o b --output-format csv -- python3 $root/tools/${PROBE:-pmc_sq_probe.py} > $out/b.log 2>&1
 python3 - <<PY
 import csv, collections, glob
+import re
 agg = collections.defaultdict(list)
 for f in glob.glob("$out/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("gather", "m128", "wgrad")):
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if any(k in r["Kernel_Name"] for k in ("gather", "m128", "wgrad", "conv2d_same", "t2_kernel")):
+            name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+            agg[(name, r["Grid_Size"], r["Counter_Name"])].append(float(r["Counter_Value"]))
 for k in sorted(agg):
-    print("$tag", k, "%.4g" % (sum(agg[k]) / len(agg[k])))
+    print("$tag", k[0], "grid", k[1], k[2], "%.4g" % (sum(agg[k]) / len(agg[k])))
 PY
