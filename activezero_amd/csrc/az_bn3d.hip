@@ -95,7 +95,31 @@ __global__ void bn_eval_affine_kernel(float *scale, float *shift, const float *g
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-template <int C>
+// Streaming access for tensors larger than the 256 MB Infinity Cache (the V0 volumes are 802 MB): nontemporal
+// loads and stores keep lines that will not be reused out of L2 / MALL (measured on bn_apply over a V0 tensor:
+// 5.32 -> 5.71 TB/s; torch's copy kernel on the same box 5.55).  Smaller tensors keep the default policy: their
+// consumer finds them in the cache.
+typedef float az_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 bn_ld4(const float4 *p) {
+    if (NT) {
+        const az_v4f v = __builtin_nontemporal_load(reinterpret_cast<const az_v4f *>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void bn_st4(float4 *p, const float4 &o) {
+    if (NT) {
+        const az_v4f v = {o.x, o.y, o.z, o.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<az_v4f *>(p));
+    } else {
+        *p = o;
+    }
+}
+#define BN_NT_BYTES (256LL << 20)
+
+template <int C, bool NT>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
                 const float *__restrict__ scale, const float *__restrict__ shift,
@@ -114,19 +138,19 @@ bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
     __syncthreads();
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
         const int c4 = (int)(i % C4);
-        const float4 v = x[i], sc = ssc[c4], sh = ssh[c4];
+        const float4 v = bn_ld4<NT>(&x[i]), sc = ssc[c4], sh = ssh[c4];
         // (fmaf spelled out: the backward kernels recompute this value for the ReLU mask and must
         //  round identically)
         float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z),
                                fmaf(v.w, sc.w, sh.w));
         if (res) {
-            const float4 r = res[i];
+            const float4 r = bn_ld4<NT>(&res[i]);
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         if (relu) {
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
-        y[i] = o;
+        bn_st4<NT>(&y[i], o);
     }
 }
 
@@ -134,7 +158,7 @@ __device__ __forceinline__ int c4_of(int tid, int C4) { return tid % C4; }
 
 // ---- backward ---------------------------------------------------------------------------
 // partial[block][C][2]: sum(dz), sum(dz * xhat) over the block's voxels
-template <int C>
+template <int C, bool NT>
 __global__ void __launch_bounds__(256)
 bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
                      const float *__restrict__ y, const float *__restrict__ x,
@@ -162,12 +186,12 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
     for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
         const size_t i = (size_t)v * C4 + c4;
-        float4 g = reinterpret_cast<const float4 *>(dy)[i];
-        const float4 xx = reinterpret_cast<const float4 *>(x)[i];
+        float4 g = bn_ld4<NT>(reinterpret_cast<const float4 *>(dy) + i);
+        const float4 xx = bn_ld4<NT>(reinterpret_cast<const float4 *>(x) + i);
         if (relu) {
             float4 yy;
             if (remask) yy = make_float4(fmaf(xx.x, sc.x, sh.x), fmaf(xx.y, sc.y, sh.y), fmaf(xx.z, sc.z, sh.z), fmaf(xx.w, sc.w, sh.w));
-            else yy = reinterpret_cast<const float4 *>(y)[i];
+            else yy = bn_ld4<NT>(reinterpret_cast<const float4 *>(y) + i);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
@@ -229,7 +253,7 @@ bn_bwd_finalize_kernel(float *__restrict__ dgamma, float *__restrict__ dbeta,
     }
 }
 
-template <int C>
+template <int C, bool NT>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
                     const float4 *__restrict__ dy, const float4 *__restrict__ y,
@@ -257,23 +281,23 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
     __syncthreads();
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
         const int c = (int)(i % C4) * 4;
-        float4 g = dy[i];
-        const float4 xx = x[i];
+        float4 g = bn_ld4<NT>(&dy[i]);
+        const float4 xx = bn_ld4<NT>(&x[i]);
         if (relu) {
             float4 yy;
             if (remask) yy = make_float4(fmaf(xx.x, ssc[c + 0], ssh[c + 0]), fmaf(xx.y, ssc[c + 1], ssh[c + 1]),
                                          fmaf(xx.z, ssc[c + 2], ssh[c + 2]), fmaf(xx.w, ssc[c + 3], ssh[c + 3]));
-            else yy = y[i];
+            else yy = bn_ld4<NT>(&y[i]);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
-        if (dz_out) dz_out[i] = g;
+        if (dz_out) bn_st4<NT>(&dz_out[i], g);
         float4 o;
         o.x = k0[c + 0] * (g.x - k1[c + 0] - (xx.x - smu[c + 0]) * sis[c + 0] * k2[c + 0]);
         o.y = k0[c + 1] * (g.y - k1[c + 1] - (xx.y - smu[c + 1]) * sis[c + 1] * k2[c + 1]);
         o.z = k0[c + 2] * (g.z - k1[c + 2] - (xx.z - smu[c + 2]) * sis[c + 2] * k2[c + 2]);
         o.w = k0[c + 3] * (g.w - k1[c + 3] - (xx.w - smu[c + 3]) * sis[c + 3] * k2[c + 3]);
-        dx[i] = o;
+        bn_st4<NT>(&dx[i], o);
     }
 }
 
@@ -356,6 +380,19 @@ sum4_kernel(float4 *__restrict__ y, const float4 *__restrict__ a, const float4 *
 }
 
 #define BN_GRID(total) az_grid_for((total), 256)
+// KERNEL<C, NT> for the three channel counts, NT chosen at run time
+#define BN_LAUNCH(KERNEL, C, NT, GRID, STREAM, ...)                                                             \
+    do {                                                                                                        \
+        if (NT) {                                                                                               \
+            if ((C) == 32) hipLaunchKernelGGL((KERNEL<32, true>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);     \
+            else if ((C) == 64) hipLaunchKernelGGL((KERNEL<64, true>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<128, true>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);              \
+        } else {                                                                                                \
+            if ((C) == 32) hipLaunchKernelGGL((KERNEL<32, false>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);    \
+            else if ((C) == 64) hipLaunchKernelGGL((KERNEL<64, false>), GRID, dim3(256), 0, STREAM, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<128, false>), GRID, dim3(256), 0, STREAM, __VA_ARGS__);             \
+        }                                                                                                       \
+    } while (0)
 
 extern "C" int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
                                 float *running_mean, float *running_var, const float *partials,
@@ -390,17 +427,10 @@ extern "C" int az_bn3d_apply(float *y, const float *x, const float *scale, const
     AZ_REQUIRE(nvox > 0);
     const long long total4 = nvox * C / 4;
     const float4 *r4 = reinterpret_cast<const float4 *>(residual);
-    if (C == 32)
-        hipLaunchKernelGGL(bn_apply_kernel<32>, dim3(BN_GRID(total4)), dim3(256), 0, az_stream(stream),
-                           (float4 *)y, (const float4 *)x, scale, shift, r4, relu, total4);
-    else if (C == 64)
-        hipLaunchKernelGGL(bn_apply_kernel<64>, dim3(BN_GRID(total4)), dim3(256), 0, az_stream(stream),
-                           (float4 *)y, (const float4 *)x, scale, shift, r4, relu, total4);
-    else if (C == 128)
-        hipLaunchKernelGGL(bn_apply_kernel<128>, dim3(BN_GRID(total4)), dim3(256), 0, az_stream(stream),
-                           (float4 *)y, (const float4 *)x, scale, shift, r4, relu, total4);
-    else
-        return AZ_EUNSUPPORTED;
+    if (C != 32 && C != 64 && C != 128) return AZ_EUNSUPPORTED;
+    const bool nt = total4 * 16 >= BN_NT_BYTES;
+    BN_LAUNCH(bn_apply_kernel, C, nt, dim3(BN_GRID(total4)), az_stream(stream), (float4 *)y, (const float4 *)x, scale,
+              shift, r4, relu, total4);
     return az_launch_status();
 }
 
@@ -427,30 +457,12 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
     const int blocks = (int)(need / (C * 2 * sizeof(float)));
     const long long total4 = nvox * C / 4;
     hipStream_t s = az_stream(stream);
-    if (C == 32) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
-                           x, mean, invstd, scale, shift, relu, nvox);
-    } else if (C == 64) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<64>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
-                           x, mean, invstd, scale, shift, relu, nvox);
-    } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<128>, dim3(blocks), dim3(256), 0, s, workspace, dy, y,
-                           x, mean, invstd, scale, shift, relu, nvox);
-    }
+    const bool nt = total4 * 16 >= BN_NT_BYTES;
+    BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef,
                        workspace, gamma, invstd, blocks, C, (double)nvox, 1);
-    if (C == 32)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<32>, dim3(BN_GRID(total4)), dim3(256), 0, s,
-                           (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
-                           (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
-    else if (C == 64)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<64>, dim3(BN_GRID(total4)), dim3(256), 0, s,
-                           (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
-                           (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<128>, dim3(BN_GRID(total4)), dim3(256), 0, s,
-                           (float4 *)dx, (float4 *)dz_out, (const float4 *)dy, (const float4 *)y,
-                           (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
+    BN_LAUNCH(bn_bwd_apply_kernel, C, nt, dim3(BN_GRID(total4)), s, (float4 *)dx, (float4 *)dz_out, (const float4 *)dy,
+              (const float4 *)y, (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
     return az_launch_status();
 }
 
@@ -526,7 +538,7 @@ static void bn2d_fwd_launch(float *y, float *mean, float *invstd, float *scale, 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_FIN_THREADS), 0, s, mean, invstd, scale, shift, rm, rv,
                        part, cnt, gamma, beta, tiles, C, eps, momentum, groups);
     const long long total4 = nvox * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel<C>, dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)y,
+    hipLaunchKernelGGL((bn_apply_kernel<C, false>), dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)y,
                        (const float4 *)x, scale, shift, (const float4 *)res, relu, total4);
 }
 
@@ -557,12 +569,12 @@ static void bn2d_bwd_launch(float *dx, float *dz, float *dgamma, float *dbeta, f
                             long long nvox, hipStream_t s) {
     const int blocks = bn2d_blocks(nvox, C);
     float *partial = ws, *coef = ws + (size_t)groups * blocks * C * 2;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<C>, dim3(blocks, groups), dim3(256), 0, s, partial, dy, y, x, mean,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<C, false>), dim3(blocks, groups), dim3(256), 0, s, partial, dy, y, x, mean,
                        invstd, scale, shift, relu, nvox);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef, partial, gamma,
                        invstd, blocks, C, (double)nvox, groups);
     const long long total4 = nvox * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<C>, dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)dx,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<C, false>), dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)dx,
                        (float4 *)dz, (const float4 *)dy, (const float4 *)y, (const float4 *)x, mean, invstd,
                        coef, scale, shift, relu, total4);
 }

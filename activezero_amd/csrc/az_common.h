@@ -6,9 +6,6 @@
 #include "../../include/azhip.h"
 
 #define AZ_WAVE 64
-#ifndef AZ_STEP_VARIANT
-#define AZ_STEP_VARIANT 0
-#endif
 
 #define AZ_REQUIRE_PTR(p) \
     do {                  \
@@ -106,6 +103,9 @@ __device__ __forceinline__ unsigned short az_split3_part(float x, int p) {
 //     error 4x.  LARGEST TERMS FIRST costs nothing and removes it: hi*hi starts from zero, each later group is
 //     added to a C at least as large as its products, whose own low bits stay inside the adder.
 //
+// (Measured, profiles/r02_clock_pipe_ablation.md: against the plain chain the adds are free in the multi-wave 2-D
+// kernels and cost 10 % in the one-wave V0 kernel; issued as v_pk_add_f32 they are no faster -- hipcc itself
+// unpacks packed adds that sit in an MFMA's shadow.)
 // az_mfma6_step overlaps the adds with the next block's MFMAs (two temporaries in flight = 32 registers);
 // az_mfma6_now is the single-temporary form for kernels at their register limit; az_mfma6 is the plain chain
 // into a running accumulator (weight-gradient kernels).
@@ -130,40 +130,11 @@ __device__ __forceinline__ void az_mfma6_now(az_f32x16 &c, const float4 (&aq)[3]
 }
 // tnew = block product (from zero);  cprev += tprev  (tprev: the temporary of the block before), the adds
 // interleaved between this block's MFMAs: the matrix pipe never waits for them
-typedef float az_f32x2 __attribute__((ext_vector_type(2)));
-// c[2i..2i+1] += t[2i..2i+1] as ONE v_pk_add_f32 (hipcc scalarises every form of this add written in C)
-__device__ __forceinline__ void az_pk_add(az_f32x16 &c, const az_f32x16 &t, int i) {
-    az_f32x2 c2 = {c[2 * i], c[2 * i + 1]};
-    const az_f32x2 t2 = {t[2 * i], t[2 * i + 1]};
-    asm("v_pk_add_f32 %0, %0, %1" : "+v"(c2) : "v"(t2));
-    c[2 * i] = c2[0];
-    c[2 * i + 1] = c2[1];
-}
 __device__ __forceinline__ void az_mfma6_step(az_f32x16 &tnew, const float4 (&aq)[3], const float4 (&bq)[3],
                                               az_f32x16 &cprev, const az_f32x16 &tprev) {
-#if AZ_STEP_VARIANT == 2  // timing experiment: plain chain
-    cprev = AZ_X6(cprev, 0, 0); cprev = AZ_X6(cprev, 0, 1); cprev = AZ_X6(cprev, 1, 0); cprev = AZ_X6(cprev, 1, 1);
-    cprev = AZ_X6(cprev, 0, 2); cprev = AZ_X6(cprev, 2, 0);
-    tnew = tprev;
-    return;
-#endif
     az_f32x16 t;
 #pragma unroll
     for (int e = 0; e < 16; ++e) t[e] = 0.f;
-#if AZ_STEP_VARIANT == 1
-    t = AZ_X6(t, 0, 0);
-    t = AZ_X6(t, 0, 1);
-    az_pk_add(cprev, tprev, 0); az_pk_add(cprev, tprev, 1);
-    t = AZ_X6(t, 1, 0);
-    az_pk_add(cprev, tprev, 2); az_pk_add(cprev, tprev, 3);
-    t = AZ_X6(t, 1, 1);
-    az_pk_add(cprev, tprev, 4); az_pk_add(cprev, tprev, 5);
-    t = AZ_X6(t, 0, 2);
-    az_pk_add(cprev, tprev, 6); az_pk_add(cprev, tprev, 7);
-    t = AZ_X6(t, 2, 0);
-    tnew = t;
-    asm volatile("" : "+v"(cprev));
-#else
     t = AZ_X6(t, 0, 0);
 #pragma unroll
     for (int e = 0; e < 3; ++e) cprev[e] += tprev[e];
@@ -181,12 +152,14 @@ __device__ __forceinline__ void az_mfma6_step(az_f32x16 &tnew, const float4 (&aq
     for (int e = 12; e < 16; ++e) cprev[e] += tprev[e];
     t = AZ_X6(t, 2, 0);
     tnew = t;
+    // the adds must stay HERE: without a use at this point LLVM sinks each add down to the next add of the
+    // same accumulator (a whole tap later), every temporary stays live and the kernel spills ~600 registers
     asm volatile("" : "+v"(cprev));
+    // pin the interleave: one MFMA, then three (four) of the independent adds, six times
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-#endif
 }
