@@ -8,16 +8,25 @@
 //           slab is staged once in LDS (voxel stride 36 dwords) and feeds three output planes
 //           through rolling accumulators; weights are wave-uniform scalar loads.  Optional
 //           fused "+ previous cost".
-//   dgrad : gin[v][c] = sum_k gout[v+1-k] * w[c][k]; 8 lanes per voxel (one channel
-//           quad each) -> every voxel's 128 B is written coalesced; the 3x10x34 gout
-//           halo tile lives in LDS, the lane's 108 weights in registers.
-//   wgrad : gw[c][k] = sum_v in[v][c] * gout[v+1-k]; same mapping, 108 register
+//   dgrad : gin[v][c] = sum_k gout[v+1-k] * w[c][k]; a lane owns one channel pair of EIGHT voxels adjacent
+//           in x: each row of the 3x10x(32+2) gout halo tile in LDS is read once as 10 values and serves
+//           8 voxels x 3 kw taps -- 27 wide LDS reads per 216 packed FMAs (the one-voxel-per-lane version
+//           issued 27 ds_read_b32 per 54 and was LDS-issue bound); the lane's 54 weights live in
+//           registers; every voxel's 128 B is written by 16 adjacent lanes.
+//   wgrad : gw[c][k] = sum_v in[v][c] * gout[v+1-k]; a lane owns one channel quad of FOUR adjacent voxels
+//           (6 tile values per row: one ds_read_b128 + one ds_read_b64), 108 register
 //           accumulators per lane, LDS reduction per block, 864 float atomics per block.
 #include "az_common.h"
 
 #define C1_TH 8
 #define C1_TW 32
 #define C1_VS 36
+#define C1_GP 36  // row pitch of the gout tile (dgrad / wgrad): rows start 16-byte aligned
+// the multiply-adds of dgrad / wgrad are written on channel PAIRS: v_pk_fma_f32 (two fp32 lanes per issue slot,
+// the scalar factor broadcast by op_sel); spelled out because hipcc's own pairing of the scalar form needs
+// ~0.7 v_mov per FMA to line the operands up
+typedef float c1_f2 __attribute__((ext_vector_type(2)));
+#define C1_FMA2(a, b, c) __builtin_elementwise_fma(a, b, c)
 
 
 // Marches along depth: input plane `id` is staged once and feeds the three output planes
@@ -86,44 +95,76 @@ __device__ __forceinline__ void c1_load_gtile(float *gt, const float *__restrict
         const int r = q / SX;
         const int sy = r % SY, sd = r / SY;
         const int gd = od - 1 + sd, gh = ty0 - 1 + sy, gw = tx0 - 1 + sx;
-        gt[q] = (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
-                    ? gout[(((size_t)b * D + gd) * H + gh) * W + gw] : 0.f;
+        gt[r * C1_GP + sx] = (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                                 ? gout[(((size_t)b * D + gd) * H + gh) * W + gw] : 0.f;
     }
+}
+// the 6 tile values under 4 adjacent voxels (lx0 .. lx0+3, lx0 % 4 == 0) of row (pd, sy): r[j + 2 - kw] is
+// gout at voxel j for tap kw
+__device__ __forceinline__ void c1_row6(float (&r)[6], const float *gt, int pd, int sy, int lx0) {
+    const float *row = static_cast<const float *>(__builtin_assume_aligned(gt + (pd * (C1_TH + 2) + sy) * C1_GP + lx0, 16));
+    const float4 a = *reinterpret_cast<const float4 *>(row);
+    const float2 c = *reinterpret_cast<const float2 *>(row + 4);
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = c.x; r[5] = c.y;
 }
 
 __global__ void __launch_bounds__(256)
 c1_dgrad_kernel(float *__restrict__ gin, const float *__restrict__ gout,
                 const float *__restrict__ w, int D, int H, int W, int tiles_x) {
-    constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
-    __shared__ float gt[3 * SY * SX];
+    constexpr int SY = C1_TH + 2;
+    __shared__ __attribute__((aligned(16))) float gt[3 * SY * C1_GP];
     const int tx0 = (blockIdx.x % tiles_x) * C1_TW, ty0 = (blockIdx.x / tiles_x) * C1_TH;
     const int od = blockIdx.y, b = blockIdx.z;
     c1_load_gtile(gt, gout, b, od, ty0, tx0, D, H, W);
-    const int quad = threadIdx.x & 7, vl = threadIdx.x >> 3;  // 32 voxels per pass
-    float wr[4][27];
+    // a lane owns one channel PAIR (54 weight registers) of EIGHT voxels adjacent in x; 16 lanes write a
+    // voxel's 128 B together
+    const int cp = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 groups of 8 voxels per pass
+    c1_f2 wp[27];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < 27; ++t) wr[c][t] = w[(quad * 4 + c) * 27 + t];
+    for (int t = 0; t < 27; ++t) wp[t] = c1_f2{w[(cp * 2 + 0) * 27 + t], w[(cp * 2 + 1) * 27 + t]};
     __syncthreads();
-    for (int p = 0; p < C1_TH; ++p) {  // one tile row (32 voxels) per pass
-        const int ly = p, lx = vl;
-        const int oh = ty0 + ly, ow = tx0 + lx;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int p = 0; p < C1_TH * C1_TW / 128; ++p) {  // 4 tile rows per pass
+        const int gi = p * 16 + grp, ly = gi >> 2, lx0 = (gi & 3) * 8;
+        const int oh = ty0 + ly;
+        c1_f2 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = c1_f2{0.f, 0.f};
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+            for (int kh = 0; kh < 3; ++kh) {
+                // gin[v] += gout[v + 1 - k] * w[k]; tile-local index of v+1-k is (+1) shifted
+                float r[12];
+                {
+                    const float *row = static_cast<const float *>(__builtin_assume_aligned(
+                        gt + ((2 - kd) * SY + ly + 2 - kh) * C1_GP + lx0, 16));
+                    const float4 a = *reinterpret_cast<const float4 *>(row);
+                    const float4 c = *reinterpret_cast<const float4 *>(row + 4);
+                    const float2 e = *reinterpret_cast<const float2 *>(row + 8);
+                    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = c.x; r[5] = c.y; r[6] = c.z; r[7] = c.w;
+                    r[8] = e.x; r[9] = e.y;
+                }
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    // gin[v] += gout[v + 1 - k] * w[k]; tile-local index of v+1-k is (+1) shifted
-                    const float g = gt[((2 - kd) * SY + (ly + 2 - kh)) * SX + lx + 2 - kw];
                     const int t = (kd * 3 + kh) * 3 + kw;
-                    acc.x += g * wr[0][t]; acc.y += g * wr[1][t];
-                    acc.z += g * wr[2][t]; acc.w += g * wr[3][t];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const c1_f2 g2 = {r[j + 2 - kw], r[j + 2 - kw]};
+                        acc[j] = C1_FMA2(g2, wp[t], acc[j]);
+                    }
                 }
-        if (oh < H && ow < W)
-            *reinterpret_cast<float4 *>(gin + ((((size_t)b * D + od) * H + oh) * W + ow) * 32 + quad * 4) = acc;
+            }
+        // (without this the compiler sinks each voxel's 27 FMAs into its own bounds-checked store below and keeps
+        //  all nine tile rows live: 184 registers, 114 v_mov per pass)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[j]));
+        if (oh < H) {
+            float *dst = gin + ((((size_t)b * D + od) * H + oh) * W + tx0 + lx0) * 32 + cp * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (tx0 + lx0 + j < W) *reinterpret_cast<float2 *>(dst + j * 32) = make_float2(acc[j][0], acc[j][1]);
+        }
     }
 }
 
@@ -131,16 +172,14 @@ __global__ void __launch_bounds__(256)
 c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
                 const float *__restrict__ gout, int D, int H, int W, int tiles_x, int tiles_y,
                 long long ntiles) {
-    constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
-    __shared__ float gt[3 * SY * SX];
+    constexpr int SY = C1_TH + 2;
+    __shared__ __attribute__((aligned(16))) float gt[3 * SY * C1_GP];
     __shared__ float red[864];
     for (int q = threadIdx.x; q < 864; q += 256) red[q] = 0.f;
-    const int quad = threadIdx.x & 7, vl = threadIdx.x >> 3;
-    float acc[4][27];
+    const int quad = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    c1_f2 a01[27], a23[27];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < 27; ++t) acc[c][t] = 0.f;
+    for (int t = 0; t < 27; ++t) { a01[t] = c1_f2{0.f, 0.f}; a23[t] = c1_f2{0.f, 0.f}; }
     // a block walks a strided list of (b, d, tile) items and keeps its 108 partial sums per
     // lane in registers, so the 864 global atomics are paid once per block, not once per tile
     for (long long item = blockIdx.x; item < ntiles; item += gridDim.x) {
@@ -152,24 +191,36 @@ c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
         __syncthreads();
         c1_load_gtile(gt, gout, b, od, ty0, tx0, D, H, W);
         __syncthreads();
-        for (int p = 0; p < C1_TH; ++p) {
-            const int ly = p, lx = vl;
-            const int ih = ty0 + ly, iw = tx0 + lx;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ih < H && iw < W)
-                x = *reinterpret_cast<const float4 *>(in + ((((size_t)b * D + od) * H + ih) * W + iw) * 32 + quad * 4);
+#pragma unroll 1
+        for (int p = 0; p < C1_TH * C1_TW / 128; ++p) {
+            const int gi = p * 32 + grp, ly = gi >> 3, lx0 = (gi & 7) * 4;
+            const int ih = ty0 + ly;
+            c1_f2 x01[4], x23[4];
+            const float *src = in + ((((size_t)b * D + od) * H + ih) * W + tx0 + lx0) * 32 + quad * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ih < H && tx0 + lx0 + j < W) x = *reinterpret_cast<const float4 *>(src + j * 32);
+                x01[j] = c1_f2{x.x, x.y}; x23[j] = c1_f2{x.z, x.w};
+            }
 #pragma unroll
             for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh) {
+                    // out[o] = sum_k in[o - 1 + k] w[k]  =>  gw[k] += in[v] * gout[v + 1 - k]
+                    float r[6];
+                    c1_row6(r, gt, 2 - kd, ly + 2 - kh, lx0);
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        // out[o] = sum_k in[o - 1 + k] w[k]  =>  gw[k] += in[v] * gout[v + 1 - k]
-                        const float g = gt[((2 - kd) * SY + (ly + 2 - kh)) * SX + lx + 2 - kw];
                         const int t = (kd * 3 + kh) * 3 + kw;
-                        acc[0][t] += x.x * g; acc[1][t] += x.y * g;
-                        acc[2][t] += x.z * g; acc[3][t] += x.w * g;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const c1_f2 g2 = {r[j + 2 - kw], r[j + 2 - kw]};
+                            a01[t] = C1_FMA2(x01[j], g2, a01[t]);
+                            a23[t] = C1_FMA2(x23[j], g2, a23[t]);
+                        }
                     }
+                }
         }
     }
     // reduce the 32 voxel-lanes that share a channel quad: lanes with equal (lane & 7);
@@ -178,7 +229,7 @@ c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
-            float v = acc[c][t];
+            float v = (c < 2 ? a01[t] : a23[t])[c & 1];
             v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
             if ((threadIdx.x & 63) < 8) atomicAdd(&red[(quad * 4 + c) * 27 + t], v);
         }

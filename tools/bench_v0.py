@@ -26,3 +26,14 @@ for name, fn in (("fwd+stats", lambda: conv3d._run_gather(x, pk, conv3d.CONV_S1,
                  ("wgrad", lambda: conv3d._wgrad(g, x, 1, C, C, "conv", A.wgrad))):
     ms = timeit(fn)
     print(f"V0 {name:10s} {ms:7.3f} ms  {gf / ms:6.1f} TFLOP/s  ({gf / ms / 416.7:.2f} of 416.7)")
+# classifier convolution (32 -> 1): VALU kernels, priced against the bytes they must move
+from activezero_amd.ops import _call, _p, _stream
+wc = torch.randn(1, C, 3, 3, 3, device=dev) * 0.05
+go = torch.randn(B, D, H, W, device=dev)
+out = torch.empty(B, D, H, W, device=dev); gx = torch.empty_like(x); gwc = torch.empty_like(wc)
+mb = 4.0 * (x.numel() + out.numel()) / 1e6
+for name, fn in (("c1 fwd", lambda: _call("az_conv3d_c1_fwd", _p(out), _p(x), _p(wc), None, B, D, H, W, _stream())),
+                 ("c1 dgrad", lambda: _call("az_conv3d_c1_dgrad", _p(gx), _p(go), _p(wc), B, D, H, W, _stream())),
+                 ("c1 wgrad", lambda: _call("az_conv3d_c1_wgrad", _p(gwc), _p(x), _p(go), B, D, H, W, _stream()))):
+    ms = timeit(fn)
+    print(f"V0 {name:10s} {ms:7.3f} ms  {mb / ms / 1e3:6.2f} TB/s of {mb:.0f} MB")
