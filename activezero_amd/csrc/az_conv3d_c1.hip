@@ -4,10 +4,10 @@
 //
 // N = 1 is not MFMA-shaped (and fp32 MFMA runs at the VALU rate anyway): these are
 // VALU kernels, 2*27*32 flops per voxel against 128 B of input -> HBM/LDS bound.
-//   fwd   : block = 8x32 output voxels marching over a depth segment (chosen per launch); each 10x34x32ch input
+//   fwd   : block = 8x16 output voxels marching over a depth segment (chosen per launch); each 10x18x32ch input
 //           slab is staged once in LDS (voxel stride 36 dwords) and feeds three output planes
-//           through rolling accumulators; weights are wave-uniform scalar loads.  Optional
-//           fused "+ previous cost".
+//           through rolling accumulators; a lane owns a channel pair of 8 adjacent voxels (weights in
+//           registers), the 16 lanes of a voxel group reduce with DPP.  Optional fused "+ previous cost".
 //   dgrad : gin[v][c] = sum_k gout[v+1-k] * w[c][k]; a lane owns one channel pair of EIGHT voxels adjacent
 //           in x: each row of the 3x10x(32+2) gout halo tile in LDS is read once as 10 values and serves
 //           8 voxels x 3 kw taps -- 27 wide LDS reads per 216 packed FMAs (the one-voxel-per-lane version
@@ -33,56 +33,102 @@ typedef float c1_f2 __attribute__((ext_vector_type(2)));
 // id+1 (kd=0), id (kd=1), id-1 (kd=2) through three rolling accumulators, so the slab and every
 // LDS read are shared by three taps (the first version re-staged three planes per output plane:
 // 3x the global and LDS traffic, 0.75 ms at B=4 full size).
+// Lane mapping (second version; the first gave every lane ONE voxel and all 32 channels with scalar weights:
+// 72 ds_read_b128 per 432 packed FMAs, LDS-issue bound at 0.47 ms): a lane owns one channel PAIR of EIGHT
+// voxels adjacent in x.  A tile row is read once as 10 float2 (30 ds_read_b64 per plane) and serves
+// 8 voxels x 3 kw x 3 kd = 216 packed FMAs against the lane's 27 weight pairs in registers; the 16 lanes of
+// a voxel group then sum their channel pairs with four DPP row steps per output value.
+#define C1F_TH 8
+#define C1F_TW 16
+template <int CTRL>
+__device__ __forceinline__ float c1_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __global__ void __launch_bounds__(256)
 c1_fwd_kernel(float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
               const float *__restrict__ addend, int D, int H, int W, int tiles_x, int dseg) {
-    extern __shared__ __attribute__((aligned(16))) float slab[];  // (TH+2)*(TW+2)*36
-    const int tx0 = (blockIdx.x % tiles_x) * C1_TW, ty0 = (blockIdx.x / tiles_x) * C1_TH;
+    constexpr int SX = C1F_TW + 2, SY = C1F_TH + 2;
+    __shared__ __attribute__((aligned(16))) float slab[SY * SX * C1_VS];
+    const int tx0 = (blockIdx.x % tiles_x) * C1F_TW, ty0 = (blockIdx.x / tiles_x) * C1F_TH;
     const int d0 = blockIdx.y * dseg, d1 = min(d0 + dseg, D), b = blockIdx.z;
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    constexpr int SX = C1_TW + 2, SY = C1_TH + 2;
-    const int oh = ty0 + ly, ow = tx0 + lx;
-    const bool live = oh < H && ow < W;
-    float a_prev = 0.f, a_cur = 0.f, a_next = 0.f;  // output planes id-1, id, id+1
+    const int cp = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int ly = grp >> 1, lx0 = (grp & 1) * 8;
+    const int oh = ty0 + ly;
+    c1_f2 wp[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) wp[t] = c1_f2{w[(cp * 2 + 0) * 27 + t], w[(cp * 2 + 1) * 27 + t]};
+    c1_f2 a_prev[8], a_cur[8], a_next[8];  // output planes id-1, id, id+1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a_prev[j] = c1_f2{0.f, 0.f}; a_cur[j] = c1_f2{0.f, 0.f}; a_next[j] = c1_f2{0.f, 0.f}; }
+    // plane id+1 travels global -> registers while plane id is multiplied; it is written to LDS after the
+    // block has finished reading plane id
+    constexpr int NQ = SY * SX * 8, NLD = (NQ + 255) / 256;
+    float4 pre[NLD];
+    auto issue = [&](int id) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int q = threadIdx.x + 256 * it, v = q >> 3, part = q & 7;
+            const int sy = v / SX, sx = v - sy * SX;
+            const int ih = ty0 - 1 + sy, iw = tx0 - 1 + sx;
+            pre[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < NQ && id >= 0 && id < D && ih >= 0 && ih < H && iw >= 0 && iw < W)
+                pre[it] = *reinterpret_cast<const float4 *>(
+                    in + ((((size_t)b * D + id) * H + ih) * W + iw) * 32 + part * 4);
+        }
+    };
+    issue(d0 - 1);
     for (int id = d0 - 1; id <= d1; ++id) {
         if (id >= 0 && id < D) {  // block-uniform; planes outside the volume are zero padding
             __syncthreads();
-            for (int q = threadIdx.x; q < SY * SX * 8; q += 256) {
-                const int v = q >> 3, part = q & 7;
-                const int sy = v / SX, sx = v - sy * SX;
-                const int ih = ty0 - 1 + sy, iw = tx0 - 1 + sx;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
-                    val = *reinterpret_cast<const float4 *>(
-                        in + ((((size_t)b * D + id) * H + ih) * W + iw) * 32 + part * 4);
-                *reinterpret_cast<float4 *>(&slab[v * C1_VS + part * 4]) = val;
+#pragma unroll
+            for (int it = 0; it < NLD; ++it) {
+                const int q = threadIdx.x + 256 * it;
+                if (q < NQ) *reinterpret_cast<float4 *>(&slab[(q >> 3) * C1_VS + (q & 7) * 4]) = pre[it];
             }
             __syncthreads();
-            // channel quad outermost: its 4 x 27 weights are contiguous in w ([1][32][27]) and
-            // wave-uniform -> wide scalar loads
-#pragma unroll 1
-            for (int c4 = 0; c4 < 8; ++c4) {
-                const float *wq = w + c4 * 4 * 27;
+        }
+        if (id < d1) issue(id + 1);
+        if (id >= 0 && id < D) {
 #pragma unroll
-                for (int t9 = 0; t9 < 9; ++t9) {
-                    const float4 x = *reinterpret_cast<const float4 *>(
-                        &slab[((ly + t9 / 3) * SX + lx + t9 % 3) * C1_VS + 4 * c4]);
-                    const float xs[4] = {x.x, x.y, x.z, x.w};
+            for (int kh = 0; kh < 3; ++kh) {
+                c1_f2 r[10];
+                const float *row = &slab[((ly + kh) * SX + lx0) * C1_VS + cp * 2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a_next += xs[e] * wq[e * 27 + t9];       // kd = 0 -> output plane id+1
-                        a_cur += xs[e] * wq[e * 27 + 9 + t9];    // kd = 1 -> id
-                        a_prev += xs[e] * wq[e * 27 + 18 + t9];  // kd = 2 -> id-1
-                    }
+                for (int i = 0; i < 10; ++i) {
+                    const float2 x = *reinterpret_cast<const float2 *>(row + i * C1_VS);
+                    r[i] = c1_f2{x.x, x.y};
                 }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        a_next[j] = C1_FMA2(r[j + kw], wp[kh * 3 + kw], a_next[j]);       // kd = 0 -> plane id+1
+                        a_cur[j] = C1_FMA2(r[j + kw], wp[9 + kh * 3 + kw], a_cur[j]);     // kd = 1 -> id
+                        a_prev[j] = C1_FMA2(r[j + kw], wp[18 + kh * 3 + kw], a_prev[j]);  // kd = 2 -> id-1
+                    }
             }
         }
         const int od = id - 1;  // complete now: it has seen planes od-1, od, od+1
-        if (od >= d0 && od < d1 && live) {
-            const size_t o = (((size_t)b * D + od) * H + oh) * W + ow;
-            out[o] = addend ? a_prev + addend[o] : a_prev;
+        if (od >= d0 && od < d1) {  // block-uniform
+            // sum the 16 channel pairs of each voxel: xor 1, xor 2 inside quads, then the two row mirrors
+            float mine = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = a_prev[j][0] + a_prev[j][1];
+                v = c1_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+                v = c1_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+                v = c1_dpp_add<0x141>(v);  // row_half_mirror
+                v = c1_dpp_add<0x140>(v);  // row_mirror
+                mine = (cp == j) ? v : mine;
+            }
+            const int ow = tx0 + lx0 + cp;
+            if (cp < 8 && oh < H && ow < W) {
+                const size_t o = (((size_t)b * D + od) * H + oh) * W + ow;
+                out[o] = addend ? mine + addend[o] : mine;
+            }
         }
-        a_prev = a_cur; a_cur = a_next; a_next = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a_prev[j] = a_cur[j]; a_cur[j] = a_next[j]; a_next[j] = c1_f2{0.f, 0.f}; }
     }
 }
 
@@ -247,10 +293,9 @@ extern "C" int az_conv3d_c1_fwd(float *logits, const float *in, const float *w,
                                 const float *addend, int B, int D, int H, int W, void *stream) {
     AZ_REQUIRE_PTR(logits); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(w);
     if (int e = c1_check(B, D, H, W)) return e;
-    const int tiles_x = (W + C1_TW - 1) / C1_TW, tiles_y = (H + C1_TH - 1) / C1_TH;
-    const size_t lds = (size_t)(C1_TH + 2) * (C1_TW + 2) * C1_VS * sizeof(float);
+    const int tiles_x = (W + C1F_TW - 1) / C1F_TW, tiles_y = (H + C1F_TH - 1) / C1F_TH;
     // depth segment per block: every segment stages 2 halo planes, and the grid should fill a whole
-    // number of residency rounds (3 blocks of 49 KB LDS per CU x 256 CUs); minimise rounds x planes
+    // number of residency rounds (3 blocks per CU x 256 CUs by registers); minimise rounds x planes
     int best = 1;
     long long best_cost = -1;
     for (int nseg = 1; nseg <= D; ++nseg) {
@@ -259,7 +304,7 @@ extern "C" int az_conv3d_c1_fwd(float *logits, const float *in, const float *w,
         const long long cost = ((blocks + 767) / 768) * (dseg + 2);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = dseg; }
     }
-    hipLaunchKernelGGL(c1_fwd_kernel, dim3(tiles_x * tiles_y, (D + best - 1) / best, B), dim3(256), lds,
+    hipLaunchKernelGGL(c1_fwd_kernel, dim3(tiles_x * tiles_y, (D + best - 1) / best, B), dim3(256), 0,
                        az_stream(stream), logits, in, w, addend, D, H, W, tiles_x, best);
     return az_launch_status();
 }
