@@ -59,8 +59,8 @@ def deconv_bn(vol, unit, relu=False, add=None, arith=None):
     return conv3d.conv_bn(vol, unit[0], unit[1], conv3d.DECONV_S2, relu, add, arith)
 
 
-def conv_logits(vol, conv, add=None):
-    return conv3d.conv_logits(vol, conv, add)
+def conv_logits(vol, conv, add=None, arith=None):
+    return conv3d.conv_logits(vol, conv, add, arith.sink if arith is not None else None)
 
 
 def add(a, b):

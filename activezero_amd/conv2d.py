@@ -17,7 +17,7 @@ triplet image made per call (memoised between no_grad forwards).
 """
 import torch
 
-from . import _lib, conv3d, profiler
+from . import _lib, conv3d, overlap, profiler
 from .conv3d import _cache_get, _cache_key, _cache_put
 from .ops import _call, _chk, _p, _stream
 
@@ -70,19 +70,27 @@ def _run(xr, packed, cin, cout, kh, kw, dil, scale=None, shift=None, res=None, r
     return out
 
 
-def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d"):
-    """gr: [B,H,W,>=cm] grad rows, xr: [B,H,W,>=cn] input rows -> [cm_real, cn_real, kh, kw]."""
+def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=None):
+    """gr: [B,H,W,>=cm] grad rows, xr: [B,H,W,>=cn] input rows -> [cm_real, cn_real, kh, kw].
+    sink: overlap.Sink or None -- the kernels run on its side stream (the result is valid after its join)."""
     b, h, w, _ = xr.shape
     gw = xr.new_empty(cm_real, cn_real, kh, kw)
     ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cm, cn, kh, kw)
     if ws_bytes < 0:
         raise RuntimeError(f"conv2d wgrad: unsupported channel counts {cm} x {cn}")
-    ws = xr.new_empty(ws_bytes // 4)
-    with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
-                        peak=PEAK_X6):
-        _call("az_conv2d_wgrad", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w, cm, cn, cm_real, cn_real,
-              gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
+    with overlap.scope(sink, gr, xr):
+        ws = xr.new_empty(ws_bytes // 4)
+        with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
+                            peak=PEAK_X6):
+            _call("az_conv2d_wgrad", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w, cm, cn, cm_real, cn_real,
+                  gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
     return gw
+
+
+def _leaf_sink(sink, weight):
+    """A sink defers a weight gradient past the point where autograd hands it on; that is only sound when the
+    next reader is the parameter's AccumulateGrad (overlap.py), i.e. when the weight is a leaf."""
+    return sink if (sink is not None and weight.is_leaf) else None
 
 
 class _ConvSame(torch.autograd.Function):
@@ -94,7 +102,8 @@ class _ConvSame(torch.autograd.Function):
     kernel of the autograd engine (one read + one write of the activation per block saved)."""
 
     @staticmethod
-    def forward(ctx, x, weight, dil, with_skip):
+    def forward(ctx, x, weight, dil, with_skip, sink=None):
+        ctx.sink = _leaf_sink(sink, weight)
         cout, cin, kh, kw = weight.shape
         xr = _chk(rows(x), "x")
         with torch.cuda.device(x.device):
@@ -113,7 +122,7 @@ class _ConvSame(torch.autograd.Function):
         cout, cin, kh, kw = weight.shape
         dil = ctx.dil
         if gy is None:  # only the shortcut was used downstream
-            return gskip, None, None, None
+            return gskip, None, None, None, None
         gr = _chk(rows(gy), "grad_y")
         gx = gw = None
         with torch.cuda.device(gy.device):
@@ -122,8 +131,8 @@ class _ConvSame(torch.autograd.Function):
                 sk = _chk(rows(gskip), "grad_skip") if gskip is not None else None
                 gx = image(_run(gr, pk, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
             if ctx.needs_input_grad[1]:
-                gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil)
-        return gx, gw, None, None
+                gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil, sink=ctx.sink)
+        return gx, gw, None, None, None
 
 
 def _check_same(weight, dilation):
@@ -133,14 +142,14 @@ def _check_same(weight, dilation):
     return 1 if kh == 1 else dilation
 
 
-def conv_same(x, weight, dilation=1):
+def conv_same(x, weight, dilation=1, sink=None):
     """F.conv2d(x, weight, padding="same", dilation=dilation) for [B,C,H,W] x (channels_last preferred)."""
-    return _ConvSame.apply(x, weight, _check_same(weight, dilation), False)
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), False, sink)
 
 
-def conv_same_skip(x, weight, dilation=1):
+def conv_same_skip(x, weight, dilation=1, sink=None):
     """(conv_same(x, weight, dilation), x): the second output is x for the block's shortcut (see _ConvSame)."""
-    return _ConvSame.apply(x, weight, _check_same(weight, dilation), True)
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), True, sink)
 
 
 class _ConvS2Vol(torch.autograd.Function):
@@ -159,6 +168,7 @@ class _ConvS2Vol(torch.autograd.Function):
             y = conv3d._run_gather(xv, pk, conv3d.CONV_S2, cin, cout, arith.conv, tag="fe2d_s2")
         ctx.save_for_backward(xv, w3)
         ctx.arith = arith
+        ctx.sink = _leaf_sink(arith.sink, weight)
         return image(y.squeeze(1))
 
     @staticmethod
@@ -173,7 +183,10 @@ class _ConvS2Vol(torch.autograd.Function):
                 g2 = conv3d._input_grad(gv, w3, conv3d.CONV_S2, cin, cout, arith.conv)  # [B,2,H,W,cin]
                 gx = image(g2[:, 0, :xv.shape[2], :xv.shape[3]])
             if ctx.needs_input_grad[1]:
-                gw = conv3d._weight_grad(xv, gv, conv3d.CONV_S2, cin, cout, arith.wgrad)[:, :, 1].contiguous()
+                g3 = conv3d._weight_grad(xv, gv, conv3d.CONV_S2, cin, cout, arith.wgrad, ctx.sink)
+                gw = g3.new_empty(cout, cin, 3, 3)
+                with overlap.scope(ctx.sink, g3):  # the slice reads g3 on the stream that wrote it
+                    gw.copy_(g3[:, :, 1])
         return gx, gw, None
 
 
@@ -181,7 +194,13 @@ class _ConvS2Patches(torch.autograd.Function):
     """3x3, stride 2, pad 1 on a thin image (C = 3 or 6 -> 32): patch extraction + 1x1 convolution."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, sink=None, token=None):
+        # `token`: the sink's 1-element tensor (overlap._Tail's output).  This layer is the first convolution of
+        # the extractor, hence the last convolution node of the backward pass: its gradient for the token is
+        # what makes _Tail.backward -- the join of the side stream -- run after every weight-gradient launch.
+        ctx.sink = _leaf_sink(sink, weight)
+        if ctx.sink is not None and token is not None and token.requires_grad:
+            ctx.sink.armed = True
         cout, cin = weight.shape[:2]
         xr = _chk(rows(x), "x")
         b, h, w, _ = xr.shape
@@ -213,9 +232,12 @@ class _ConvS2Patches(torch.autograd.Function):
                 _call("az_col2im_s2k3", _p(gxr), _p(gp), b, cin, h, w, kp, _stream())
                 gx = image(gxr)
             if ctx.needs_input_grad[1]:
-                g2 = _wgrad(gr, patches, cout, kp, cout, 9 * cin, 1, 1, 1, tag="fe2d_first")  # [cout, 9cin,1,1]
-                gw = g2.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
-        return gx, gw
+                g2 = _wgrad(gr, patches, cout, kp, cout, 9 * cin, 1, 1, 1, tag="fe2d_first", sink=ctx.sink)  # [cout, 9cin,1,1]
+                gw = g2.new_empty(cout, cin, 3, 3)
+                with overlap.scope(ctx.sink, g2):
+                    gw.copy_(g2.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2))
+        gtok = gr.new_zeros(1) if ctx.needs_input_grad[3] else None
+        return gx, gw, None, gtok
 
 
 def is_same(m):
@@ -233,16 +255,17 @@ def conv(x, m, arith=None, skip=False):
     k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
     cin, cout = m.in_channels, m.out_channels
     if is_same(m):
-        return (conv_same_skip if skip else conv_same)(x, m.weight, d[0])
+        return (conv_same_skip if skip else conv_same)(x, m.weight, d[0], arith.sink)
     if skip:
         raise RuntimeError(f"conv2d.conv: skip output needs a stride-1 layer, got {m}")
     if s == (2, 2) and k == (3, 3) and p == (1, 1) and d == (1, 1):
         if cin in (32, 64) and cout in (32, 64) and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
             return _ConvS2Vol.apply(x, m.weight, arith)
         if 9 * cin <= 64 and cout % 32 == 0:
-            return _ConvS2Patches.apply(x, m.weight)
+            sink = arith.sink
+            return _ConvS2Patches.apply(x, m.weight, sink, sink.token if sink is not None else None)
     if s == (2, 2) and k == (1, 1) and p == (0, 0):
-        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), m.weight, 1)
+        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), m.weight, 1, arith.sink)
     raise RuntimeError(f"conv2d.conv: unsupported layer {m}")
 
 

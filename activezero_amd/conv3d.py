@@ -19,7 +19,7 @@ import threading
 
 import torch
 
-from . import _lib, profiler
+from . import _lib, overlap, profiler
 from .ops import _call, _chk, _p, _stream
 
 CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
@@ -27,12 +27,14 @@ FP32, BF16X6 = 0, 1
 _PREC = {"fp32": FP32, "bf16x6": BF16X6}
 
 
-class Arith(collections.namedtuple("Arith", "conv wgrad")):
+class Arith(collections.namedtuple("Arith", "conv wgrad sink", defaults=(None,))):
     """Arithmetic of the MFMA kernels, passed with every call (no process-wide switch):
       fp32   -- v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chain (157 TFLOP/s peak)
       bf16x6 -- exact 3-way bf16 split of both operands, six bf16 MFMAs per product, fp32
                 accumulate: fp32-class accuracy (measured ~1e-7 relative) at 2.7x the rate
-    `conv` covers forward / input-gradient / transposed kernels, `wgrad` the weight gradients."""
+    `conv` covers forward / input-gradient / transposed kernels, `wgrad` the weight gradients.
+    `sink` (overlap.Sink or None) is not arithmetic but travels the same way, with every call: when set, the
+    weight-gradient kernels of this forward/backward pass run on its side stream (overlap.py)."""
     __slots__ = ()
 
     @classmethod
@@ -200,16 +202,17 @@ def _run_gather(x, packed, mode, cin, cout, precision, scale=None, shift=None, r
     return out
 
 
-def _wgrad(coarse, fine, stride, cm, cn, tag, precision):
+def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
     b, dc, hc, wc, _ = _dims(coarse)
     _, df, hf, wf, _ = _dims(fine)
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
     ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
-    ws = coarse.new_empty(ws_bytes // 4)
-    with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
-                        peak=_peak(precision)):
-        _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, precision,
-              b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
+    with overlap.scope(sink, coarse, fine):
+        ws = coarse.new_empty(ws_bytes // 4)
+        with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
+                            peak=_peak(precision)):
+            _call("az_conv3d_wgrad", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), stride, precision,
+                  b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
     return gw
 
 
@@ -225,10 +228,10 @@ def _input_grad(dy, weight, mode, cin, cout, precision):
     return _run_gather(dy, pk, CONV_S2, cout, cin, precision, tag="dgrad")
 
 
-def _weight_grad(x, dy, mode, cin, cout, precision):
+def _weight_grad(x, dy, mode, cin, cout, precision, sink=None):
     if mode == DECONV_S2:
-        return _wgrad(x, dy, 2, cin, cout, "deconv", precision)
-    return _wgrad(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", precision)
+        return _wgrad(x, dy, 2, cin, cout, "deconv", precision, sink)
+    return _wgrad(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", precision, sink)
 
 
 class _ConvBN(torch.autograd.Function):
@@ -276,6 +279,8 @@ class _ConvBN(torch.autograd.Function):
         remask = relu and residual is None
         ctx.save_for_backward(x, weight, gamma, raw, y if (relu and not remask) else None, mean, invstd,
                               scale if remask else None, shift if remask else None)
+        if arith.sink is not None and not weight.is_leaf:  # see conv2d._leaf_sink
+            arith = arith._replace(sink=None)
         ctx.cfg = (mode, relu, residual is not None, cin, cout, arith, True)
         return y
 
@@ -314,7 +319,7 @@ class _ConvBN(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 gx = _input_grad(dx_raw, weight, mode, cin, cout, arith.conv)
             if ctx.needs_input_grad[1]:
-                gw = _weight_grad(x, dx_raw, mode, cin, cout, arith.wgrad)
+                gw = _weight_grad(x, dx_raw, mode, cin, cout, arith.wgrad, arith.sink)
         return gx, gw, dgamma, dbeta, g_res, None, None, None, None
 
 
@@ -343,7 +348,8 @@ class _ConvLogits(torch.autograd.Function):
     """logits = Conv3d(32 -> 1)(x) + addend  (classifN[2] and the running cost sums)."""
 
     @staticmethod
-    def forward(ctx, x, weight, addend):
+    def forward(ctx, x, weight, addend, sink):
+        ctx.sink = sink if (sink is not None and weight.is_leaf) else None
         x = _chk(x, "x")
         w = _chk(weight.detach().contiguous(), "weight")
         b, d, h, wd, c = _dims(x)
@@ -372,13 +378,14 @@ class _ConvLogits(torch.autograd.Function):
                     _call("az_conv3d_c1_dgrad", _p(gx), _p(g), _p(w), b, d, h, wd, _stream())
             if ctx.needs_input_grad[1]:
                 gw = torch.empty_like(w)
-                with profiler.scope("conv3d_c1_wgrad", bytes=4.0 * (x.numel() + g.numel()), bound="hbm"):
+                with overlap.scope(ctx.sink, x, g), \
+                        profiler.scope("conv3d_c1_wgrad", bytes=4.0 * (x.numel() + g.numel()), bound="hbm"):
                     _call("az_conv3d_c1_wgrad", _p(gw), _p(x), _p(g), b, d, h, wd, _stream())
-        return gx, gw, (g if ctx.has_add else None)
+        return gx, gw, (g if ctx.has_add else None), None
 
 
-def conv_logits(x, conv, addend=None):
-    return _ConvLogits.apply(x, conv.weight, addend)
+def conv_logits(x, conv, addend=None, sink=None):
+    return _ConvLogits.apply(x, conv.weight, addend, sink)
 
 
 class _AddRelu(torch.autograd.Function):

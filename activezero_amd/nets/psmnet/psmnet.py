@@ -15,5 +15,6 @@ class PSMNet(_p3.PSMNet):
 
     def forward(self, img_L, img_R, img_L_transformed, img_R_transformed):
         cat = lambda a, b: self._nhwc(torch.cat((a, b), 1))  # psmnet_submodule.py:167 (image + adapter output)
+        a = self._pass_arith(img_L)
         return self._from_features(*self.feature_extraction.forward_pair(cat(img_L, img_L_transformed),
-                                                                          cat(img_R, img_R_transformed)))
+                                                                          cat(img_R, img_R_transformed), a), a)

@@ -14,6 +14,7 @@ hard-codes .cuda(); this path has no CPU fallback).
 """
 import math
 
+from activezero_amd import overlap
 from activezero_amd import agg3d, conv3d, ops
 from activezero_amd.nets.psmnet.psmnet_submodule_3 import *  # noqa: F401,F403
 from activezero_amd.nets.psmnet import psmnet_submodule_3 as _sub
@@ -84,6 +85,12 @@ class PSMNet(nn.Module):
         # arithmetic of the MFMA kernels of THIS module (conv3d.Arith): an attribute, not a
         # process-wide switch -- two models with different arithmetic can run side by side
         self.arith = conv3d.DEFAULT_ARITH
+        # weight-gradient kernels of a training pass on a second stream, beside the rest of the backward pass
+        self.wgrad_overlap = True
+
+    def set_weight_grad_overlap(self, enabled=True):
+        self.wgrad_overlap = bool(enabled)
+        return self
 
     def set_arithmetic(self, conv="bf16x6", wgrad=None):
         """'bf16x6' (default: exact 3-way bf16 split, six MFMAs per product) or 'fp32' (fp32 MFMA)."""
@@ -103,8 +110,8 @@ class PSMNet(nn.Module):
                 m.bias.data.zero_()
 
     # -- hot path ------------------------------------------------------------
-    def _aggregate(self, vol, first=None):
-        a = self.arith
+    def _aggregate(self, vol, first=None, arith=None):
+        a = self.arith if arith is None else arith
         # `first`: dres0[0]'s activation when it was computed straight from the feature maps
         c0 = first if first is not None else agg3d.conv_bn(vol, self.dres0[0], relu=True, arith=a)
         c0 = agg3d.conv_bn(c0, self.dres0[2], relu=True, arith=a)
@@ -118,19 +125,26 @@ class PSMNet(nn.Module):
         out3, _pre3, _post3 = self.dres4(out2, pre1, post2, out_add=c0d, arith=a)
 
         def head(cls, v, running):
-            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True, arith=a), cls[2], running)
+            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True, arith=a), cls[2], running, arith=a)
 
         cost1 = head(self.classif1, out1, None)
         cost2 = head(self.classif2, out2, cost1)
         cost3 = head(self.classif3, out3, cost2)
         return cost1, cost2, cost3
 
-    def _from_features(self, feat_l, feat_r):
+    def _pass_arith(self, like):
+        """The per-call arithmetic of ONE forward pass: self.arith plus, in training passes, a fresh
+        overlap.Sink (weight-gradient kernels on a side stream; overlap.py explains why autograd and DDP are
+        unaffected).  Nothing is stored on the module."""
+        sink = overlap.begin(self, like) if self.wgrad_overlap else None
+        return self.arith._replace(sink=sink)
+
+    def _from_features(self, feat_l, feat_r, arith=None):
+        a = self.arith if arith is None else arith
         # cost volume + dres0[0] factored into 2-D convolutions of the two feature maps: the
         # [B,64,D/4,h,w] volume (psmnet_3.py:149-163) and its gradient are never formed
-        first = agg3d.costvol_conv_bn(feat_l, feat_r, self.maxdisp // 4, self.dres0[0], relu=True,
-                                      arith=self.arith)
-        cost1, cost2, cost3 = self._aggregate(None, first)
+        first = agg3d.costvol_conv_bn(feat_l, feat_r, self.maxdisp // 4, self.dres0[0], relu=True, arith=a)
+        cost1, cost2, cost3 = self._aggregate(None, first, a)
         pred3 = ops.softargmin(cost3)
         if self.training:
             return pred3, ops.softargmin(cost2), ops.softargmin(cost1)
@@ -142,4 +156,5 @@ class PSMNet(nn.Module):
 
     def forward(self, img_L, img_R):
         # both images in one pass of the extractor, statistics per image set (forward_pair)
-        return self._from_features(*self.feature_extraction.forward_pair(self._nhwc(img_L), self._nhwc(img_R)))
+        a = self._pass_arith(img_L)
+        return self._from_features(*self.feature_extraction.forward_pair(self._nhwc(img_L), self._nhwc(img_R), a), a)

@@ -15,10 +15,11 @@ import torch.nn.functional as F
 from activezero_amd import bn2d, conv2d
 
 
-def _convbn_unit(x, unit, relu=False, residual=None, groups=1, skip=False):
+def _convbn_unit(x, unit, relu=False, residual=None, groups=1, skip=False, arith=None):
     """unit = Sequential(Conv2d, BatchNorm2d): y = relu?(bn(conv(x)) + residual).
     skip=True returns (y, x'), x' = x routed through the convolution's autograd node for the caller's
     shortcut, so that the shortcut's gradient is added inside the input-gradient kernel (conv2d._ConvSame).
+    `arith`: conv3d.Arith of the pass (arithmetic of the stride-2 route, weight-gradient sink), None = default.
     `groups`: consecutive equal parts of the batch that take their OWN batch statistics (2 when the left
     and right images run as one stacked batch, FeatureExtraction.forward_pair); passed down explicitly --
     no module-level state, so replicas on several threads (nn.DataParallel, train.py:540-541) cannot
@@ -35,9 +36,9 @@ def _convbn_unit(x, unit, relu=False, residual=None, groups=1, skip=False):
         if y is not None:
             return (y, x) if skip else y
     if skip and torch.is_grad_enabled() and x.requires_grad and conv2d.is_same(conv):
-        c, shortcut = conv2d.conv(x, conv, skip=True)
+        c, shortcut = conv2d.conv(x, conv, arith, skip=True)
         return bn2d.bn_act(c, bn, relu, residual, groups), shortcut
-    y = bn2d.bn_act(conv2d.conv(x, conv), bn, relu, residual, groups)
+    y = bn2d.bn_act(conv2d.conv(x, conv, arith), bn, relu, residual, groups)
     return (y, x) if skip else y
 
 
@@ -79,13 +80,13 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, arith=None):
         if self.downsample is None:
-            y, shortcut = _convbn_unit(x, self.conv1[0], relu=True, groups=groups, skip=True)
+            y, shortcut = _convbn_unit(x, self.conv1[0], relu=True, groups=groups, skip=True, arith=arith)
         else:
-            shortcut = _convbn_unit(x, self.downsample, groups=groups)
-            y = _convbn_unit(x, self.conv1[0], relu=True, groups=groups)
-        return _convbn_unit(y, self.conv2, relu=False, residual=shortcut, groups=groups)
+            shortcut = _convbn_unit(x, self.downsample, groups=groups, arith=arith)
+            y = _convbn_unit(x, self.conv1[0], relu=True, groups=groups, arith=arith)
+        return _convbn_unit(y, self.conv2, relu=False, residual=shortcut, groups=groups, arith=arith)
 
 
 class DisparityRegression(nn.Module):
@@ -171,20 +172,20 @@ class FeatureExtraction(nn.Module):
         layers += [block(self.inplanes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def _trunk(self, x, groups=1):
-        g = groups
-        y = _convbn_unit(x, self.firstconv[0], relu=True, groups=g)
-        y = _convbn_unit(y, self.firstconv[2], relu=True, groups=g)
-        y = _convbn_unit(y, self.firstconv[4], relu=True, groups=g)
+    def _trunk(self, x, groups=1, arith=None):
+        g, a = groups, arith
+        y = _convbn_unit(x, self.firstconv[0], relu=True, groups=g, arith=a)
+        y = _convbn_unit(y, self.firstconv[2], relu=True, groups=g, arith=a)
+        y = _convbn_unit(y, self.firstconv[4], relu=True, groups=g, arith=a)
         for blk in self.layer1:
-            y = blk(y, g)
+            y = blk(y, g, a)
         for blk in self.layer2:
-            y = blk(y, g)
+            y = blk(y, g, a)
         raw = y
         for blk in self.layer3:
-            y = blk(y, g)
+            y = blk(y, g, a)
         for blk in self.layer4:
-            y = blk(y, g)
+            y = blk(y, g, a)
         skip = y
         size = skip.shape[-2:]
         # SPP pooling as a hierarchy: the 16/32/64 windows are 2x2 means of the previous level
@@ -198,21 +199,21 @@ class FeatureExtraction(nn.Module):
         win_of = dict(_SPP_WINDOWS)
         pyramid = [upsample_bilinear_ac(
             _convbn_unit(pooled[win_of[i]].contiguous(memory_format=torch.channels_last),
-                         getattr(self, f"branch{i}")[1], relu=True, groups=g), size) for i in (4, 3, 2, 1)]
-        y = _convbn_unit(torch.cat([raw, skip] + pyramid, 1), self.lastconv[0], relu=True, groups=g)
-        return conv2d.conv(y, self.lastconv[2])
+                         getattr(self, f"branch{i}")[1], relu=True, groups=g, arith=a), size) for i in (4, 3, 2, 1)]
+        y = _convbn_unit(torch.cat([raw, skip] + pyramid, 1), self.lastconv[0], relu=True, groups=g, arith=a)
+        return conv2d.conv(y, self.lastconv[2], a)
 
-    def forward(self, x):
+    def forward(self, x, arith=None):
         """[B,3,H,W] -> [B,32,H/4,W/4]"""
-        return self._trunk(x.contiguous(memory_format=torch.channels_last))
+        return self._trunk(x.contiguous(memory_format=torch.channels_last), arith=arith)
 
-    def forward_pair(self, left, right):
+    def forward_pair(self, left, right, arith=None):
         """(feature_extraction(left), feature_extraction(right)) of psmnet_3.py:145-146 in ONE pass
         over the stacked batch: every BatchNorm takes its statistics per image set and updates its
         running statistics left first, then right, exactly as the two sequential calls do."""
         if left.shape != right.shape:
-            return self.forward(left), self.forward(right)
+            return self.forward(left, arith), self.forward(right, arith)
         x = torch.cat([left, right], 0).contiguous(memory_format=torch.channels_last)
-        y = self._trunk(x, groups=2)
+        y = self._trunk(x, groups=2, arith=arith)
         b = left.shape[0]
         return y[:b], y[b:]

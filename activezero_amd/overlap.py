@@ -1,0 +1,118 @@
+"""Weight-gradient kernels on a second HIP stream, overlapped with the rest of the backward pass.
+
+The backward pass of the path alternates MFMA-bound kernels (input gradients, weight gradients) with
+HBM-bound ones (BatchNorm reductions and applies, gradient sums).  Only the chain
+    input gradient of layer L -> BatchNorm backward of layer L-1 -> input gradient of layer L-1 -> ...
+is sequentially dependent; the weight gradient of layer L has no consumer until the optimizer step.  With a
+`Sink`, every weight-gradient kernel is launched on a side stream (after that stream has waited for the
+main stream's current position, i.e. for its operands) and the main stream continues at once: matrix work
+then runs beside the streaming kernels of the following layers (measured: 133.9 -> 126.5 ms per step at
+B=4, 544x960, D=192).
+
+Autograd and DistributedDataParallel see nothing unusual, by construction of the graph rather than by
+convention:
+  * `begin()` runs at the start of a forward pass and puts ONE extra node (`_Tail`) into the graph.  Every
+    convolution weight is an input of that node, its single output (a 1-element token) is an input of the
+    first convolution of the model.  In the backward pass the first convolution's node is necessarily the
+    last convolution node to run (every other one consumes, directly or not, what it produced), so
+    `_Tail.backward` runs after every weight-gradient kernel has been launched; there the main stream waits
+    for the side stream.
+  * Each weight therefore has two incoming gradient edges -- the real gradient from its convolution node and
+    an empty one from `_Tail` -- and the engine runs its AccumulateGrad (and DDP's hook behind it) only after
+    BOTH have arrived, i.e. after the join.  No gradient tensor is read before the stream that wrote it has
+    been waited for.
+  * Operands of side-stream kernels are kept referenced by the sink until the join, so the caching allocator
+    cannot hand their memory to later main-stream work while the side stream still reads it.
+There is no module-level state: a Sink belongs to one forward/backward pass of one module replica (the side
+stream itself is cached per device).  `begin()` returns None -- plain in-order weight gradients -- whenever the
+construction above does not apply (no grad mode, a frozen convolution weight, CPU tensors).
+"""
+import threading
+
+import torch
+
+_STREAMS = {}
+_STREAMS_LOCK = threading.Lock()
+
+
+def side_stream(device):
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    with _STREAMS_LOCK:
+        s = _STREAMS.get(idx)
+        if s is None:
+            s = _STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return s
+
+
+class Sink:
+    """State of one forward/backward pass: the side stream, the token that ties `_Tail` to the first
+    convolution, and the operands kept alive until the join."""
+
+    def __init__(self, device):
+        self.stream = side_stream(device)
+        self.token = None
+        self.keep = []
+        self.armed = False   # set by the first convolution when it takes the token: without that edge in the
+        self.joined = False  # graph nothing would ever join the side stream, so nothing is sent there
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+        self.joined = True
+
+
+class _Tail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sink, *weights):
+        ctx.sink = sink
+        ctx.n = len(weights)
+        return weights[0].new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _g):
+        ctx.sink.join()
+        return (None,) * (ctx.n + 1)
+
+
+def conv_weights(module):
+    return [m.weight for m in module.modules()
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.ConvTranspose3d))]
+
+
+def begin(module, like):
+    """Start of a forward pass of `module` (all of whose convolutions run on this library's kernels and whose
+    first convolution accepts the sink's token): returns a Sink, or None when weight gradients stay in order."""
+    if not (torch.is_grad_enabled() and like.is_cuda):
+        return None
+    weights = conv_weights(module)
+    if not weights or not all(w.requires_grad and w.is_leaf for w in weights):
+        return None  # (replicas of nn.DataParallel hold non-leaf copies: their gradients flow on through autograd)
+    sink = Sink(like.device)
+    sink.token = _Tail.apply(sink, *weights)
+    return sink
+
+
+class scope:
+    """`with scope(sink, *operands):` -- kernels launched inside go to the sink's stream (nothing changes for
+    sink None).  Output buffers that the main stream reads after the join are allocated OUTSIDE the scope."""
+
+    def __init__(self, sink, *operands):
+        self.sink = sink
+        self.operands = operands
+        self.ctx = None
+
+    def __enter__(self):
+        sink = self.sink
+        if sink is not None and sink.armed and not sink.joined:
+            sink.keep.extend(t for t in self.operands if t is not None)
+            sink.stream.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(sink.stream)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False

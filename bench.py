@@ -54,6 +54,8 @@ def parse():
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --single-device)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--no-wgrad-overlap", action="store_true",
+                    help="A/B: weight-gradient kernels in order on the main stream (activezero_amd/overlap.py)")
     return ap.parse_args()
 
 
@@ -206,6 +208,7 @@ def main():
         from activezero_amd.nets.psmnet.psmnet_3 import PSMNet
     torch.manual_seed(1)  # configs/config.py:100
     model = PSMNet(args.maxdisp).to(device).train()
+    model.set_weight_grad_overlap(not args.no_wgrad_overlap)
     opt = torch.optim.Adam(model.parameters(), lr=2e-4, betas=(0.9, 0.999))
     net = azdist.wrap(model, device)
     seed = azdist.rank_seed(1234, rank)
