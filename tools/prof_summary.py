@@ -56,6 +56,17 @@ def main():
         c[0] += 1; c[1] += d; c[2] = min(c[2], d); c[3] = max(c[3], d)
     total = sum(c[1] for c in agg.values())
     wall = max(int(r["End_Timestamp"]) for r in sel) - t0
+    # kernels of the two streams run side by side (overlap.py): time with at least one / at least two in flight
+    ev = sorted([(int(r["Start_Timestamp"]), 1) for r in sel] + [(int(r["End_Timestamp"]), -1) for r in sel])
+    busy = both = depth = 0
+    last = ev[0][0]
+    for t, d in ev:
+        if depth >= 1:
+            busy += t - last
+        if depth >= 2:
+            both += t - last
+        depth += d
+        last = t
     items = sorted(agg.items(), key=lambda kv: -kv[1][1])
     with open(a.out + "_kernel_stats.csv", "w") as f:
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
@@ -65,8 +76,9 @@ def main():
         f.write(f"# rocprofv3 --kernel-trace summary, timed region only ({steps} steps)\n\n")
         if a.note:
             f.write(a.note + "\n\n")
-        f.write(f"GPU busy {total / 1e6:.1f} ms over {wall / 1e6:.1f} ms wall "
-                f"({total / 1e6 / steps:.1f} ms busy per step)\n\n")
+        f.write(f"wall {wall / 1e6:.1f} ms ({wall / 1e6 / steps:.1f} ms per step); at least one kernel in flight "
+                f"{busy / 1e6 / steps:.1f} ms per step, two or more {both / 1e6 / steps:.1f} ms per step; sum of kernel "
+                f"durations {total / 1e6 / steps:.1f} ms per step (kernels that share the chip run longer each)\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for k, (n, tot, mn, mx) in items[:45]:
             f.write(f"| `{k}` | {n} | {tot / 1e6:.2f} | {tot / n / 1e3:.1f} | {100.0 * tot / total:.1f} |\n")
