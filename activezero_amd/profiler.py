@@ -31,12 +31,13 @@ def scope(name, flops=0.0, bytes=0.0, bound="mfma", peak=None):
         return
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
+    side = torch.cuda.current_stream() != torch.cuda.default_stream()  # overlap.py: weight gradients
     a.record()
     try:
         yield
     finally:
         b.record()
-        _records.setdefault(name, []).append((a, b, float(flops), float(bytes), bound, peak))
+        _records.setdefault(name, []).append((a, b, float(flops), float(bytes), bound, peak, side))
 
 
 def stop():
@@ -49,7 +50,7 @@ def stop():
         out[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                      "flops": sum(r[2] for r in recs) / len(recs),
                      "bytes": sum(r[3] for r in recs) / len(recs), "bound": recs[0][4],
-                     "peak": recs[0][5]}
+                     "peak": recs[0][5], "side_stream": any(r[6] for r in recs)}
     _records.clear()
     return out
 
@@ -82,11 +83,30 @@ def pmc_traffic(scope_name, per_launch_work, pmc_json):
     return k["hbm_bytes"]
 
 
-def roofline(prof, pmc_json=None):
-    """roofline object for the kernel with the largest total time in the timed region."""
+def held_clock(scope_name, clock_json):
+    """Clock and MFMA-pipe occupancy of the kernel from the committed counter pass (tools/pmc_clock.sh:
+    GRBM_GUI_ACTIVE / 8 / wall, SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles)); None when absent."""
+    import json
+    import os
+
+    if not clock_json or not os.path.exists(clock_json) or scope_name not in _PMC_NAMES:
+        return None
+    data = json.load(open(clock_json))["kernels"]
+    for sym in _PMC_NAMES[scope_name]:
+        if sym in data:
+            return data[sym]
+    return None
+
+
+def roofline(prof, pmc_json=None, clock_json=None):
+    """roofline object for the kernel with the largest total time in the timed region among the kernels of
+    the main stream.  (The weight-gradient kernels run on the side stream BESIDE main-stream kernels,
+    overlap.py: their event-to-event durations are those of a kernel sharing the chip, not single-kernel
+    rates; they are listed under `others` with "side_stream": true.)"""
     if not prof:
         return None
-    name, r = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    name, r = max(((k, v) for k, v in prof.items() if not v.get("side_stream")),
+                  key=lambda kv: kv[1]["total_ms"], default=max(prof.items(), key=lambda kv: kv[1]["total_ms"]))
     peak, unit = PEAK[r["bound"]]
     peak_basis = "fp32 MFMA dense" if r["bound"] == "mfma" else "HBM3E spec"
     if r.get("peak"):
@@ -97,8 +117,11 @@ def roofline(prof, pmc_json=None):
             "peak_basis": peak_basis, "unit": unit,
             "frac": achieved / peak,
             "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
+            "selection": "largest total time among main-stream kernels",
+            "held_clock": held_clock(name, clock_json),
             "avg_launch_ms": r["avg_ms"],
             "launches_timed": r["launches"],
             "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
-            "others": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]}
+            "others": {k: dict({"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]},
+                               **({"side_stream": True} if v.get("side_stream") else {}))
                        for k, v in prof.items() if k != name}}

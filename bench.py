@@ -300,7 +300,8 @@ def main():
                                      "everywhere; every convolution on this library's kernels"},
             "loss": float(loss.item()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
-            "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "pmc_traffic_b4.json")),
+            "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "pmc_traffic_b4.json"),
+                                          os.path.join(REPO, "profiles", "pmc_clock_b4.json")),
             "cpu_baseline": None,
             "eager_gpu": None,
         }
