@@ -40,7 +40,7 @@ _SIGS = {
     "az_bn3d_stats_tiles": [_LL, _INT],
     "az_bn3d_stats": [_PTR] * 3 + [_LL, _INT, _PTR],
     "az_bn2d_workspace": [_INT, _LL, _INT],
-    "az_bn2d_fwd": [_PTR] * 12 + [_LL, _INT, _INT, _LL, _INT, _C.c_float, _C.c_float, _PTR],
+    "az_bn2d_fwd": [_PTR] * 12 + [_LL, _INT, _INT, _LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR],
     "az_bn2d_bwd": [_PTR] * 5 + [_LL] + [_PTR] * 8 + [_INT, _INT, _LL, _INT, _PTR],
     "az_disp_loss_fwd": [_PTR] * 6 + [_C.c_float, _C.c_float, _C.c_longlong, _PTR],
     "az_disp_loss_bwd": [_PTR] * 8 + [_C.c_float, _C.c_float, _PTR, _PTR] + [_C.c_float] * 3 + [_C.c_longlong, _PTR],
@@ -55,7 +55,7 @@ _SIGS = {
     "az_conv3d_c1_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_dgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_wgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
-    "az_bn3d_finalize": [_PTR] * 10 + [_LL, _INT, _C.c_float, _C.c_float, _PTR],
+    "az_bn3d_finalize": [_PTR] * 10 + [_LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR],
     "az_bn3d_eval_affine": [_PTR] * 6 + [_C.c_float, _INT, _PTR],
     "az_bn3d_apply": [_PTR] * 5 + [_INT, _LL, _INT, _PTR],
     "az_bn3d_bwd_workspace": [_LL, _INT],

@@ -55,12 +55,14 @@ class _BNAct(torch.autograd.Function):
             ws = xr.new_empty(ws_bytes // 4)
             stats = xr.new_empty(4, groups, c)  # mean, invstd, scale, shift per group
             track = bn.track_running_stats and bn.running_mean is not None
+            nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
             _call("az_bn2d_fwd", _p(yr), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
                   _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None, _p(xr), _p(rr),
                   _p(g_), _p(b_), _p(ws), ws_bytes, int(relu), groups, nvox, c, eps,
-                  float(bn.momentum) if bn.momentum is not None else 0.1, _stream())
-            if track and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(groups)
+                  float(bn.momentum) if bn.momentum is not None else 0.1, _p(nbt), _stream())
+            if nbt is not None:
+                from .conv3d import _touched
+                _touched(nbt, bn.running_mean, bn.running_var)
         # a ReLU layer without residual recomputes its mask from x in backward: y need not be kept
         ctx.save_for_backward(xr, yr if (relu and residual is not None) else None, gamma, stats)
         ctx.cfg = (True, relu, residual is not None, groups, (n, c, h, w))

@@ -59,6 +59,14 @@ def _arith(a):
     return a
 
 
+def _touched(*tensors):
+    """Bump the version counters of buffers a kernel has just written through their raw pointers (BatchNorm
+    running statistics and call counter): the memoised inference operands are keyed on them."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def _dims(x):
     b, d, h, w, c = x.shape
     return b, d, h, w, c
@@ -263,12 +271,13 @@ class _ConvBN(torch.autograd.Function):
             mean, invstd = x.new_empty(cout), x.new_empty(cout)
             track = bn.track_running_stats and bn.running_mean is not None
             momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+            nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
             _call("az_bn3d_finalize", _p(mean), _p(invstd), _p(scale), _p(shift),
                   _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
                   _p(part), _p(cnt), _p(gamma.detach()), _p(beta.detach()), ntiles, cout, eps,
-                  momentum, _stream())
-            if track and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+                  momentum, _p(nbt), _stream())
+            if nbt is not None:  # the kernel wrote through raw pointers: tell the version counters (cache keys)
+                _touched(nbt, bn.running_mean, bn.running_var)
             y = torch.empty_like(raw)
             nvox = raw.numel() // cout
             with profiler.scope(f"bn3d_apply_{cout}", bytes=4.0 * raw.numel() * (3 if residual is not None else 2),

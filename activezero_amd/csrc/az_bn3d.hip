@@ -25,8 +25,12 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
                    float *__restrict__ running_mean, float *__restrict__ running_var,
                    const float *__restrict__ part, const float *__restrict__ cnt,
                    const float *__restrict__ gamma, const float *__restrict__ beta,
-                   long long ntiles, int C, float eps, float momentum, int groups) {
+                   long long ntiles, int C, float eps, float momentum, int groups,
+                   long long *__restrict__ num_batches_tracked) {
     const int c = blockIdx.x;
+    // BatchNorm's call counter (nn.BatchNorm*.num_batches_tracked, one count per statistic group): bumped here
+    // instead of by a separate elementwise launch per layer (85 per step)
+    if (num_batches_tracked != nullptr && c == 0 && threadIdx.x == 0) *num_batches_tracked += groups;
     // statistic groups (bn2d: the left and the right image set) are finalised one after the other
     // by the same block, so the running statistics see them in order, as two module calls would
     for (int grp = 0; grp < groups; ++grp, part += (long long)C * ntiles * 2, cnt += ntiles,
@@ -398,14 +402,14 @@ extern "C" int az_bn3d_finalize(float *mean, float *invstd, float *scale, float 
                                 float *running_mean, float *running_var, const float *partials,
                                 const float *counts, const float *gamma, const float *beta,
                                 long long ntiles, int C, float eps, float momentum,
-                                void *stream) {
+                                long long *num_batches_tracked, void *stream) {
     AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
     AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta);
     AZ_REQUIRE(ntiles > 0 && C > 0);
     if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_FIN_THREADS), 0, az_stream(stream), mean, invstd,
                        scale, shift, running_mean, running_var, partials, counts, gamma, beta,
-                       ntiles, C, eps, momentum, 1);
+                       ntiles, C, eps, momentum, 1, num_batches_tracked);
     return az_launch_status();
 }
 
@@ -531,12 +535,12 @@ template <int C>
 static void bn2d_fwd_launch(float *y, float *mean, float *invstd, float *scale, float *shift, float *rm,
                             float *rv, const float *x, const float *res, const float *gamma,
                             const float *beta, float *ws, int relu, int groups, long long nvox, float eps,
-                            float momentum, hipStream_t s) {
+                            float momentum, long long *nbt, hipStream_t s) {
     const long long tiles = az_bn3d_stats_tiles(nvox, C);
     float *part = ws, *cnt = ws + (size_t)groups * C * tiles * 2;
     hipLaunchKernelGGL(bn_stats_kernel<C>, dim3((unsigned)tiles, groups), dim3(256), 0, s, part, cnt, x, nvox, tiles);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_FIN_THREADS), 0, s, mean, invstd, scale, shift, rm, rv,
-                       part, cnt, gamma, beta, tiles, C, eps, momentum, groups);
+                       part, cnt, gamma, beta, tiles, C, eps, momentum, groups, nbt);
     const long long total4 = nvox * C / 4;
     hipLaunchKernelGGL((bn_apply_kernel<C, false>), dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)y,
                        (const float4 *)x, scale, shift, (const float4 *)res, relu, total4);
@@ -547,7 +551,7 @@ extern "C" int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, f
                            float *running_mean, float *running_var, const float *x, const float *residual,
                            const float *gamma, const float *beta, float *workspace, long long workspace_bytes,
                            int relu, int groups, long long nvox, int C, float eps, float momentum,
-                           void *stream) {
+                           long long *num_batches_tracked, void *stream) {
     AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
     AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta); AZ_REQUIRE_PTR(workspace);
     if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
@@ -556,9 +560,9 @@ extern "C" int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, f
     if (workspace_bytes < need) return AZ_EWORKSPACE;
     if (groups > 65535) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
-    if (C == 32) bn2d_fwd_launch<32>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, s);
-    else if (C == 64) bn2d_fwd_launch<64>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, s);
-    else bn2d_fwd_launch<128>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, s);
+    if (C == 32) bn2d_fwd_launch<32>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, s);
+    else if (C == 64) bn2d_fwd_launch<64>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, s);
+    else bn2d_fwd_launch<128>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, s);
     return az_launch_status();
 }
 

@@ -176,11 +176,12 @@ int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *grad_logits,
 /* ---- BatchNorm3d pieces around K4/K5 (psmnet_submodule_3.py:55) --------------------
  * finalize: merge the conv partials (Chan, fp64) -> mean, invstd, scale = gamma*invstd,
  * shift = beta - mean*scale; running stats updated in place (momentum, unbiased var)
- * unless running_mean/var are NULL. */
+ * unless running_mean/var are NULL; *num_batches_tracked (int64, may be NULL) += 1. */
 int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
                      float *running_mean, float *running_var, const float *partials,
                      const float *counts, const float *gamma, const float *beta,
-                     long long ntiles, int C, float eps, float momentum, void *stream);
+                     long long ntiles, int C, float eps, float momentum,
+                     long long *num_batches_tracked, void *stream);
 /* batch statistics of a channels-last tensor x[nvox][C] (C = 32, 64, 128) whose producer is not one
  * of these convolutions (the 2-D extractor's layers, nets/psmnet/psmnet_submodule_3.py:8-22):
  * partials [C][tiles][2], counts [tiles] with tiles = az_bn3d_stats_tiles(nvox, C), for az_bn3d_finalize */
@@ -194,7 +195,8 @@ long long az_bn2d_workspace(int groups, long long nvox, int C);
 int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, float *shift, float *running_mean,
                 float *running_var, const float *x, const float *residual, const float *gamma,
                 const float *beta, float *workspace, long long workspace_bytes, int relu, int groups,
-                long long nvox, int C, float eps, float momentum, void *stream);
+                long long nvox, int C, float eps, float momentum, long long *num_batches_tracked /* += groups; may be NULL */,
+                void *stream);
 /* backward: dx [groups][nvox][C]; dgamma/dbeta [C] summed over the groups; dz_out (may be NULL) = the
  * gradient of the residual branch when relu != 0 */
 int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *workspace,
