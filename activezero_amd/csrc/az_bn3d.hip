@@ -16,6 +16,27 @@
 //   az_bn3d_bwd_apply: dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); optional dz out.
 #include "az_common.h"
 
+// Block-wide fp64 sum in two barriers: DPP/shuffle inside each wave, one LDS slot per wave, then every thread
+// adds the (at most 16) wave sums.  The finalize kernels below are latency bound -- one block per channel, a
+// few thousand partials -- and the 10-step LDS tree they used cost 10 barriers per reduction (18 us per launch,
+// 170 launches per step).
+__device__ __forceinline__ double bn_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int NT>
+__device__ __forceinline__ double bn_block_sum(double v, double *slots /* [NT/64] */) {
+    v = bn_wave_sum(v);
+    __syncthreads();  // the slots may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += slots[w];
+    return t;
+}
+
 // one block per channel; 1024 threads: the V0 layers merge 97 920 tile partials per channel and a
 // 256-thread block took 130 us per layer (25 layers per step) on two dependent fp64 passes
 #define BN_FIN_THREADS 1024
@@ -35,26 +56,17 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
     // by the same block, so the running statistics see them in order, as two module calls would
     for (int grp = 0; grp < groups; ++grp, part += (long long)C * ntiles * 2, cnt += ntiles,
              mean_out += C, invstd_out += C, scale += C, shift += C) {
-    __syncthreads();
     // pass 1: N = sum n_t, S = sum s_t  ->  mean
     // pass 2: M2 = sum [ M2_t + n_t (s_t/n_t - mean)^2 ]   (Chan's merge with the final mean)
-    __shared__ double sn[BN_FIN_THREADS], sm[BN_FIN_THREADS], s2[BN_FIN_THREADS];
+    __shared__ double slots[BN_FIN_THREADS / 64];
     const float2 *pc = reinterpret_cast<const float2 *>(part) + (long long)c * ntiles;
     double n = 0.0, sum = 0.0;
     for (long long t = threadIdx.x; t < ntiles; t += BN_FIN_THREADS) {
         n += (double)cnt[t];
         sum += (double)pc[t].x;
     }
-    sn[threadIdx.x] = n; sm[threadIdx.x] = sum;
-    __syncthreads();
-    for (int o = BN_FIN_THREADS / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            sn[threadIdx.x] += sn[threadIdx.x + o];
-            sm[threadIdx.x] += sm[threadIdx.x + o];
-        }
-        __syncthreads();
-    }
-    const double Ntot = sn[0], mean_all = sm[0] / sn[0];
+    const double Ntot = bn_block_sum<BN_FIN_THREADS>(n, slots);
+    const double mean_all = bn_block_sum<BN_FIN_THREADS>(sum, slots) / Ntot;
     double m2 = 0.0;
     for (long long t = threadIdx.x; t < ntiles; t += BN_FIN_THREADS) {
         const float nt = cnt[t];
@@ -63,17 +75,9 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
         const double dlt = (double)pr.x / (double)nt - mean_all;
         m2 += (double)pr.y + (double)nt * dlt * dlt;
     }
-    __syncthreads();
-    s2[threadIdx.x] = m2;
-    __syncthreads();
-    for (int o = BN_FIN_THREADS / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) s2[threadIdx.x] += s2[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { sn[0] = Ntot; sm[0] = mean_all; }
-    __syncthreads();
+    const double M2 = bn_block_sum<BN_FIN_THREADS>(m2, slots);
     if (threadIdx.x == 0) {
-        const double N = sn[0], mu = sm[0], var = s2[0] / N;
+        const double N = Ntot, mu = mean_all, var = M2 / N;
         const double istd = 1.0 / sqrt(var + (double)eps);
         mean_out[c] = (float)mu;
         invstd_out[c] = (float)istd;
@@ -81,7 +85,7 @@ bn_finalize_kernel(float *__restrict__ mean_out, float *__restrict__ invstd_out,
         scale[c] = sc;
         shift[c] = beta[c] - (float)mu * sc;
         if (running_mean) {
-            const double unbiased = N > 1.0 ? s2[0] / (N - 1.0) : var;
+            const double unbiased = N > 1.0 ? M2 / (N - 1.0) : var;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
@@ -224,7 +228,7 @@ bn_bwd_finalize_kernel(float *__restrict__ dgamma, float *__restrict__ dbeta,
                        const float *__restrict__ gamma, const float *__restrict__ invstd,
                        int nblocks, int C, double nvox, int groups) {
     const int c = blockIdx.x;
-    __shared__ double sa[256], sb[256];
+    __shared__ double slots[256 / 64];
     double dg_tot = 0.0, db_tot = 0.0;  // parameter gradients: summed over the statistic groups
     for (int grp = 0; grp < groups; ++grp, partial += (size_t)nblocks * C * 2, invstd += C, coef += C * 3) {
         double a = 0.0, b = 0.0;
@@ -232,23 +236,14 @@ bn_bwd_finalize_kernel(float *__restrict__ dgamma, float *__restrict__ dbeta,
             a += partial[((size_t)t * C + c) * 2 + 0];
             b += partial[((size_t)t * C + c) * 2 + 1];
         }
-        __syncthreads();
-        sa[threadIdx.x] = a; sb[threadIdx.x] = b;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) {
-                sa[threadIdx.x] += sa[threadIdx.x + o];
-                sb[threadIdx.x] += sb[threadIdx.x + o];
-            }
-            __syncthreads();
-        }
+        const double sa = bn_block_sum<256>(a, slots), sb = bn_block_sum<256>(b, slots);
         if (threadIdx.x == 0) {
-            db_tot += sa[0];
-            dg_tot += sb[0];
+            db_tot += sa;
+            dg_tot += sb;
             // dx = k0 * (dz - k1 - xhat * k2)
             coef[c * 3 + 0] = gamma[c] * invstd[c];
-            coef[c * 3 + 1] = (float)(sa[0] / nvox);
-            coef[c * 3 + 2] = (float)(sb[0] / nvox);
+            coef[c * 3 + 1] = (float)(sa / nvox);
+            coef[c * 3 + 2] = (float)(sb / nvox);
         }
     }
     if (threadIdx.x == 0) {
