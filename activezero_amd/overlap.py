@@ -31,6 +31,8 @@ import threading
 
 import torch
 
+from . import profiler
+
 _STREAMS = {}
 _STREAMS_LOCK = threading.Lock()
 
@@ -61,6 +63,7 @@ class Sink:
         torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
         self.joined = True
+        profiler.joined()
 
 
 class _Tail(torch.autograd.Function):
@@ -110,9 +113,11 @@ class scope:
             sink.stream.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(sink.stream)
             self.ctx.__enter__()
+            profiler.side(+1)
         return self
 
     def __exit__(self, *exc):
         if self.ctx is not None:
+            profiler.side(-1)
             self.ctx.__exit__(*exc)
         return False

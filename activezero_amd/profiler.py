@@ -16,6 +16,19 @@ PEAK = {"mfma": (157.3, "TFLOP/s"),  # dense fp32 MFMA (MI355X_MICROARCH.md, chi
 
 _active = False
 _records = {}
+_side_depth = 0  # measurement tooling only (bench.py, one thread)
+_side_pending = False  # side-stream work launched and not yet joined: main-stream kernels share the chip
+
+
+def side(delta):
+    global _side_depth, _side_pending
+    _side_depth += delta
+    _side_pending = True
+
+
+def joined():
+    global _side_pending
+    _side_pending = False
 
 
 def start():
@@ -31,13 +44,14 @@ def scope(name, flops=0.0, bytes=0.0, bound="mfma", peak=None):
         return
     a = torch.cuda.Event(enable_timing=True)
     b = torch.cuda.Event(enable_timing=True)
-    side = torch.cuda.current_stream() != torch.cuda.default_stream()  # overlap.py: weight gradients
+    side = _side_depth > 0  # inside overlap.scope: a weight-gradient kernel on the side stream
+    beside = _side_pending and not side  # a main-stream kernel while side-stream kernels are in flight
     a.record()
     try:
         yield
     finally:
         b.record()
-        _records.setdefault(name, []).append((a, b, float(flops), float(bytes), bound, peak, side))
+        _records.setdefault(name, []).append((a, b, float(flops), float(bytes), bound, peak, side, beside))
 
 
 def stop():
@@ -50,7 +64,8 @@ def stop():
         out[name] = {"launches": len(recs), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms),
                      "flops": sum(r[2] for r in recs) / len(recs),
                      "bytes": sum(r[3] for r in recs) / len(recs), "bound": recs[0][4],
-                     "peak": recs[0][5], "side_stream": any(r[6] for r in recs)}
+                     "peak": recs[0][5], "side_stream": any(r[6] for r in recs),
+                     "beside_side_stream": any(r[7] for r in recs)}
     _records.clear()
     return out
 
@@ -99,14 +114,15 @@ def held_clock(scope_name, clock_json):
 
 
 def roofline(prof, pmc_json=None, clock_json=None):
-    """roofline object for the kernel with the largest total time in the timed region among the kernels of
-    the main stream.  (The weight-gradient kernels run on the side stream BESIDE main-stream kernels,
-    overlap.py: their event-to-event durations are those of a kernel sharing the chip, not single-kernel
-    rates; they are listed under `others` with "side_stream": true.)"""
+    """roofline object for the kernel with the largest total time in the timed region among the kernels that
+    have the chip to themselves.  (In the backward pass the weight-gradient kernels run on the side stream
+    BESIDE the main stream's kernels, overlap.py: event-to-event durations there are those of kernels sharing
+    the chip -- a BatchNorm reduction waiting for wave slots reads 10x its solo time -- not single-kernel rates;
+    those entries are listed under `others` with "side_stream" / "beside_side_stream": true.)"""
     if not prof:
         return None
-    name, r = max(((k, v) for k, v in prof.items() if not v.get("side_stream")),
-                  key=lambda kv: kv[1]["total_ms"], default=max(prof.items(), key=lambda kv: kv[1]["total_ms"]))
+    alone = [(k, v) for k, v in prof.items() if not (v.get("side_stream") or v.get("beside_side_stream"))]
+    name, r = max(alone or list(prof.items()), key=lambda kv: kv[1]["total_ms"])
     peak, unit = PEAK[r["bound"]]
     peak_basis = "fp32 MFMA dense" if r["bound"] == "mfma" else "HBM3E spec"
     if r.get("peak"):
@@ -117,11 +133,12 @@ def roofline(prof, pmc_json=None, clock_json=None):
             "peak_basis": peak_basis, "unit": unit,
             "frac": achieved / peak,
             "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
-            "selection": "largest total time among main-stream kernels",
+            "selection": "largest total time among the kernels that run alone (not beside the side stream)",
             "held_clock": held_clock(name, clock_json),
             "avg_launch_ms": r["avg_ms"],
             "launches_timed": r["launches"],
             "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
             "others": {k: dict({"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]},
-                               **({"side_stream": True} if v.get("side_stream") else {}))
+                               **({"side_stream": True} if v.get("side_stream") else {}),
+                               **({"beside_side_stream": True} if v.get("beside_side_stream") else {}))
                        for k, v in prof.items() if k != name}}
