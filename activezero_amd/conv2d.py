@@ -88,9 +88,15 @@ def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=Non
 
 
 def _leaf_sink(sink, weight):
-    """A sink defers a weight gradient past the point where autograd hands it on; that is only sound when the
-    next reader is the parameter's AccumulateGrad (overlap.py), i.e. when the weight is a leaf."""
-    return sink if (sink is not None and weight.is_leaf) else None
+    """A sink lets a weight gradient be handed to autograd before its kernel has run; that is only sound when
+    the next reader is the pass's own gate node (overlap.py), i.e. when `weight` is one of the sink's gated
+    parameters -- not for derived tensors such as the merged kernels of the cost-volume convolution."""
+    return sink if (sink is not None and sink.owns(weight)) else None
+
+
+def _w(m, arith):
+    """the weight tensor a layer uses in this pass: the sink's gated alias, or the parameter itself"""
+    return arith.sink.weight(m.weight) if arith.sink is not None else m.weight
 
 
 class _ConvSame(torch.autograd.Function):
@@ -255,17 +261,17 @@ def conv(x, m, arith=None, skip=False):
     k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
     cin, cout = m.in_channels, m.out_channels
     if is_same(m):
-        return (conv_same_skip if skip else conv_same)(x, m.weight, d[0], arith.sink)
+        return (conv_same_skip if skip else conv_same)(x, _w(m, arith), d[0], arith.sink)
     if skip:
         raise RuntimeError(f"conv2d.conv: skip output needs a stride-1 layer, got {m}")
     if s == (2, 2) and k == (3, 3) and p == (1, 1) and d == (1, 1):
         if cin in (32, 64) and cout in (32, 64) and x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
-            return _ConvS2Vol.apply(x, m.weight, arith)
+            return _ConvS2Vol.apply(x, _w(m, arith), arith)
         if 9 * cin <= 64 and cout % 32 == 0:
             sink = arith.sink
-            return _ConvS2Patches.apply(x, m.weight, sink, sink.token if sink is not None else None)
+            return _ConvS2Patches.apply(x, _w(m, arith), sink, sink.token if sink is not None else None)
     if s == (2, 2) and k == (1, 1) and p == (0, 0):
-        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), m.weight, 1, arith.sink)
+        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), _w(m, arith), 1, arith.sink)
     raise RuntimeError(f"conv2d.conv: unsupported layer {m}")
 
 

@@ -288,7 +288,7 @@ class _ConvBN(torch.autograd.Function):
         remask = relu and residual is None
         ctx.save_for_backward(x, weight, gamma, raw, y if (relu and not remask) else None, mean, invstd,
                               scale if remask else None, shift if remask else None)
-        if arith.sink is not None and not weight.is_leaf:  # see conv2d._leaf_sink
+        if arith.sink is not None and not arith.sink.owns(weight):  # see conv2d._leaf_sink
             arith = arith._replace(sink=None)
         ctx.cfg = (mode, relu, residual is not None, cin, cout, arith, True)
         return y
@@ -350,7 +350,8 @@ def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None):
             scale, shift = eval_affine(bn, x, cache=True)
             return _run_gather(x, packed, mode, cin, cout, arith.conv, scale, shift,
                                _chk(residual, "residual") if residual is not None else None, relu)
-    return _ConvBN.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, mode, relu, arith)
+    w = arith.sink.weight(conv.weight) if arith.sink is not None else conv.weight
+    return _ConvBN.apply(x, w, bn.weight, bn.bias, residual, bn, mode, relu, arith)
 
 
 class _ConvLogits(torch.autograd.Function):
@@ -358,7 +359,7 @@ class _ConvLogits(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, addend, sink):
-        ctx.sink = sink if (sink is not None and weight.is_leaf) else None
+        ctx.sink = sink if (sink is not None and sink.owns(weight)) else None
         x = _chk(x, "x")
         w = _chk(weight.detach().contiguous(), "weight")
         b, d, h, wd, c = _dims(x)
@@ -394,7 +395,7 @@ class _ConvLogits(torch.autograd.Function):
 
 
 def conv_logits(x, conv, addend=None, sink=None):
-    return _ConvLogits.apply(x, conv.weight, addend, sink)
+    return _ConvLogits.apply(x, sink.weight(conv.weight) if sink is not None else conv.weight, addend, sink)
 
 
 class _AddRelu(torch.autograd.Function):

@@ -11,16 +11,18 @@ B=4, 544x960, D=192).
 
 Autograd and DistributedDataParallel see nothing unusual, by construction of the graph rather than by
 convention:
-  * `begin()` runs at the start of a forward pass and puts ONE extra node (`_Tail`) into the graph.  Every
-    convolution weight is an input of that node, its single output (a 1-element token) is an input of the
-    first convolution of the model.  In the backward pass the first convolution's node is necessarily the
-    last convolution node to run (every other one consumes, directly or not, what it produced), so
-    `_Tail.backward` runs after every weight-gradient kernel has been launched; there the main stream waits
-    for the side stream.
-  * Each weight therefore has two incoming gradient edges -- the real gradient from its convolution node and
-    an empty one from `_Tail` -- and the engine runs its AccumulateGrad (and DDP's hook behind it) only after
-    BOTH have arrived, i.e. after the join.  No gradient tensor is read before the stream that wrote it has
-    been waited for.
+  * `begin()` runs at the start of a forward pass.  It wraps every convolution weight w in a `_Gate` node (an
+    identity whose output g(w) the layers use in place of w) and puts ONE `_Tail` node into the graph: all gated
+    weights are its inputs, its single output (a 1-element token) is an input of the first convolution of the
+    model.  In the backward pass the first convolution's node is necessarily the last convolution node to run
+    (every other one consumes, directly or not, what it produced), so `_Tail.backward` runs after every
+    weight-gradient kernel has been launched; there the main stream waits for the side stream.
+  * Each `_Gate` therefore has two incoming gradient edges -- the real gradient from its layer's node and an empty
+    one from `_Tail` -- and the engine runs `_Gate.backward` only after BOTH have arrived, i.e. after the join.
+    Only then does the gradient travel on to the weight's AccumulateGrad (and DDP's hook behind it).  Between the
+    layer's node and the gate nothing reads the tensor: the gate's input buffer holds a single defined gradient,
+    so the engine has nothing to add up early -- also when several forward passes of the same module are
+    back-propagated together (each pass has its own gates, tail and join).
   * Operands of side-stream kernels are kept referenced by the sink until the join, so the caching allocator
     cannot hand their memory to later main-stream work while the side stream still reads it.
 There is no module-level state: a Sink belongs to one forward/backward pass of one module replica (the side
@@ -55,15 +57,39 @@ class Sink:
     def __init__(self, device):
         self.stream = side_stream(device)
         self.token = None
+        self.gated = {}      # id(weight) -> (weight, gated alias) of this pass
+        self.owned = set()   # id(gated alias)
         self.keep = []
         self.armed = False   # set by the first convolution when it takes the token: without that edge in the
         self.joined = False  # graph nothing would ever join the side stream, so nothing is sent there
+
+    def weight(self, w):
+        """The tensor a layer of this pass must use for parameter w."""
+        hit = self.gated.get(id(w))
+        return hit[1] if hit is not None else w
+
+    def owns(self, t):
+        """True when t is one of this pass's gated weights: only their gradients may be produced late."""
+        return id(t) in self.owned
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
         self.joined = True
         profiler.joined()
+
+
+class _Gate(torch.autograd.Function):
+    """identity on a weight; its backward is held back by the edge to _Tail (module docstring)"""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.set_materialize_grads(False)
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 class _Tail(torch.autograd.Function):
@@ -93,7 +119,11 @@ def begin(module, like):
     if not weights or not all(w.requires_grad and w.is_leaf for w in weights):
         return None  # (replicas of nn.DataParallel hold non-leaf copies: their gradients flow on through autograd)
     sink = Sink(like.device)
-    sink.token = _Tail.apply(sink, *weights)
+    for w in weights:
+        gw = _Gate.apply(w)
+        sink.gated[id(w)] = (w, gw)
+        sink.owned.add(id(gw))
+    sink.token = _Tail.apply(sink, *(g for _, g in sink.gated.values()))
     return sink
 
 

@@ -66,6 +66,28 @@ def test_side_stream_weight_gradients_equal_the_in_order_pass(mod, nin):
     assert overlap.side_stream(DEV).query()
 
 
+def test_two_forward_passes_one_backward():
+    """Gradient accumulation across two forward passes back-propagated together: every weight has two real
+    gradients, each held at its own pass's gate until that pass's join (overlap.py)."""
+    md = 32
+    base = load_procedural(psm3.PSMNet(md), "g4.").to(DEV).train()
+    ims = [seeded((1, 3, 256, 256), 800 + i, -2.0, 2.0).to(DEV) for i in range(4)]
+    gts = [1.0 + 28.0 * seeded((1, 1, 256, 256), 90 + i, 0.0, 1.0).to(DEV) for i in range(2)]
+
+    def grads(model):
+        l1 = po.psmnet_disp_loss(model(ims[0], ims[1]), gts[0], po.disparity_mask(gts[0], md))
+        l2 = po.psmnet_disp_loss(model(ims[2], ims[3]), gts[1], po.disparity_mask(gts[1], md))
+        (l1 + l2).backward()
+        return {k: p.grad.detach().double().cpu().numpy() for k, p in model.named_parameters()}
+
+    ga = grads(copy.deepcopy(base))
+    gb = grads(copy.deepcopy(base).set_weight_grad_overlap(False))
+    for k in gb:
+        assert np.isfinite(ga[k]).all(), k
+        # (the second pass sees the running statistics the first one left: identical in both modes)
+        assert np.linalg.norm(ga[k] - gb[k]) <= 2e-4 * np.linalg.norm(gb[k]) + 1e-9, k
+
+
 def test_sink_is_armed_joined_and_released(monkeypatch):
     seen = []
     real = overlap.begin

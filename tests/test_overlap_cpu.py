@@ -1,7 +1,8 @@
-"""The graph construction behind activezero_amd/overlap.py, on CPU tensors: a parameter that is an input of
-`_Tail` AND of its own layer receives its gradient (AccumulateGrad, and any hook behind it such as DDP's) only
-after `_Tail.backward` has run -- i.e. after the point where the main stream has waited for the side stream --
-no matter in which order the layers' own backward nodes hand their weight gradients over."""
+"""The graph construction behind activezero_amd/overlap.py, on CPU tensors: a parameter whose layer uses its
+gated alias (`_Gate`, itself an input of `_Tail`) receives its gradient (AccumulateGrad, and any hook behind it
+such as DDP's) only after `_Tail.backward` has run -- i.e. after the point where the main stream has waited for
+the side stream -- no matter in which order the layers' own backward nodes hand their weight gradients over, and
+also when two forward passes are back-propagated together."""
 import torch
 
 from activezero_amd import overlap
@@ -25,13 +26,39 @@ class _Layer(torch.autograd.Function):
 
 
 class _Sink(overlap.Sink):
-    def __init__(self, log):
-        self.stream, self.token, self.keep, self.armed, self.joined, self.log = None, None, [object()], True, False, log
+    def __init__(self, log, tag=0):
+        self.stream, self.token, self.keep, self.armed, self.joined = None, None, [object()], True, False
+        self.gated, self.owned, self.log, self.tag = {}, set(), log, tag
 
     def join(self):
-        self.log.append(("join",))
+        self.log.append(("join", self.tag))
         self.keep.clear()
         self.joined = True
+
+
+def _begin(ws, log, tag=0):
+    """overlap.begin() with the stub sink (no GPU here)"""
+    sink = _Sink(log, tag)
+    for w in ws:
+        g = overlap._Gate.apply(w)
+        sink.gated[id(w)] = (w, g)
+        sink.owned.add(id(g))
+    sink.token = overlap._Tail.apply(sink, *(g for _, g in sink.gated.values()))
+    return sink
+
+
+def _net(x, ws, sink, log, tag=0):
+    g = sink.weight
+    assert all(sink.owns(g(w)) and not sink.owns(w) for w in ws)
+    h = _Layer.apply(x, g(ws[0]), sink.token, log, (tag, 0))  # the first layer takes the token
+    a = _Layer.apply(h, g(ws[1]), None, log, (tag, 1))          # two branches that rejoin, as the residual blocks do
+    b = _Layer.apply(h, g(ws[2]), None, log, (tag, 2))
+    return _Layer.apply(a + b, g(ws[3]), None, log, (tag, 3))
+
+
+def _plain(x, ws):
+    h = x * ws[0]
+    return ((h * ws[1]) + (h * ws[2])) * ws[3]
 
 
 def test_every_weight_gradient_is_accumulated_after_the_join():
@@ -39,26 +66,49 @@ def test_every_weight_gradient_is_accumulated_after_the_join():
     ws = [torch.nn.Parameter(torch.tensor([float(i + 2)])) for i in range(4)]
     for i, w in enumerate(ws):
         w.register_post_accumulate_grad_hook(lambda p, i=i: log.append(("accumulate", i)))
-    sink = _Sink(log)
-    sink.token = overlap._Tail.apply(sink, *ws)
+    sink = _begin(ws, log)
     assert sink.token.requires_grad and sink.token.shape == (1,)
     x = torch.ones(1)
-    h = _Layer.apply(x, ws[0], sink.token, log, 0)  # the first layer takes the token
-    a = _Layer.apply(h, ws[1], None, log, 1)          # two branches that rejoin, as the residual blocks do
-    b = _Layer.apply(h, ws[2], None, log, 2)
-    out = _Layer.apply(a + b, ws[3], None, log, 3)
-    out.sum().backward()
-    join_at = log.index(("join",))
+    _net(x, ws, sink, log).sum().backward()
+    join_at = log.index(("join", 0))
     layers = [i for i, e in enumerate(log) if e[0] == "layer"]
     accs = [i for i, e in enumerate(log) if e[0] == "accumulate"]
     assert len(layers) == 4 and len(accs) == 4
     assert max(layers) < join_at < min(accs), log           # all launches, then the join, then every accumulation
-    assert log[max(layers)] == ("layer", 0)                  # the token's consumer is the last layer node to run
+    assert log[max(layers)] == ("layer", (0, 0))             # the token's consumer is the last layer node to run
     assert sink.joined and not sink.keep                     # operands released at the join
-    # values: the same graph in plain autograd
     ref = [torch.nn.Parameter(w.detach().clone()) for w in ws]
-    h = x * ref[0]
-    (((h * ref[1]) + (h * ref[2])) * ref[3]).sum().backward()
+    _plain(x, ref).sum().backward()
+    for w, r in zip(ws, ref):
+        assert torch.equal(w.grad, r.grad)
+
+
+def test_two_passes_backpropagated_together_each_wait_for_their_own_join():
+    """Gradient accumulation over two forward passes with ONE backward: a weight then has two real gradients.
+    Each passes its own gate after its own join, so the engine's early `grad1 + grad2` in the weight's input
+    buffer only ever sees joined tensors."""
+    log = []
+    ws = [torch.nn.Parameter(torch.tensor([float(i + 2)])) for i in range(4)]
+    gate_log = []
+    real_gate_bwd = overlap._Gate.backward
+    x1, x2 = torch.ones(1), torch.full((1,), 3.0)
+    s1 = _begin(ws, log, 1)
+    y1 = _net(x1, ws, s1, log, 1)
+    s2 = _begin(ws, log, 2)
+    y2 = _net(x2, ws, s2, log, 2)
+    try:
+        overlap._Gate.backward = staticmethod(lambda ctx, g: (gate_log.append(tuple(e for e in log if e[0] == "join")), g)[1])
+        (y1.sum() + y2.sum()).backward()
+    finally:
+        overlap._Gate.backward = real_gate_bwd
+    assert ("join", 1) in log and ("join", 2) in log and s1.joined and s2.joined
+    # every gate ran after at least its own pass's join; 8 gates (4 weights x 2 passes) ran in all
+    assert len(gate_log) == 8 and all(len(j) >= 1 for j in gate_log)
+    for tag in (1, 2):
+        last_layer = max(i for i, e in enumerate(log) if e[0] == "layer" and e[1][0] == tag)
+        assert last_layer < log.index(("join", tag))
+    ref = [torch.nn.Parameter(w.detach().clone()) for w in ws]
+    (_plain(x1, ref).sum() + _plain(x2, ref).sum()).backward()
     for w, r in zip(ws, ref):
         assert torch.equal(w.grad, r.grad)
 
@@ -68,10 +118,9 @@ def test_unused_token_leaves_the_graph_untouched():
     (and the real sink never arms, so no kernel goes to the side stream)."""
     log = []
     w = torch.nn.Parameter(torch.tensor([3.0]))
-    sink = _Sink(log)
-    sink.token = overlap._Tail.apply(sink, w)
-    _Layer.apply(torch.ones(1), w, None, log, 0).sum().backward()
-    assert ("join",) not in log and torch.equal(w.grad, torch.ones(1))
+    sink = _begin([w], log)
+    _Layer.apply(torch.ones(1), sink.weight(w), None, log, 0).sum().backward()
+    assert not any(e[0] == "join" for e in log) and torch.equal(w.grad, torch.ones(1))
 
 
 def test_begin_declines_without_grad_mode_cpu_tensors_or_with_frozen_weights():
