@@ -1,5 +1,5 @@
 """BatchNorm2d (+ residual) (+ ReLU) of the 2-D feature extractor on the HIP BatchNorm kernels
-(csrc/az_bn3d.hip), for channels-last activations whose convolution ran elsewhere (MIOpen).
+(csrc/az_bn3d.hip), for the channels-last outputs of the 2-D convolution kernels (conv2d.py).
 
 `groups` splits the batch into equal consecutive parts that get their OWN batch statistics and
 update the running statistics one after the other.  With groups=2 one pass over the stacked

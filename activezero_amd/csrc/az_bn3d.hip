@@ -315,8 +315,8 @@ add_relu_kernel(float4 *__restrict__ y, const float4 *__restrict__ a,
 }
 
 
-// Standalone batch statistics of a channels-last tensor x[nvox][C] (used where the producer is not
-// one of our convolutions: the 2-D feature extractor's MIOpen convs).  Block `t` reduces voxels
+// Standalone batch statistics of a channels-last tensor x[nvox][C] (used where the producing kernel does not
+// emit BatchNorm partials in its epilogue: the 2-D convolution kernels of the feature extractor).  Block `t` reduces voxels
 // t*VPB + k*gridDim*VPB ... to one (sum, centred M2, count) partial per channel, in the layout
 // az_bn3d_finalize consumes ([C][tiles][2], counts[tiles]).  Sums are taken about the block's first
 // voxel (shifted data) so M2 = S2 - S1^2/n does not cancel.

@@ -11,8 +11,8 @@
 // delta = x - d (only delta < 2 cuts taps), and the G are 2-D 3x5 convolutions of R whose horizontal
 // tap index is kw - kd (the mask is R's own left zero padding; only the image's right edge needs its own
 // variant).  The 2-D convolutions (32 -> 96 full width + 384 on D+1 columns, and 32 -> 192: ~45 GFLOP at B=4
-// instead of 693) run on MIOpen through autograd (activezero_amd/costconv.py builds the merged kernels with
-// differentiable tensor ops); this file holds the memory-bound ends:
+// instead of 693) run on this library's 2-D convolution kernels through autograd (activezero_amd/costconv.py
+// builds the merged kernels with differentiable tensor ops); this file holds the memory-bound ends:
 //   assemble_fwd : out[b,d,y,x,:] = F[...] + G[...]                 (writes the 32-channel V0 tensor once)
 //   assemble_bwd : dF, dG = the matching reductions of grad_out over d (reads it twice)
 #include "az_common.h"

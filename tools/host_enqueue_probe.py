@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Host time to ENQUEUE one training step (forward, backward, Adam) against the time the GPU needs for it:
+22 ms vs 124 ms at B=4 -- the step is not launch bound."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import bench
