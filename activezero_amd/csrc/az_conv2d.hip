@@ -273,7 +273,8 @@ conv2d_same_kernel(const C2Args a) {
             float y = acc[m][r] * sc + sf;
             if (resp) y += resp[pix * (unsigned)a.res_cs];
             if (a.relu == 1) y = fmaxf(y, 0.f);
-            else if (a.relu == 2) y = 1.f / (1.f + __expf(-y));
+            if constexpr (PARTS == 1) {  // the gate activations exist only in the plain-bf16 (GRU) instantiations
+            if (a.relu == 2) y = 1.f / (1.f + __expf(-y));
             else if (a.relu >= 3) {
                 const float e2 = __expf(-2.f * fabsf(y));  // tanh without overflow
                 const float th = (1.f - e2) / (1.f + e2);
@@ -283,6 +284,7 @@ conv2d_same_kernel(const C2Args a) {
                     const float z = a.gz[(ib + pix) * a.gz_cs + co], hp = a.gh[(ib + pix) * a.gh_cs + co];
                     y = (1.f - z) * hp + z * y;
                 }
+            }
             }
             outp[pix * (unsigned)a.out_cs] = y;
         }
@@ -374,7 +376,7 @@ extern "C" int az_conv2d_fwd(float *out, const float *in, const float *packed_w,
         if ((long long)H * W * (cs > res_cstride ? cs : res_cstride) > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     }
     C2Args a{};
-    a.in = in; a.wp = packed_w; a.out = out; a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu;
+    a.in = in; a.wp = packed_w; a.out = out; a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu ? 1 : 0;
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
     a.in_cs = in_cstride; a.out_cs = out_cstride; a.res_cs = res_cstride;
     a.tiles_y = (H + C2_TY - 1) / C2_TY; a.tiles_x = (W + C2_TX - 1) / C2_TX;
