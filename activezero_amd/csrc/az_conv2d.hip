@@ -258,20 +258,24 @@ conv2d_same_kernel(const C2Args a) {
     // ---- epilogue: C/D map of the 32x32 MFMA -- column (out channel) = lane & 31, row (pixel of the 4x8
     // tile) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); M-tile m covers rows 4(m>>1).., cols 8(m&1)..
     const int co = ntile * 32 + row;
-    float *outp = a.out + (size_t)b * a.H * a.W * a.out_cs + co;
-    const float *resp = a.res ? a.res + (size_t)b * a.H * a.W * a.res_cs + co : nullptr;
+    // per-lane base at the patch's pixel (ty0, tx0 + 4*half); every (m, r) then adds a wave-uniform offset
+    // (rows and columns of the C/D map are compile-time): scalar address arithmetic instead of a 64-bit
+    // multiply chain per output element
+    const unsigned pix0 = (unsigned)(ty0 * a.W + tx0 + 4 * half);
+    float *outp = a.out + (size_t)b * a.H * a.W * a.out_cs + co + (size_t)pix0 * a.out_cs;
+    const float *resp = a.res ? a.res + (size_t)b * a.H * a.W * a.res_cs + co + (size_t)pix0 * a.res_cs : nullptr;
     const float sc = a.scale ? a.scale[co] : 1.f, sf = a.shift ? a.shift[co] : 0.f;
     const bool full = (ty0 + C2_TY <= a.H) && (tx0 + C2_TX <= a.W);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int vrow = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int oh = ty0 + 4 * (m >> 1) + (vrow >> 3), ow = tx0 + 8 * (m & 1) + (vrow & 7);
-            if (!(full || (oh < a.H && ow < a.W))) continue;
-            const unsigned pix = (unsigned)(oh * a.W + ow);
+            const int cy = 4 * (m >> 1) + (r >> 2), cx = 8 * (m & 1) + (r & 3);  // compile-time
+            if (!(full || (ty0 + cy < a.H && tx0 + cx + 4 * half < a.W))) continue;
+            const unsigned dpix = (unsigned)(cy * a.W + cx);  // wave-uniform
+            const unsigned pix = pix0 + dpix;
             float y = acc[m][r] * sc + sf;
-            if (resp) y += resp[pix * (unsigned)a.res_cs];
+            if (resp) y += resp[dpix * (unsigned)a.res_cs];
             if (a.relu == 1) y = fmaxf(y, 0.f);
             if constexpr (PARTS == 1) {  // the gate activations exist only in the plain-bf16 (GRU) instantiations
             if (a.relu == 2) y = 1.f / (1.f + __expf(-y));
@@ -286,7 +290,7 @@ conv2d_same_kernel(const C2Args a) {
                 }
             }
             }
-            outp[pix * (unsigned)a.out_cs] = y;
+            outp[dpix * (unsigned)a.out_cs] = y;
         }
 }
 
