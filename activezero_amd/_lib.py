@@ -55,7 +55,8 @@ _SIGS = {
     "az_conv3d_c1_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_dgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_wgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
-    "az_bn3d_finalize": [_PTR] * 10 + [_LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR],
+    "az_bn3d_finalize": [_PTR] * 10 + [_LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR, _LL, _PTR],
+    "az_bn3d_finalize_scratch": [_INT],
     "az_bn3d_eval_affine": [_PTR] * 6 + [_C.c_float, _INT, _PTR],
     "az_bn3d_apply": [_PTR] * 5 + [_INT, _LL, _INT, _PTR],
     "az_bn3d_bwd_workspace": [_LL, _INT],
@@ -82,7 +83,8 @@ _SIGS = {
 _RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_packed_floats": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL,
             "az_bn3d_stats_tiles": _LL, "az_bn2d_workspace": _LL,
-            "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL, "az_ir_pattern_workspace": _LL}
+            "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL, "az_ir_pattern_workspace": _LL,
+            "az_bn3d_finalize_scratch": _LL}
 
 
 def declared_symbols():

@@ -272,10 +272,11 @@ class _ConvBN(torch.autograd.Function):
             track = bn.track_running_stats and bn.running_mean is not None
             momentum = 0.1 if bn.momentum is None else float(bn.momentum)
             nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
+            scratch = x.new_empty(int(_lib.lib().az_bn3d_finalize_scratch(cout))) if ntiles >= 4096 else None
             _call("az_bn3d_finalize", _p(mean), _p(invstd), _p(scale), _p(shift),
                   _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
                   _p(part), _p(cnt), _p(gamma.detach()), _p(beta.detach()), ntiles, cout, eps,
-                  momentum, _p(nbt), _stream())
+                  momentum, _p(nbt), _p(scratch), scratch.numel() if scratch is not None else 0, _stream())
             if nbt is not None:  # the kernel wrote through raw pointers: tell the version counters (cache keys)
                 _touched(nbt, bn.running_mean, bn.running_var)
             y = torch.empty_like(raw)

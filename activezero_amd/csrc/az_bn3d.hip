@@ -37,6 +37,42 @@ __device__ __forceinline__ double bn_block_sum(double v, double *slots /* [NT/64
     return t;
 }
 
+// First stage for layers with very many partials (V0: 97 920 tiles per channel = 25 MB over 32 channels, which 32
+// blocks on 32 CUs pulled in 105 us): grid (C, S), block (c, s) merges slice s of channel c's partials into ONE
+// partial of the same format -- (sum, M2 about the slice mean) and the slice's count -- which bn_finalize_kernel
+// then merges as usual (Chan's formula is associative).
+#define BN_PRE_SLICES 32
+__global__ void __launch_bounds__(256)
+bn_premerge_kernel(float *__restrict__ part_out, float *__restrict__ cnt_out, const float *__restrict__ part,
+                   const float *__restrict__ cnt, long long ntiles) {
+    const int c = blockIdx.x, sl = blockIdx.y;
+    const long long per = (ntiles + BN_PRE_SLICES - 1) / BN_PRE_SLICES;
+    const long long t0 = sl * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    __shared__ double slots[256 / 64];
+    const float2 *pc = reinterpret_cast<const float2 *>(part) + (long long)c * ntiles;
+    double n = 0.0, sum = 0.0;
+    for (long long t = t0 + threadIdx.x; t < t1; t += 256) {
+        n += (double)cnt[t];
+        sum += (double)pc[t].x;
+    }
+    const double N = bn_block_sum<256>(n, slots);
+    const double S = bn_block_sum<256>(sum, slots);
+    const double mean = N > 0.0 ? S / N : 0.0;
+    double m2 = 0.0;
+    for (long long t = t0 + threadIdx.x; t < t1; t += 256) {
+        const float nt = cnt[t];
+        if (nt <= 0.f) continue;
+        const float2 pr = pc[t];
+        const double dlt = (double)pr.x / (double)nt - mean;
+        m2 += (double)pr.y + (double)nt * dlt * dlt;
+    }
+    const double M2 = bn_block_sum<256>(m2, slots);
+    if (threadIdx.x == 0) {
+        reinterpret_cast<float2 *>(part_out)[c * BN_PRE_SLICES + sl] = make_float2((float)S, (float)M2);
+        if (c == 0) cnt_out[sl] = (float)N;
+    }
+}
+
 // one block per channel; 1024 threads: the V0 layers merge 97 920 tile partials per channel and a
 // 256-thread block took 130 us per layer (25 layers per step) on two dependent fp64 passes
 #define BN_FIN_THREADS 1024
@@ -393,15 +429,25 @@ sum4_kernel(float4 *__restrict__ y, const float4 *__restrict__ a, const float4 *
         }                                                                                                       \
     } while (0)
 
+extern "C" long long az_bn3d_finalize_scratch(int C) { return (long long)C * BN_PRE_SLICES * 2 + BN_PRE_SLICES; }
+
 extern "C" int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
                                 float *running_mean, float *running_var, const float *partials,
                                 const float *counts, const float *gamma, const float *beta,
                                 long long ntiles, int C, float eps, float momentum,
-                                long long *num_batches_tracked, void *stream) {
+                                long long *num_batches_tracked, float *scratch,
+                                long long scratch_floats, void *stream) {
     AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
     AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta);
     AZ_REQUIRE(ntiles > 0 && C > 0);
     if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
+    if (scratch != nullptr && ntiles >= 4096) {  // two stages (see bn_premerge_kernel)
+        if (scratch_floats < az_bn3d_finalize_scratch(C)) return AZ_EWORKSPACE;
+        float *p2 = scratch, *c2 = scratch + (size_t)C * BN_PRE_SLICES * 2;
+        hipLaunchKernelGGL(bn_premerge_kernel, dim3(C, BN_PRE_SLICES), dim3(256), 0, az_stream(stream), p2, c2, partials,
+                           counts, ntiles);
+        partials = p2; counts = c2; ntiles = BN_PRE_SLICES;
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_FIN_THREADS), 0, az_stream(stream), mean, invstd,
                        scale, shift, running_mean, running_var, partials, counts, gamma, beta,
                        ntiles, C, eps, momentum, 1, num_batches_tracked);

@@ -176,12 +176,15 @@ int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *grad_logits,
 /* ---- BatchNorm3d pieces around K4/K5 (psmnet_submodule_3.py:55) --------------------
  * finalize: merge the conv partials (Chan, fp64) -> mean, invstd, scale = gamma*invstd,
  * shift = beta - mean*scale; running stats updated in place (momentum, unbiased var)
- * unless running_mean/var are NULL; *num_batches_tracked (int64, may be NULL) += 1. */
+ * unless running_mean/var are NULL; *num_batches_tracked (int64, may be NULL) += 1.
+ * scratch (may be NULL; az_bn3d_finalize_scratch(C) floats): with it, layers with >= 4096 partials per channel are
+ * merged in two stages (C x 32 blocks, then C blocks) instead of by C blocks alone. */
+long long az_bn3d_finalize_scratch(int C);
 int az_bn3d_finalize(float *mean, float *invstd, float *scale, float *shift,
                      float *running_mean, float *running_var, const float *partials,
                      const float *counts, const float *gamma, const float *beta,
                      long long ntiles, int C, float eps, float momentum,
-                     long long *num_batches_tracked, void *stream);
+                     long long *num_batches_tracked, float *scratch, long long scratch_floats, void *stream);
 /* batch statistics of a channels-last tensor x[nvox][C] (C = 32, 64, 128) whose producer is not one
  * of these convolutions (the 2-D extractor's layers, nets/psmnet/psmnet_submodule_3.py:8-22):
  * partials [C][tiles][2], counts [tiles] with tiles = az_bn3d_stats_tiles(nvox, C), for az_bn3d_finalize */
