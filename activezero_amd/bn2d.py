@@ -26,9 +26,21 @@ def _rows(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
+class Partials:
+    """BatchNorm partials of a tensor made by its producing convolution (conv2d.conv(..., stats=...)): filled by
+    the convolution's forward, consumed by bn_act in place of a statistics pass over the tensor."""
+
+    def __init__(self, groups):
+        self.groups, self.part, self.cnt, self.tiles = groups, None, None, 0
+
+    @property
+    def ready(self):
+        return self.part is not None
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, bn, relu, groups, cache):
+    def forward(ctx, x, gamma, beta, residual, bn, relu, groups, cache, partials=None):
         n, c, h, w = x.shape
         if n % groups:
             raise RuntimeError("batch must divide into the statistic groups")
@@ -56,10 +68,13 @@ class _BNAct(torch.autograd.Function):
             stats = xr.new_empty(4, groups, c)  # mean, invstd, scale, shift per group
             track = bn.track_running_stats and bn.running_mean is not None
             nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
+            pre = partials is not None and partials.ready and partials.groups == groups
             _call("az_bn2d_fwd", _p(yr), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
                   _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None, _p(xr), _p(rr),
                   _p(g_), _p(b_), _p(ws), ws_bytes, int(relu), groups, nvox, c, eps,
-                  float(bn.momentum) if bn.momentum is not None else 0.1, _p(nbt), _stream())
+                  float(bn.momentum) if bn.momentum is not None else 0.1, _p(nbt),
+                  _p(partials.part) if pre else None, _p(partials.cnt) if pre else None, partials.tiles if pre else 0,
+                  _stream())
             if nbt is not None:
                 from .conv3d import _touched
                 _touched(nbt, bn.running_mean, bn.running_var)
@@ -82,7 +97,7 @@ class _BNAct(torch.autograd.Function):
             dgamma = (dz * (xr - rm)).sum(dim=(0, 1, 2)) * rinv
             dbeta = dz.sum(dim=(0, 1, 2))
             g_res = dz.permute(0, 3, 1, 2) if has_res else None
-            return (dz * scale).permute(0, 3, 1, 2), dgamma, dbeta, g_res, None, None, None, None
+            return (dz * scale).permute(0, 3, 1, 2), dgamma, dbeta, g_res, None, None, None, None, None
         xr, yr, gamma, stats = ctx.saved_tensors
         nvox = (n // groups) * h * w
         lib = _lib.lib()
@@ -100,9 +115,10 @@ class _BNAct(torch.autograd.Function):
         g_res = None
         if has_res:
             g_res = (dzr if relu else gr).permute(0, 3, 1, 2)
-        return dxr.permute(0, 3, 1, 2), dgb[0], dgb[1], g_res, None, None, None, None
+        return dxr.permute(0, 3, 1, 2), dgb[0], dgb[1], g_res, None, None, None, None, None
 
 
-def bn_act(x, bn, relu=False, residual=None, groups=1):
-    """relu?(BatchNorm2d(x) + residual), x [N,C,H,W] (channels_last preferred), statistics per batch group."""
-    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu, groups, not torch.is_grad_enabled())
+def bn_act(x, bn, relu=False, residual=None, groups=1, partials=None):
+    """relu?(BatchNorm2d(x) + residual), x [N,C,H,W] (channels_last preferred), statistics per batch group.
+    partials: a filled `Partials` of x from its producing convolution (train mode: no statistics pass here)."""
+    return _BNAct.apply(x, bn.weight, bn.bias, residual, bn, relu, groups, not torch.is_grad_enabled(), partials)

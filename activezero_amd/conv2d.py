@@ -70,6 +70,20 @@ def _run(xr, packed, cin, cout, kh, kw, dil, scale=None, shift=None, res=None, r
     return out
 
 
+def _run_stats(xr, packed, cin, cout, kh, kw, dil, stats):
+    """_run without epilogue operands; also fills `stats` (bn2d.Partials) with the output's BatchNorm partials."""
+    b, h, w, cx = xr.shape
+    out = xr.new_empty(b, h, w, cout)
+    tiles = int(_lib.lib().az_conv2d_stats_tiles(b, h, w, stats.groups))
+    part, cnt = xr.new_empty(stats.groups, cout, tiles, 2), xr.new_empty(stats.groups, tiles)
+    with profiler.scope(f"conv2d_{kh}x{kw}d{dil}_{cin}_{cout}", flops=2.0 * kh * kw * cin * cout * b * h * w,
+                        peak=PEAK_X6):
+        _call("az_conv2d_fwd_stats", _p(out), _p(part), _p(cnt), _p(xr), _p(packed), stats.groups, b, h, w, cin, cout,
+              cx, cout, kh, kw, dil, _stream())
+    stats.part, stats.cnt, stats.tiles = part, cnt, tiles
+    return out
+
+
 def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=None):
     """gr: [B,H,W,>=cm] grad rows, xr: [B,H,W,>=cn] input rows -> [cm_real, cn_real, kh, kw].
     sink: overlap.Sink or None -- the kernels run on its side stream (the result is valid after its join)."""
@@ -108,13 +122,16 @@ class _ConvSame(torch.autograd.Function):
     kernel of the autograd engine (one read + one write of the activation per block saved)."""
 
     @staticmethod
-    def forward(ctx, x, weight, dil, with_skip, sink=None):
+    def forward(ctx, x, weight, dil, with_skip, sink=None, stats=None):
         ctx.sink = _leaf_sink(sink, weight)
         cout, cin, kh, kw = weight.shape
         xr = _chk(rows(x), "x")
         with torch.cuda.device(x.device):
             pk = _pack(weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False)
-            y = _run(xr, pk, cin, cout, kh, kw, dil)
+            if stats is not None and (kh, kw) in ((3, 3), (1, 1)) and xr.shape[0] % stats.groups == 0:
+                y = _run_stats(xr, pk, cin, cout, kh, kw, dil, stats)  # + the BatchNorm partials of y (bn2d.Partials)
+            else:
+                y = _run(xr, pk, cin, cout, kh, kw, dil)
         ctx.save_for_backward(xr, weight)
         ctx.dil = dil
         ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero tensor
@@ -128,7 +145,7 @@ class _ConvSame(torch.autograd.Function):
         cout, cin, kh, kw = weight.shape
         dil = ctx.dil
         if gy is None:  # only the shortcut was used downstream
-            return gskip, None, None, None, None
+            return gskip, None, None, None, None, None
         gr = _chk(rows(gy), "grad_y")
         gx = gw = None
         with torch.cuda.device(gy.device):
@@ -138,7 +155,7 @@ class _ConvSame(torch.autograd.Function):
                 gx = image(_run(gr, pk, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
             if ctx.needs_input_grad[1]:
                 gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil, sink=ctx.sink)
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None
 
 
 def _check_same(weight, dilation):
@@ -148,14 +165,15 @@ def _check_same(weight, dilation):
     return 1 if kh == 1 else dilation
 
 
-def conv_same(x, weight, dilation=1, sink=None):
-    """F.conv2d(x, weight, padding="same", dilation=dilation) for [B,C,H,W] x (channels_last preferred)."""
-    return _ConvSame.apply(x, weight, _check_same(weight, dilation), False, sink)
+def conv_same(x, weight, dilation=1, sink=None, stats=None):
+    """F.conv2d(x, weight, padding="same", dilation=dilation) for [B,C,H,W] x (channels_last preferred).
+    stats: a bn2d.Partials to fill with the BatchNorm partials of the output (3x3 and 1x1 layers)."""
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), False, sink, stats)
 
 
-def conv_same_skip(x, weight, dilation=1, sink=None):
+def conv_same_skip(x, weight, dilation=1, sink=None, stats=None):
     """(conv_same(x, weight, dilation), x): the second output is x for the block's shortcut (see _ConvSame)."""
-    return _ConvSame.apply(x, weight, _check_same(weight, dilation), True, sink)
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), True, sink, stats)
 
 
 class _ConvS2Vol(torch.autograd.Function):
@@ -252,16 +270,18 @@ def is_same(m):
     return s == (1, 1) and k[0] == k[1] and p[0] == p[1] == d[0] * (k[0] - 1) // 2 and d[0] == d[1]
 
 
-def conv(x, m, arith=None, skip=False):
+def conv(x, m, arith=None, skip=False, stats=None):
     """m(x) for an nn.Conv2d of the extractor (bias-free, groups 1), differentiable, on the HIP kernels.
-    skip=True (stride-1 layers only): returns (m(x), x), see conv_same_skip."""
+    skip=True (stride-1 layers only): returns (m(x), x), see conv_same_skip.
+    stats: a bn2d.Partials; the stride-1 3x3 / 1x1 routes fill it with the output's BatchNorm partials (the other
+    routes leave it empty and the BatchNorm runs its own statistics pass)."""
     arith = conv3d._arith(arith)
     if not isinstance(m, torch.nn.Conv2d) or m.bias is not None or m.groups != 1:
         raise RuntimeError("conv2d.conv: expects a bias-free nn.Conv2d")
     k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
     cin, cout = m.in_channels, m.out_channels
     if is_same(m):
-        return (conv_same_skip if skip else conv_same)(x, _w(m, arith), d[0], arith.sink)
+        return (conv_same_skip if skip else conv_same)(x, _w(m, arith), d[0], arith.sink, stats)
     if skip:
         raise RuntimeError(f"conv2d.conv: skip output needs a stride-1 layer, got {m}")
     if s == (2, 2) and k == (3, 3) and p == (1, 1) and d == (1, 1):
@@ -271,7 +291,7 @@ def conv(x, m, arith=None, skip=False):
             sink = arith.sink
             return _ConvS2Patches.apply(x, _w(m, arith), sink, sink.token if sink is not None else None)
     if s == (2, 2) and k == (1, 1) and p == (0, 0):
-        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), _w(m, arith), 1, arith.sink)
+        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), _w(m, arith), 1, arith.sink, stats)
     raise RuntimeError(f"conv2d.conv: unsupported layer {m}")
 
 

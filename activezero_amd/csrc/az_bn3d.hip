@@ -576,10 +576,16 @@ template <int C>
 static void bn2d_fwd_launch(float *y, float *mean, float *invstd, float *scale, float *shift, float *rm,
                             float *rv, const float *x, const float *res, const float *gamma,
                             const float *beta, float *ws, int relu, int groups, long long nvox, float eps,
-                            float momentum, long long *nbt, hipStream_t s) {
-    const long long tiles = az_bn3d_stats_tiles(nvox, C);
-    float *part = ws, *cnt = ws + (size_t)groups * C * tiles * 2;
-    hipLaunchKernelGGL(bn_stats_kernel<C>, dim3((unsigned)tiles, groups), dim3(256), 0, s, part, cnt, x, nvox, tiles);
+                            float momentum, long long *nbt, const float *pre_part, const float *pre_cnt,
+                            long long pre_tiles, hipStream_t s) {
+    long long tiles = az_bn3d_stats_tiles(nvox, C);
+    const float *part = ws, *cnt = ws + (size_t)groups * C * tiles * 2;
+    if (pre_part != nullptr) {  // the producing convolution already reduced its patches (az_conv2d_fwd_stats)
+        part = pre_part; cnt = pre_cnt; tiles = pre_tiles;
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel<C>, dim3((unsigned)tiles, groups), dim3(256), 0, s, ws,
+                           ws + (size_t)groups * C * tiles * 2, x, nvox, tiles);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_FIN_THREADS), 0, s, mean, invstd, scale, shift, rm, rv,
                        part, cnt, gamma, beta, tiles, C, eps, momentum, groups, nbt);
     const long long total4 = nvox * C / 4;
@@ -592,18 +598,20 @@ extern "C" int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, f
                            float *running_mean, float *running_var, const float *x, const float *residual,
                            const float *gamma, const float *beta, float *workspace, long long workspace_bytes,
                            int relu, int groups, long long nvox, int C, float eps, float momentum,
-                           long long *num_batches_tracked, void *stream) {
+                           long long *num_batches_tracked, const float *partials,
+                           const float *counts, long long partial_tiles, void *stream) {
     AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
     AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta); AZ_REQUIRE_PTR(workspace);
     if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
+    if ((partials == nullptr) != (counts == nullptr) || (partials != nullptr && partial_tiles <= 0)) return AZ_EINVAL;
     const long long need = az_bn2d_workspace(groups, nvox, C);
     if (need < 0) return (int)need;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
     if (groups > 65535) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
-    if (C == 32) bn2d_fwd_launch<32>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, s);
-    else if (C == 64) bn2d_fwd_launch<64>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, s);
-    else bn2d_fwd_launch<128>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, s);
+    if (C == 32) bn2d_fwd_launch<32>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s);
+    else if (C == 64) bn2d_fwd_launch<64>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s);
+    else bn2d_fwd_launch<128>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s);
     return az_launch_status();
 }
 

@@ -47,13 +47,18 @@ struct C2Args {
     int in_cs, out_cs, res_cs;
     int tiles_y, tiles_x, ngroups;  // patch tiles and cout groups of 32*NW
     int relu;  // epilogue activation: 0 none, 1 ReLU, 2 sigmoid, 3 tanh, 4 GRU combine (1-z)*h + z*tanh(.)
+    // STATS instantiations: BatchNorm partials of the raw output, one (sum, M2 about the patch mean) per channel
+    // and patch in az_bn2d_fwd's layout [group][cout][stiles][2], counts [group][stiles]
+    float *spart, *scnt;
+    int sgroups;       // statistic groups: consecutive B / sgroups images each
+    long long stiles;  // patches per group
 };
 
 // PARTS = 3: the bf16x6 arithmetic above (fp32-class).  PARTS = 1: plain bf16 operands (round-to-nearest), one
 // MFMA per 16-deep block, fp32 accumulation -- the arithmetic of the reference's autocast region around the
 // RAFT-Stereo GRU update (nets/raft/raft_stereo.py:98,142-172; nets/raft/update.py:19-41), same slab / weight
 // pipeline with the mid / lo parts left out.
-template <int NW, int KH, int KW, int DIL, int PARTS = 3>
+template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv2d_same_kernel(const C2Args a) {
     constexpr int T = KH * KW;
@@ -292,6 +297,40 @@ conv2d_same_kernel(const C2Args a) {
             }
             outp[dpix * (unsigned)a.out_cs] = y;
         }
+    if constexpr (STATS) {
+        // BatchNorm partials of this wave's 32 channels over the patch (the layer's BatchNorm then skips its own
+        // statistics pass over the tensor): lane = channel co, its 64 values + the other half-wave's 64
+        float sm = 0.f;
+        int n = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cy = 4 * (m >> 1) + (r >> 2), cx = 8 * (m & 1) + (r & 3);
+                const bool ok = full || (ty0 + cy < a.H && tx0 + cx + 4 * half < a.W);
+                sm += ok ? acc[m][r] : 0.f;
+                n += ok ? 1 : 0;
+            }
+        sm += __shfl_xor(sm, 32);
+        n += __shfl_xor(n, 32);
+        const float mean = sm / (float)max(n, 1);
+        float m2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cy = 4 * (m >> 1) + (r >> 2), cx = 8 * (m & 1) + (r & 3);
+                const bool ok = full || (ty0 + cy < a.H && tx0 + cx + 4 * half < a.W);
+                const float d = acc[m][r] - mean;
+                m2 = ok ? fmaf(d, d, m2) : m2;
+            }
+        m2 += __shfl_xor(m2, 32);
+        const int per = a.B / a.sgroups, g = b / per;
+        const long long tile = ((long long)(b - g * per) * a.tiles_y + tiy) * a.tiles_x + tix;
+        if (half == 0)
+            *reinterpret_cast<float2 *>(&a.spart[(((size_t)g * a.cout + co) * a.stiles + tile) * 2]) = make_float2(sm, m2);
+        if (ntile == 0 && lane == 0) a.scnt[(size_t)g * a.stiles + tile] = (float)n;
+    }
 }
 
 // ---- weight packing ---------------------------------------------------------------------------------
@@ -348,22 +387,22 @@ extern "C" int az_conv2d_pack_weights_bf16(float *packed, const float *w, int ci
     return az_launch_status();
 }
 
-template <int NW, int KH, int KW, int DIL, int PARTS = 3>
+template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>
 static int launch_c2(C2Args a, hipStream_t s) {
     a.ngroups = (a.cout / 32) / NW;
     const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.ngroups;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv2d_same_kernel<NW, KH, KW, DIL, PARTS>), dim3((unsigned)blocks), dim3(64 * NW), 0, s, a);
+    hipLaunchKernelGGL((conv2d_same_kernel<NW, KH, KW, DIL, PARTS, STATS>), dim3((unsigned)blocks), dim3(64 * NW), 0, s, a);
     return az_launch_status();
 }
 
-template <int KH, int KW, int DIL, int PARTS = 3>
+template <int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>
 static int dispatch_nw(const C2Args &a, hipStream_t s) {
     const int nt = a.cout / 32;
-    if (nt % 4 == 0) return launch_c2<4, KH, KW, DIL, PARTS>(a, s);
-    if (nt % 3 == 0) return launch_c2<3, KH, KW, DIL, PARTS>(a, s);
-    if (nt % 2 == 0) return launch_c2<2, KH, KW, DIL, PARTS>(a, s);
-    return launch_c2<1, KH, KW, DIL, PARTS>(a, s);
+    if (nt % 4 == 0) return launch_c2<4, KH, KW, DIL, PARTS, STATS>(a, s);
+    if (nt % 3 == 0) return launch_c2<3, KH, KW, DIL, PARTS, STATS>(a, s);
+    if (nt % 2 == 0) return launch_c2<2, KH, KW, DIL, PARTS, STATS>(a, s);
+    return launch_c2<1, KH, KW, DIL, PARTS, STATS>(a, s);
 }
 
 extern "C" int az_conv2d_fwd(float *out, const float *in, const float *packed_w, const float *scale,
@@ -389,6 +428,36 @@ extern "C" int az_conv2d_fwd(float *out, const float *in, const float *packed_w,
     if (kh == 3 && kw == 3 && dilation == 2) return dispatch_nw<3, 3, 2>(a, s);
     if (kh == 1 && kw == 1) return dispatch_nw<1, 1, 1>(a, s);
     if (kh == 3 && kw == 5 && dilation == 1) return dispatch_nw<3, 5, 1>(a, s);
+    return AZ_EUNSUPPORTED;
+}
+
+/* az_conv2d_fwd without epilogue operands, plus the BatchNorm partials of the (raw) output: partials
+ * [groups][cout][tiles][2] = (sum, M2 about the patch mean) per channel and 8x16 patch, counts [groups][tiles],
+ * tiles = az_conv2d_stats_tiles(B, H, W, groups) -- what az_bn2d_fwd takes in place of its own statistics pass.
+ * 3x3 (dilation 1, 2) and 1x1 layers. */
+extern "C" long long az_conv2d_stats_tiles(int B, int H, int W, int groups) {
+    if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || B % groups) return AZ_EINVAL;
+    return (long long)(B / groups) * ((H + C2_TY - 1) / C2_TY) * ((W + C2_TX - 1) / C2_TX);
+}
+
+extern "C" int az_conv2d_fwd_stats(float *out, float *partials, float *counts, const float *in, const float *packed_w,
+                                   int groups, int B, int H, int W, int cin, int cout, int in_cstride,
+                                   int out_cstride, int kh, int kw, int dilation, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w);
+    AZ_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0 && groups > 0 && B % groups == 0);
+    if (cin % 16 || cout % 32) return AZ_EUNSUPPORTED;
+    AZ_REQUIRE(in_cstride >= cin && out_cstride >= cout && in_cstride % 4 == 0);
+    if ((long long)H * W * (in_cstride > out_cstride ? in_cstride : out_cstride) > 0x7fffffffLL) return AZ_EUNSUPPORTED;
+    C2Args a{};
+    a.in = in; a.wp = packed_w; a.out = out;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
+    a.in_cs = in_cstride; a.out_cs = out_cstride;
+    a.tiles_y = (H + C2_TY - 1) / C2_TY; a.tiles_x = (W + C2_TX - 1) / C2_TX;
+    a.spart = partials; a.scnt = counts; a.sgroups = groups; a.stiles = az_conv2d_stats_tiles(B, H, W, groups);
+    hipStream_t s = az_stream(stream);
+    if (kh == 3 && kw == 3 && dilation == 1) return dispatch_nw<3, 3, 1, 3, true>(a, s);
+    if (kh == 3 && kw == 3 && dilation == 2) return dispatch_nw<3, 3, 2, 3, true>(a, s);
+    if (kh == 1 && kw == 1) return dispatch_nw<1, 1, 1, 3, true>(a, s);
     return AZ_EUNSUPPORTED;
 }
 

@@ -35,10 +35,12 @@ def _convbn_unit(x, unit, relu=False, residual=None, groups=1, skip=False, arith
         y = conv2d.conv_bn_eval(x, conv, bn, relu, residual)
         if y is not None:
             return (y, x) if skip else y
+    # train mode: the convolution's epilogue also reduces the BatchNorm partials of its output
+    stats = bn2d.Partials(groups) if training else None
     if skip and torch.is_grad_enabled() and x.requires_grad and conv2d.is_same(conv):
-        c, shortcut = conv2d.conv(x, conv, arith, skip=True)
-        return bn2d.bn_act(c, bn, relu, residual, groups), shortcut
-    y = bn2d.bn_act(conv2d.conv(x, conv, arith), bn, relu, residual, groups)
+        c, shortcut = conv2d.conv(x, conv, arith, skip=True, stats=stats)
+        return bn2d.bn_act(c, bn, relu, residual, groups, stats), shortcut
+    y = bn2d.bn_act(conv2d.conv(x, conv, arith, stats=stats), bn, relu, residual, groups, stats)
     return (y, x) if skip else y
 
 

@@ -199,6 +199,8 @@ int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, float *shift
                 float *running_var, const float *x, const float *residual, const float *gamma,
                 const float *beta, float *workspace, long long workspace_bytes, int relu, int groups,
                 long long nvox, int C, float eps, float momentum, long long *num_batches_tracked /* += groups; may be NULL */,
+                const float *partials, const float *counts, long long partial_tiles /* of az_conv2d_fwd_stats; NULL, NULL, 0:
+                the statistics pass runs here */,
                 void *stream);
 /* backward: dx [groups][nvox][C]; dgamma/dbeta [C] summed over the groups; dz_out (may be NULL) = the
  * gradient of the residual branch when relu != 0 */
@@ -261,6 +263,14 @@ long long az_conv2d_wgrad_workspace(int cm, int cn, int kh, int kw);
 int az_conv2d_wgrad(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
                     const float *in, int B, int H, int W, int cm, int cn, int cm_real, int cn_real,
                     int go_cstride, int in_cstride, int kh, int kw, int dilation, void *stream);
+/* az_conv2d_fwd without epilogue operands that also emits the BatchNorm partials of its (raw) output -- per channel
+ * and 8x16 patch (sum, M2 about the patch mean), layout [groups][cout][tiles][2] + counts [groups][tiles] with
+ * tiles = az_conv2d_stats_tiles() -- which az_bn2d_fwd accepts in place of its own statistics pass over the tensor
+ * (psmnet_submodule_3.py:13-22 convbn: Conv2d -> BatchNorm2d).  3x3 (dilation 1, 2) and 1x1 layers. */
+long long az_conv2d_stats_tiles(int B, int H, int W, int groups);
+int az_conv2d_fwd_stats(float *out, float *partials, float *counts, const float *in, const float *packed_w,
+                        int groups, int B, int H, int W, int cin, int cout, int in_cstride, int out_cstride,
+                        int kh, int kw, int dilation, void *stream);
 /* plain-bf16 twin of az_conv2d_fwd for 3x3 layers (one MFMA per 16-deep block, operands rounded to bf16,
  * fp32 accumulation and fp32 tensors): the arithmetic of the reference's autocast region around the RAFT-Stereo
  * GRU update (nets/raft/raft_stereo.py:142-172 calling nets/raft/update.py:19-41 ConvGRU).
