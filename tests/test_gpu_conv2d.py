@@ -157,6 +157,39 @@ def test_convbn_unit_train_and_eval_vs_torch_modules(cin, cout, k, dil, stride, 
     close(ye, yre, 1e-4, 2e-5)
 
 
+@pytest.mark.parametrize("c,k,dil,hw,groups", [(32, 3, 1, (21, 37), 1), (64, 3, 1, (24, 48), 2), (128, 3, 2, (17, 23), 2),
+                                              (64, 1, 1, (9, 50), 1)])
+def test_batchnorm_partials_from_the_conv_epilogue(c, k, dil, hw, groups):
+    """az_conv2d_fwd_stats: the (sum, M2) partials the convolution's epilogue reduces per channel and 8x16 patch
+    -- ragged patches at the image border included -- give the BatchNorm the statistics its own pass over the
+    tensor gives, per statistic group: same output, same running statistics."""
+    h, w = hw
+    x = seeded((4, c, h, w), 71).to(DEV).contiguous(memory_format=CL)
+    wt = (seeded((c, c, k, k), 72) * 0.1).to(DEV)
+    want_stats = bn2d.Partials(groups)
+    y = conv2d.conv_same(x, wt, dil, stats=want_stats)
+    assert want_stats.ready and want_stats.part.shape[:2] == (groups, c) and want_stats.cnt.shape[0] == groups
+    # partials -> per-group mean / variance, against the tensor itself
+    yg = y.detach().double().reshape(groups, 4 // groups, c, h * w).permute(0, 2, 1, 3).reshape(groups, c, -1)
+    n = want_stats.cnt.double().sum(1)                                    # [groups]
+    assert torch.equal(n.cpu(), torch.full((groups,), float(4 // groups * h * w), dtype=torch.float64))
+    s = want_stats.part[..., 0].double().sum(2)                           # [groups, c]
+    mean = s / n[:, None]
+    tile_mean = want_stats.part[..., 0].double() / want_stats.cnt.double()[:, None, :]
+    m2 = (want_stats.part[..., 1].double() + want_stats.cnt.double()[:, None, :] * (tile_mean - mean[..., None]) ** 2).sum(2)
+    close(mean, yg.mean(2), 1e-5, 1e-6)
+    close(m2 / n[:, None], yg.var(2, unbiased=False), 1e-4, 1e-7)
+    # and through the BatchNorm: with the partials vs with its own statistics pass
+    bn_a = load_procedural(torch.nn.BatchNorm2d(c), "t.part.").to(DEV).train()
+    bn_b = load_procedural(torch.nn.BatchNorm2d(c), "t.part.").to(DEV).train()
+    ya = bn2d.bn_act(y, bn_a, relu=True, groups=groups, partials=want_stats)
+    yb = bn2d.bn_act(y, bn_b, relu=True, groups=groups)
+    close(ya, yb, 1e-5, 1e-6)
+    close(bn_a.running_mean, bn_b.running_mean, 1e-6, 1e-7)
+    close(bn_a.running_var, bn_b.running_var, 1e-5, 1e-7)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == groups
+
+
 def test_convbn_unit_eval_mode_backward():
     """frozen-BatchNorm fine-tuning (eval mode under autograd), as the reference's plain modules allow"""
     unit = load_procedural(sm.convbn(64, 64, 3, 1, 1, 1), "t.cb2e.").to(DEV).eval()
