@@ -218,7 +218,7 @@ class _ConvS2Patches(torch.autograd.Function):
     """3x3, stride 2, pad 1 on a thin image (C = 3 or 6 -> 32): patch extraction + 1x1 convolution."""
 
     @staticmethod
-    def forward(ctx, x, weight, sink=None, token=None):
+    def forward(ctx, x, weight, sink=None, token=None, stats=None):
         # `token`: the sink's 1-element tensor (overlap._Tail's output).  This layer is the first convolution of
         # the extractor, hence the last convolution node of the backward pass: its gradient for the token is
         # what makes _Tail.backward -- the join of the side stream -- run after every weight-gradient launch.
@@ -236,7 +236,10 @@ class _ConvS2Patches(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _call("az_im2col_s2k3", _p(patches), _p(xr), b, cin, h, w, kp, _stream())
             pk = _pack(w2, kp, cout, 9 * cin, cout, 9 * cin, 1, 1, 1, False)
-            y = _run(patches, pk, kp, cout, 1, 1, 1, tag="fe2d_first")
+            if stats is not None and b % stats.groups == 0:
+                y = _run_stats(patches, pk, kp, cout, 1, 1, 1, stats)
+            else:
+                y = _run(patches, pk, kp, cout, 1, 1, 1, tag="fe2d_first")
         ctx.save_for_backward(patches, w2)
         ctx.dims = (b, cin, h, w, kp)
         return image(y)
@@ -261,7 +264,7 @@ class _ConvS2Patches(torch.autograd.Function):
                 with overlap.scope(ctx.sink, g2):
                     gw.copy_(g2.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2))
         gtok = gr.new_zeros(1) if ctx.needs_input_grad[3] else None
-        return gx, gw, None, gtok
+        return gx, gw, None, gtok, None
 
 
 def is_same(m):
@@ -289,7 +292,7 @@ def conv(x, m, arith=None, skip=False, stats=None):
             return _ConvS2Vol.apply(x, _w(m, arith), arith)
         if 9 * cin <= 64 and cout % 32 == 0:
             sink = arith.sink
-            return _ConvS2Patches.apply(x, _w(m, arith), sink, sink.token if sink is not None else None)
+            return _ConvS2Patches.apply(x, _w(m, arith), sink, sink.token if sink is not None else None, stats)
     if s == (2, 2) and k == (1, 1) and p == (0, 0):
         return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), _w(m, arith), 1, arith.sink, stats)
     raise RuntimeError(f"conv2d.conv: unsupported layer {m}")
