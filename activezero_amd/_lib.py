@@ -54,9 +54,9 @@ _SIGS = {
     "az_conv3d_fwd_stats": [_PTR] * 6 + [_INT] * 9 + [_PTR],
     "az_conv3d_wgrad_workspace": [_INT, _INT],
     "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 11 + [_PTR],
-    "az_conv3d_c1_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
+    "az_conv3d_c1_fwd": [_PTR] * 6 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_dgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
-    "az_conv3d_c1_wgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
+    "az_conv3d_c1_wgrad": [_PTR] * 5 + [_INT] * 4 + [_PTR],
     "az_bn3d_finalize": [_PTR] * 10 + [_LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR, _LL, _PTR],
     "az_bn3d_finalize_scratch": [_INT],
     "az_bn3d_eval_affine": [_PTR] * 6 + [_C.c_float, _INT, _PTR],

@@ -51,16 +51,16 @@ def costvol_conv_bn(feat_l, feat_r, ndisp, unit, relu=False, arith=None):
     return y.permute(0, 2, 3, 1).reshape(b, d, h, w, c)
 
 
-def conv_bn(vol, unit, relu=False, add=None, arith=None):
-    return conv3d.conv_bn(vol, unit[0], unit[1], _mode_of(unit[0]), relu, add, arith)
+def conv_bn(vol, unit, relu=False, add=None, arith=None, defer=None):
+    return conv3d.conv_bn(vol, unit[0], unit[1], _mode_of(unit[0]), relu, add, arith, defer)
 
 
 def deconv_bn(vol, unit, relu=False, add=None, arith=None):
     return conv3d.conv_bn(vol, unit[0], unit[1], conv3d.DECONV_S2, relu, add, arith)
 
 
-def conv_logits(vol, conv, add=None, arith=None):
-    return conv3d.conv_logits(vol, conv, add, arith.sink if arith is not None else None)
+def conv_logits(vol, conv, add=None, arith=None, affine=None):
+    return conv3d.conv_logits(vol, conv, add, arith.sink if arith is not None else None, affine)
 
 
 def add(a, b):

@@ -246,7 +246,7 @@ class _ConvBN(torch.autograd.Function):
     """y = relu?( BN(conv(x, weight)) + residual ), one autograd node per convbn_3d unit."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, arith):
+    def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, arith, defer=None):
         x = _chk(x, "x")  # (LazyCostVolume never reaches autograd: see conv_bn)
         if residual is not None:
             residual = _chk(residual, "residual")
@@ -279,12 +279,18 @@ class _ConvBN(torch.autograd.Function):
                   momentum, _p(nbt), _p(scratch), scratch.numel() if scratch is not None else 0, _stream())
             if nbt is not None:  # the kernel wrote through raw pointers: tell the version counters (cache keys)
                 _touched(nbt, bn.running_mean, bn.running_var)
-            y = torch.empty_like(raw)
             nvox = raw.numel() // cout
-            with profiler.scope(f"bn3d_apply_{cout}", bytes=4.0 * raw.numel() * (3 if residual is not None else 2),
-                                bound="hbm"):
-                _call("az_bn3d_apply", _p(y), _p(raw), _p(scale), _p(shift), _p(residual), int(relu),
-                      nvox, cout, _stream())
+            if defer is not None and relu and residual is None:
+                # the single consumer applies relu(raw * scale + shift) itself while it stages its input
+                # (DeferredAffine): no apply pass, no second copy of the tensor; this node's output IS raw
+                defer.scale, defer.shift = scale, shift
+                y = raw
+            else:
+                y = torch.empty_like(raw)
+                with profiler.scope(f"bn3d_apply_{cout}", bytes=4.0 * raw.numel() * (3 if residual is not None else 2),
+                                    bound="hbm"):
+                    _call("az_bn3d_apply", _p(y), _p(raw), _p(scale), _p(shift), _p(residual), int(relu),
+                          nvox, cout, _stream())
         # a ReLU layer without residual recomputes its mask from raw in backward (fma(raw, scale, shift) > 0)
         remask = relu and residual is None
         ctx.save_for_backward(x, weight, gamma, raw, y if (relu and not remask) else None, mean, invstd,
@@ -330,10 +336,22 @@ class _ConvBN(torch.autograd.Function):
                 gx = _input_grad(dx_raw, weight, mode, cin, cout, arith.conv)
             if ctx.needs_input_grad[1]:
                 gw = _weight_grad(x, dx_raw, mode, cin, cout, arith.wgrad, arith.sink)
-        return gx, gw, dgamma, dbeta, g_res, None, None, None, None
+        return gx, gw, dgamma, dbeta, g_res, None, None, None, None, None
 
 
-def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None):
+class DeferredAffine:
+    """Filled by conv_bn(..., defer=this) in train mode: the returned tensor is the RAW convolution output and
+    its one consumer must take relu(raw * scale + shift) (conv_logits(..., affine=this))."""
+
+    def __init__(self):
+        self.scale = self.shift = None
+
+    @property
+    def pending(self):
+        return self.scale is not None
+
+
+def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None, defer=None):
     arith = _arith(arith)
     if isinstance(x, LazyCostVolume):  # inference: BN folded, operand synthesised in-kernel
         if torch.is_grad_enabled() or bn.training:
@@ -352,14 +370,14 @@ def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None):
             return _run_gather(x, packed, mode, cin, cout, arith.conv, scale, shift,
                                _chk(residual, "residual") if residual is not None else None, relu)
     w = arith.sink.weight(conv.weight) if arith.sink is not None else conv.weight
-    return _ConvBN.apply(x, w, bn.weight, bn.bias, residual, bn, mode, relu, arith)
+    return _ConvBN.apply(x, w, bn.weight, bn.bias, residual, bn, mode, relu, arith, defer)
 
 
 class _ConvLogits(torch.autograd.Function):
     """logits = Conv3d(32 -> 1)(x) + addend  (classifN[2] and the running cost sums)."""
 
     @staticmethod
-    def forward(ctx, x, weight, addend, sink):
+    def forward(ctx, x, weight, addend, sink, scale=None, shift=None):
         ctx.sink = sink if (sink is not None and sink.owns(weight)) else None
         x = _chk(x, "x")
         w = _chk(weight.detach().contiguous(), "weight")
@@ -371,14 +389,14 @@ class _ConvLogits(torch.autograd.Function):
         out = x.new_empty(b, d, h, wd)
         with torch.cuda.device(x.device):
             with profiler.scope("conv3d_c1_fwd", bytes=4.0 * (x.numel() + out.numel()), bound="hbm"):
-                _call("az_conv3d_c1_fwd", _p(out), _p(x), _p(w), _p(addend), b, d, h, wd, _stream())
-        ctx.save_for_backward(x, w)
+                _call("az_conv3d_c1_fwd", _p(out), _p(x), _p(w), _p(addend), _p(scale), _p(shift), b, d, h, wd, _stream())
+        ctx.save_for_backward(x, w, scale, shift)
         ctx.has_add = addend is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        x, w, scale, shift = ctx.saved_tensors
         g = _chk(g.contiguous(), "grad_logits")
         b, d, h, wd, _ = _dims(x)
         gx = gw = None
@@ -391,12 +409,14 @@ class _ConvLogits(torch.autograd.Function):
                 gw = torch.empty_like(w)
                 with overlap.scope(ctx.sink, x, g), \
                         profiler.scope("conv3d_c1_wgrad", bytes=4.0 * (x.numel() + g.numel()), bound="hbm"):
-                    _call("az_conv3d_c1_wgrad", _p(gw), _p(x), _p(g), b, d, h, wd, _stream())
-        return gx, gw, (g if ctx.has_add else None), None
+                    _call("az_conv3d_c1_wgrad", _p(gw), _p(x), _p(g), _p(scale), _p(shift), b, d, h, wd, _stream())
+        return gx, gw, (g if ctx.has_add else None), None, None, None
 
 
-def conv_logits(x, conv, addend=None, sink=None):
-    return _ConvLogits.apply(x, sink.weight(conv.weight) if sink is not None else conv.weight, addend, sink)
+def conv_logits(x, conv, addend=None, sink=None, affine=None):
+    """affine: a DeferredAffine filled by the conv_bn that produced x (x is then its raw output)."""
+    sc, sh = (affine.scale, affine.shift) if (affine is not None and affine.pending) else (None, None)
+    return _ConvLogits.apply(x, sink.weight(conv.weight) if sink is not None else conv.weight, addend, sink, sc, sh)
 
 
 class _AddRelu(torch.autograd.Function):

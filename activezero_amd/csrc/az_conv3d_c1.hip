@@ -46,7 +46,8 @@ __device__ __forceinline__ float c1_dpp_add(float v) {
 }
 __global__ void __launch_bounds__(256)
 c1_fwd_kernel(float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
-              const float *__restrict__ addend, int D, int H, int W, int tiles_x, int dseg) {
+              const float *__restrict__ addend, const float *__restrict__ in_scale,
+              const float *__restrict__ in_shift, int D, int H, int W, int tiles_x, int dseg) {
     constexpr int SX = C1F_TW + 2, SY = C1F_TH + 2;
     __shared__ __attribute__((aligned(16))) float slab[SY * SX * C1_VS];
     const int tx0 = (blockIdx.x % tiles_x) * C1F_TW, ty0 = (blockIdx.x / tiles_x) * C1F_TH;
@@ -64,16 +65,29 @@ c1_fwd_kernel(float *__restrict__ out, const float *__restrict__ in, const float
     // block has finished reading plane id
     constexpr int NQ = SY * SX * 8, NLD = (NQ + 255) / 256;
     float4 pre[NLD];
+    // in_scale / in_shift given: the operand is relu(in * scale + shift), the train-mode BatchNorm + ReLU of the
+    // layer in front (psmnet_3.py:103-117 classifN[0..1]) applied HERE instead of by a pass of its own over
+    // the 802 MB tensor; the zero padding stays zero.  A thread's channel quad is fixed (256 % 8 == 0).
+    const bool affine = in_scale != nullptr;
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (affine) {
+        isc = reinterpret_cast<const float4 *>(in_scale)[threadIdx.x & 7];
+        ish = reinterpret_cast<const float4 *>(in_shift)[threadIdx.x & 7];
+    }
+    unsigned okbits = 0;
     auto issue = [&](int id) {
+        okbits = 0;
 #pragma unroll
         for (int it = 0; it < NLD; ++it) {
             const int q = threadIdx.x + 256 * it, v = q >> 3, part = q & 7;
             const int sy = v / SX, sx = v - sy * SX;
             const int ih = ty0 - 1 + sy, iw = tx0 - 1 + sx;
             pre[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < NQ && id >= 0 && id < D && ih >= 0 && ih < H && iw >= 0 && iw < W)
+            if (q < NQ && id >= 0 && id < D && ih >= 0 && ih < H && iw >= 0 && iw < W) {
                 pre[it] = *reinterpret_cast<const float4 *>(
                     in + ((((size_t)b * D + id) * H + ih) * W + iw) * 32 + part * 4);
+                okbits |= 1u << it;
+            }
         }
     };
     issue(d0 - 1);
@@ -83,7 +97,12 @@ c1_fwd_kernel(float *__restrict__ out, const float *__restrict__ in, const float
 #pragma unroll
             for (int it = 0; it < NLD; ++it) {
                 const int q = threadIdx.x + 256 * it;
-                if (q < NQ) *reinterpret_cast<float4 *>(&slab[(q >> 3) * C1_VS + (q & 7) * 4]) = pre[it];
+                float4 v = pre[it];
+                if (affine && ((okbits >> it) & 1u)) {  // (fmaf + max exactly as az_bn3d_apply rounds)
+                    v.x = fmaxf(fmaf(v.x, isc.x, ish.x), 0.f); v.y = fmaxf(fmaf(v.y, isc.y, ish.y), 0.f);
+                    v.z = fmaxf(fmaf(v.z, isc.z, ish.z), 0.f); v.w = fmaxf(fmaf(v.w, isc.w, ish.w), 0.f);
+                }
+                if (q < NQ) *reinterpret_cast<float4 *>(&slab[(q >> 3) * C1_VS + (q & 7) * 4]) = v;
             }
             __syncthreads();
         }
@@ -216,13 +235,20 @@ c1_dgrad_kernel(float *__restrict__ gin, const float *__restrict__ gout,
 
 __global__ void __launch_bounds__(256)
 c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
-                const float *__restrict__ gout, int D, int H, int W, int tiles_x, int tiles_y,
+                const float *__restrict__ gout, const float *__restrict__ in_scale,
+                const float *__restrict__ in_shift, int D, int H, int W, int tiles_x, int tiles_y,
                 long long ntiles) {
     constexpr int SY = C1_TH + 2;
     __shared__ __attribute__((aligned(16))) float gt[3 * SY * C1_GP];
     __shared__ float red[864];
     for (int q = threadIdx.x; q < 864; q += 256) red[q] = 0.f;
     const int quad = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const bool affine = in_scale != nullptr;
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (affine) {
+        isc = reinterpret_cast<const float4 *>(in_scale)[quad];
+        ish = reinterpret_cast<const float4 *>(in_shift)[quad];
+    }
     c1_f2 a01[27], a23[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) { a01[t] = c1_f2{0.f, 0.f}; a23[t] = c1_f2{0.f, 0.f}; }
@@ -246,7 +272,13 @@ c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ih < H && tx0 + lx0 + j < W) x = *reinterpret_cast<const float4 *>(src + j * 32);
+                if (ih < H && tx0 + lx0 + j < W) {
+                    x = *reinterpret_cast<const float4 *>(src + j * 32);
+                    if (affine) {  // the operand is relu(in * scale + shift), see c1_fwd_kernel
+                        x.x = fmaxf(fmaf(x.x, isc.x, ish.x), 0.f); x.y = fmaxf(fmaf(x.y, isc.y, ish.y), 0.f);
+                        x.z = fmaxf(fmaf(x.z, isc.z, ish.z), 0.f); x.w = fmaxf(fmaf(x.w, isc.w, ish.w), 0.f);
+                    }
+                }
                 x01[j] = c1_f2{x.x, x.y}; x23[j] = c1_f2{x.z, x.w};
             }
 #pragma unroll
@@ -290,8 +322,10 @@ static int c1_check(int B, int D, int H, int W) {
 }
 
 extern "C" int az_conv3d_c1_fwd(float *logits, const float *in, const float *w,
-                                const float *addend, int B, int D, int H, int W, void *stream) {
+                                const float *addend, const float *in_scale, const float *in_shift, int B, int D,
+                                int H, int W, void *stream) {
     AZ_REQUIRE_PTR(logits); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(w);
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return AZ_EINVAL;
     if (int e = c1_check(B, D, H, W)) return e;
     const int tiles_x = (W + C1F_TW - 1) / C1F_TW, tiles_y = (H + C1F_TH - 1) / C1F_TH;
     // depth segment per block: every segment stages 2 halo planes, and the grid should fill a whole
@@ -305,7 +339,7 @@ extern "C" int az_conv3d_c1_fwd(float *logits, const float *in, const float *w,
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = dseg; }
     }
     hipLaunchKernelGGL(c1_fwd_kernel, dim3(tiles_x * tiles_y, (D + best - 1) / best, B), dim3(256), 0,
-                       az_stream(stream), logits, in, w, addend, D, H, W, tiles_x, best);
+                       az_stream(stream), logits, in, w, addend, in_scale, in_shift, D, H, W, tiles_x, best);
     return az_launch_status();
 }
 
@@ -320,8 +354,10 @@ extern "C" int az_conv3d_c1_dgrad(float *grad_in, const float *grad_logits, cons
 }
 
 extern "C" int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *grad_logits,
-                                  int B, int D, int H, int W, void *stream) {
+                                  const float *in_scale, const float *in_shift, int B, int D, int H, int W,
+                                  void *stream) {
     AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(grad_logits);
+    if ((in_scale == nullptr) != (in_shift == nullptr)) return AZ_EINVAL;
     if (int e = c1_check(B, D, H, W)) return e;
     if (hipMemsetAsync(grad_w, 0, 864 * sizeof(float), az_stream(stream)) != hipSuccess)
         return AZ_ELAUNCH;
@@ -329,6 +365,6 @@ extern "C" int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *g
     const long long ntiles = (long long)B * D * tiles_y * tiles_x;
     const unsigned grid = (unsigned)(ntiles < 2048 ? ntiles : 2048);
     hipLaunchKernelGGL(c1_wgrad_kernel, dim3(grid), dim3(256), 0, az_stream(stream), grad_w, in,
-                       grad_logits, D, H, W, tiles_x, tiles_y, ntiles);
+                       grad_logits, in_scale, in_shift, D, H, W, tiles_x, tiles_y, ntiles);
     return az_launch_status();
 }

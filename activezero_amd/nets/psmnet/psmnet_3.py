@@ -125,7 +125,11 @@ class PSMNet(nn.Module):
         out3, _pre3, _post3 = self.dres4(out2, pre1, post2, out_add=c0d, arith=a)
 
         def head(cls, v, running):
-            return agg3d.conv_logits(agg3d.conv_bn(v, cls[0], relu=True, arith=a), cls[2], running, arith=a)
+            # classifN: convbn_3d + ReLU, then Conv3d(32 -> 1) (psmnet_3.py:103-117).  In train mode the BatchNorm
+            # apply + ReLU is not a pass of its own: the 32 -> 1 kernels take it while they stage their input
+            aff = conv3d.DeferredAffine() if (torch.is_grad_enabled() and cls[0][1].training) else None
+            mid = agg3d.conv_bn(v, cls[0], relu=True, arith=a, defer=aff)
+            return agg3d.conv_logits(mid, cls[2], running, arith=a, affine=aff)
 
         cost1 = head(self.classif1, out1, None)
         cost2 = head(self.classif2, out2, cost1)

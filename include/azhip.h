@@ -165,13 +165,17 @@ int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
 
 /* 32 -> 1 classifier conv (psmnet_3.py:103-117) with the fused running sum
  * cost_k = classif_k(out_k) + cost_{k-1} (psmnet_3.py:177-179): logits [B,D,H,W] =
- * conv(in [B,D,H,W,32], w [1,32,3,3,3]) + addend (may be NULL). */
+ * conv(in [B,D,H,W,32], w [1,32,3,3,3]) + addend (may be NULL).
+ * in_scale / in_shift ([32] each, both or neither): the operand is relu(in * scale + shift) -- the train-mode
+ * BatchNorm + ReLU of classifN[0..1] in front of this layer, applied while the input is staged instead of by a
+ * pass of its own over the tensor (`in` is then the RAW convolution output); the weight gradient takes the
+ * same pair. */
 int az_conv3d_c1_fwd(float *logits, const float *in, const float *w, const float *addend,
-                     int B, int D, int H, int W, void *stream);
+                     const float *in_scale, const float *in_shift, int B, int D, int H, int W, void *stream);
 int az_conv3d_c1_dgrad(float *grad_in, const float *grad_logits, const float *w, int B, int D,
                        int H, int W, void *stream);
-int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *grad_logits, int B, int D,
-                       int H, int W, void *stream);
+int az_conv3d_c1_wgrad(float *grad_w, const float *in, const float *grad_logits, const float *in_scale,
+                       const float *in_shift, int B, int D, int H, int W, void *stream);
 
 /* ---- BatchNorm3d pieces around K4/K5 (psmnet_submodule_3.py:55) --------------------
  * finalize: merge the conv partials (Chan, fp64) -> mean, invstd, scale = gamma*invstd,

@@ -32,8 +32,8 @@ wc = torch.randn(1, C, 3, 3, 3, device=dev) * 0.05
 go = torch.randn(B, D, H, W, device=dev)
 out = torch.empty(B, D, H, W, device=dev); gx = torch.empty_like(x); gwc = torch.empty_like(wc)
 mb = 4.0 * (x.numel() + out.numel()) / 1e6
-for name, fn in (("c1 fwd", lambda: _call("az_conv3d_c1_fwd", _p(out), _p(x), _p(wc), None, B, D, H, W, _stream())),
+for name, fn in (("c1 fwd", lambda: _call("az_conv3d_c1_fwd", _p(out), _p(x), _p(wc), None, None, None, B, D, H, W, _stream())),
                  ("c1 dgrad", lambda: _call("az_conv3d_c1_dgrad", _p(gx), _p(go), _p(wc), B, D, H, W, _stream())),
-                 ("c1 wgrad", lambda: _call("az_conv3d_c1_wgrad", _p(gwc), _p(x), _p(go), B, D, H, W, _stream()))):
+                 ("c1 wgrad", lambda: _call("az_conv3d_c1_wgrad", _p(gwc), _p(x), _p(go), None, None, B, D, H, W, _stream()))):
     ms = timeit(fn)
     print(f"V0 {name:10s} {ms:7.3f} ms  {mb / ms / 1e3:6.2f} TB/s of {mb:.0f} MB")
