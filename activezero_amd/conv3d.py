@@ -25,6 +25,19 @@ from .ops import _call, _chk, _p, _stream
 CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
 FP32, BF16X6 = 0, 1
 _PREC = {"fp32": FP32, "bf16x6": BF16X6}
+# include/azhip.h precision 2: the bf16x6 arithmetic on the depth-rolling 16x16x32 kernel (az_conv3d_roll.hip),
+# which reads its own packed-weight layout.  Not an arithmetic a caller chooses: _layout() routes the stride-1
+# layers with 32 output channels (the V0 layers and their input gradients) there.  AZ_CONV_ROLL=0 (read once)
+# keeps them on az_conv3d_m128.hip for A/B runs.
+BF16X6_R16 = 2
+_ROLL = os.environ.get("AZ_CONV_ROLL", "1") != "0"
+
+
+def _layout(precision, mode, op_cout):
+    """precision code the C ABI is called with (packing and launch must agree)"""
+    if precision == BF16X6 and mode == CONV_S1 and op_cout == 32 and _ROLL:
+        return BF16X6_R16
+    return precision
 
 
 class Arith(collections.namedtuple("Arith", "conv wgrad sink", defaults=(None,))):
@@ -145,11 +158,13 @@ def eval_affine(bn, like, cache=False):
     return scale, shift
 
 
-def _pack_forward(weight, mode, precision, cache=False):
+def _pack_forward(weight, mode, precision, cache=False, lazy=False):
     if mode == DECONV_S2:  # [Cin, Cout, 27]
         cin, cout = weight.shape[0], weight.shape[1]
         return _pack(weight, cin, cout, 27, cout * 27, False, precision, cache), cin, cout
     cout, cin = weight.shape[0], weight.shape[1]
+    if not lazy:  # (the fused cost-volume operand, src = 1, stays on the 32x32x16 kernels)
+        precision = _layout(precision, mode, cout)
     return _pack(weight, cin, cout, cin * 27, 27, False, precision, cache), cin, cout
 
 
@@ -190,6 +205,7 @@ def _run_gather(x, packed, mode, cin, cout, precision, scale=None, shift=None, r
         return out
     b, d, h, w, c = _dims(x)
     assert c == cin, (c, cin)
+    precision = _layout(precision, mode, cout)  # `packed` was made by _pack_forward / _input_grad: same rule
     if mode == CONV_S2 and ((d % 2 and d != 1) or h % 2 or w % 2):
         raise RuntimeError("stride-2 layers need even D/H/W (as PSMNet's hourglass does; D = 1: a 2-D layer)")
     do, ho, wo = _out_dims(mode, d, h, w)
@@ -227,7 +243,7 @@ def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
 def _input_grad(dy, weight, mode, cin, cout, precision):
     """gradient of the layer's input from the gradient dy of its (raw) convolution output"""
     if mode == CONV_S1:    # flipped taps, channels swapped
-        pk = _pack(weight, cout, cin, 27, cin * 27, True, precision)
+        pk = _pack(weight, cout, cin, 27, cin * 27, True, _layout(precision, CONV_S1, cin))
         return _run_gather(dy, pk, CONV_S1, cout, cin, precision, tag="dgrad")
     if mode == CONV_S2:    # transposed conv of dy with W[co][ci][k]
         pk = _pack(weight, cout, cin, 27, cin * 27, False, precision)
@@ -357,7 +373,7 @@ def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None, defer=None
         if torch.is_grad_enabled() or bn.training:
             raise RuntimeError("LazyCostVolume is an inference-only operand")
         with torch.cuda.device(x.fl.device):
-            packed, cin, cout = _pack_forward(conv.weight, mode, arith.conv, cache=True)
+            packed, cin, cout = _pack_forward(conv.weight, mode, arith.conv, cache=True, lazy=True)
             scale, shift = eval_affine(bn, x.fl, cache=True)
             return _run_gather(x, packed, mode, cin, cout, arith.conv, scale, shift, residual, relu)
     training = bn.training or not bn.track_running_stats

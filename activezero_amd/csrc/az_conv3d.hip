@@ -576,6 +576,10 @@ static int dispatch_mode(const ConvArgs &a, int mode, int precision, int cin, in
         if (mode == 1) return dispatch_channels<1, EPI, 1>(a, cin, cout, src, s);
         return dispatch_channels<2, EPI, 1>(a, cin, cout, src, s);
     }
+    if (precision == 2) {  // bf16x6 arithmetic, weights packed for the depth-rolling 16x16x32 kernel
+        if (mode != 0 || cout != 32 || src != 0) return AZ_EUNSUPPORTED;
+        return az_conv3d_roll_launch(a, cin, EPI, s);
+    }
     return AZ_EINVAL;
 }
 
@@ -610,7 +614,8 @@ extern "C" long long az_conv3d_num_tiles(int mode, int B, int Di, int Hi, int Wi
 }
 
 extern "C" long long az_conv3d_packed_floats(int cin, int cout, int precision) {
-    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || precision < 0 || precision > 1) return AZ_EINVAL;
+    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || precision < 0 || precision > 2) return AZ_EINVAL;
+    if (precision == 2 && cout != 32) return AZ_EINVAL;
     return precision == 0 ? 27LL * cin * cout : 27LL * cin * cout * 3 / 2;
 }
 
@@ -628,6 +633,8 @@ extern "C" int az_conv3d_pack_weights(float *packed, const float *w, int cin, in
         hipLaunchKernelGGL(conv3d_pack_x6_kernel, dim3((total + 255) / 256), dim3(256), 0,
                            az_stream(stream), reinterpret_cast<unsigned short *>(packed), w, cin, cout,
                            stride_out, stride_in, flip, total);
+    } else if (precision == 2) {
+        return az_conv3d_pack_r16(packed, w, cin, cout, stride_out, stride_in, flip, az_stream(stream));
     } else {
         return AZ_EINVAL;
     }

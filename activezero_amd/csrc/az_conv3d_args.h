@@ -16,10 +16,17 @@ struct ConvArgs {
     int Dt, tiles_y, tiles_x;  // index-space extents (MODE 2: coarse dims / phase tiles)
     int relu;
     int map_mode;  // block->tile map: 0 linear, 1 XCD-chunked linear, 2 XCD-chunked + banded
+    int nseg, seg_len;  // az_conv3d_roll.hip: depth segments per patch, output depths per segment
 };
 
 // bf16x6, stride-1, 32 output channels, 8x16-voxel tile per wave (az_conv3d_m128.hip)
 int az_conv3d_m128_launch(const ConvArgs &a, int cin, int epi, int src, hipStream_t s);
+
+// bf16x6 on the 16x16x32 MFMA, stride 1, 32 output channels, depth-rolling workgroups (az_conv3d_roll.hip);
+// weights in that kernel's own packed layout (az_conv3d_pack_r16 = az_conv3d_pack_weights precision 2)
+int az_conv3d_roll_launch(const ConvArgs &a, int cin, int epi, hipStream_t s);
+int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long long stride_out, long long stride_in,
+                       int flip, hipStream_t s);
 
 // bf16x6, stride-2 transposed, 32 output channels: one workgroup owns all 8 output-parity phases of a coarse
 // patch (az_conv3d_t2.hip)

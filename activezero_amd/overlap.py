@@ -25,6 +25,18 @@ convention:
     back-propagated together (each pass has its own gates, tail and join).
   * Operands of side-stream kernels are kept referenced by the sink until the join, so the caching allocator
     cannot hand their memory to later main-stream work while the side stream still reads it.
+Backstops, so that the scheme cannot silently corrupt memory outside the case it was designed around:
+  * the first kernel a pass sends to the side stream registers `sink.join` as an end-of-backward callback of the
+    autograd engine: the join also happens when the engine never reaches `_Tail` (`backward(inputs=[...])` or
+    `autograd.grad` on a subset that prunes the first convolution / the gates: the convolution nodes still launch
+    their weight-gradient kernels because `needs_input_grad[1]` is set, but their results are dropped).  `join` is
+    idempotent;
+  * a gated weight that is requested twice in one pass (a module whose forward runs a convolution twice, e.g. the
+    unequal-shape fallback of `forward_pair`) would give its gate two REAL gradient edges, which the engine sums
+    as soon as the second arrives -- before the join.  The sink then disarms itself: every weight gradient of that
+    pass stays in order;
+  * `begin()` first makes the main stream wait for the side stream, so that a pass that died part-way through its
+    backward (exception: no callback runs) cannot leak un-joined work into the next one.
 There is no module-level state: a Sink belongs to one forward/backward pass of one module replica (the side
 stream itself is cached per device).  `begin()` returns None -- plain in-order weight gradients -- whenever the
 construction above does not apply (no grad mode, a frozen convolution weight, CPU tensors).
@@ -62,21 +74,43 @@ class Sink:
         self.keep = []
         self.armed = False   # set by the first convolution when it takes the token: without that edge in the
         self.joined = False  # graph nothing would ever join the side stream, so nothing is sent there
+        self.uses = {}       # id(weight) -> times requested in this pass
+        self.disarmed = False
+        self.callback_set = False
 
     def weight(self, w):
         """The tensor a layer of this pass must use for parameter w."""
         hit = self.gated.get(id(w))
-        return hit[1] if hit is not None else w
+        if hit is None:
+            return w
+        n = self.uses.get(id(w), 0) + 1
+        self.uses[id(w)] = n
+        if n > 1:  # two gradient edges into one gate: the engine would add them before the join
+            self.disarmed = True
+        return hit[1]
+
+    @property
+    def live(self):
+        """weight-gradient kernels of this pass may go to the side stream"""
+        return self.armed and not self.joined and not self.disarmed
 
     def owns(self, t):
         """True when t is one of this pass's gated weights: only their gradients may be produced late."""
         return id(t) in self.owned
 
     def join(self):
+        if self.joined:
+            return
         torch.cuda.current_stream().wait_stream(self.stream)
         self.keep.clear()
         self.joined = True
         profiler.joined()
+
+    def ensure_callback(self):
+        """called from inside a backward pass, before the first side-stream launch"""
+        if not self.callback_set:
+            self.callback_set = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.join)
 
 
 class _Gate(torch.autograd.Function):
@@ -119,6 +153,7 @@ def begin(module, like):
     if not weights or not all(w.requires_grad and w.is_leaf for w in weights):
         return None  # (replicas of nn.DataParallel hold non-leaf copies: their gradients flow on through autograd)
     sink = Sink(like.device)
+    torch.cuda.current_stream(like.device).wait_stream(sink.stream)  # nothing un-joined survives into this pass
     for w in weights:
         gw = _Gate.apply(w)
         sink.gated[id(w)] = (w, gw)
@@ -138,7 +173,8 @@ class scope:
 
     def __enter__(self):
         sink = self.sink
-        if sink is not None and sink.armed and not sink.joined:
+        if sink is not None and sink.live:
+            sink.ensure_callback()
             sink.keep.extend(t for t in self.operands if t is not None)
             sink.stream.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(sink.stream)

@@ -136,7 +136,12 @@ int az_lcn(float *normed, float *stdv, const float *img, int B, int H, int W, in
 /* precision: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chain);
  *            1 = "bf16x6": both operands are split exactly into three bf16 parts and the
  *                six significant partial products run on v_mfma_f32_32x32x16_bf16 with fp32
- *                accumulation (error ~1e-7 relative, like fp32; 2.7x the fp32 MFMA rate).
+ *                accumulation (error ~1e-7 relative, like fp32; 2.7x the fp32 MFMA rate);
+ *            2 = the same bf16x6 arithmetic on v_mfma_f32_16x16x32_bf16 (one accumulator rounding
+ *                per 32-deep block) with the weights packed [tap][cin/32][cout/16][3][64][8 bf16]
+ *                for the depth-rolling kernel: mode 0, cout = 32, src = 0 only (the V0 layers of
+ *                psmnet_3.py:87-117 and their input gradients); anything else returns
+ *                AZ_EUNSUPPORTED.  A buffer packed with precision p must be used with precision p.
  * The packed buffer holds az_conv3d_packed_floats(cin, cout, precision) floats. */
 long long az_conv3d_packed_floats(int cin, int cout, int precision);
 int az_conv3d_pack_weights(float *packed, const float *w, int cin, int cout,

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from activezero_amd import overlap  # noqa: E402
+from activezero_amd import conv3d, overlap  # noqa: E402
 from activezero_amd.nets.psmnet import psmnet as psm6  # noqa: E402
 from activezero_amd.nets.psmnet import psmnet_3 as psm3  # noqa: E402
 from oracle import psmnet_oracle as po  # noqa: E402
@@ -110,3 +110,50 @@ def test_sink_is_armed_joined_and_released(monkeypatch):
     out = model(il, ir)
     assert seen == [None]
     sum(o.sum() for o in out).backward()
+
+
+def test_partial_backward_still_joins_the_side_stream():
+    """loss.backward(inputs=[BatchNorm parameters]): the engine prunes the gates, _Tail and the first
+    convolution's weight path, but the convolution nodes still launch their weight-gradient kernels on the side
+    stream (needs_input_grad[1] is set).  The end-of-backward callback must join them (overlap.py, backstops)."""
+    seen = []
+    real = overlap.begin
+    try:
+        overlap.begin = lambda m, like: seen.append(real(m, like)) or seen[-1]
+        model = load_procedural(psm3.PSMNet(32), "g4.").to(DEV).train()
+        il, ir = (seeded((1, 3, 256, 256), 900 + i, -2.0, 2.0).to(DEV) for i in range(2))
+        out = model(il, ir)
+    finally:
+        overlap.begin = real
+    sink = seen[0]
+    bn_params = [p for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for p in m.parameters()]
+    sum(o.sum() for o in out).backward(inputs=bn_params)
+    assert sink.joined and not sink.keep
+    torch.cuda.current_stream().synchronize()
+    assert overlap.side_stream(DEV).query()
+    ref = load_procedural(psm3.PSMNet(32), "g4.").to(DEV).train().set_weight_grad_overlap(False)
+    sum(o.sum() for o in ref(il, ir)).backward()
+    want = [p for m in ref.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for p in m.parameters()]
+    for a, b in zip(bn_params, want):
+        assert torch.allclose(a.grad, b.grad, rtol=2e-3, atol=2e-3 * float(b.grad.abs().max()) + 1e-7)
+    assert all(m.weight.grad is None for m in model.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d)))
+
+
+def test_extractor_called_twice_with_one_sink_stays_in_order():
+    """forward_pair's unequal-shape fallback runs the extractor twice with the same sink: every gated weight is
+    requested twice, the sink disarms, and the gradients equal the in-order ones."""
+    from activezero_amd.nets.psmnet import psmnet_submodule_3 as sub
+    torch.manual_seed(5)
+    fe = sub.FeatureExtraction().to(DEV).train()
+    ref = copy.deepcopy(fe)
+    a, b = torch.randn(1, 3, 128, 160, device=DEV), torch.randn(1, 3, 128, 192, device=DEV)  # unequal widths
+    sink = overlap.begin(fe, a)
+    arith = conv3d.DEFAULT_ARITH._replace(sink=sink)
+    fa, fb = fe.forward_pair(a, b, arith)
+    assert sink.disarmed and not sink.live
+    (fa.sum() + fb.sum()).backward()
+    ra, rb = ref.forward_pair(a, b, conv3d.DEFAULT_ARITH)
+    (ra.sum() + rb.sum()).backward()
+    torch.cuda.synchronize()
+    for (k, p), (_, q) in zip(fe.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-3, atol=1e-3 * float(q.grad.abs().max()) + 1e-8), k

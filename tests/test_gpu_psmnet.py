@@ -247,3 +247,68 @@ def test_full_model_d192_error_split(golden, arith, capsys):
         #     triangle bound; 99.9 % of the pixels are within the north-star 1e-3 of ref32 anyway
         assert e_hr32.max() <= e_hr64.max() + e_rr.max() + 1e-6, line
         assert np.quantile(e_hr32, 0.999) <= 1e-3, line
+        # (d) the measured distance to the fp32 reference itself, pinned so that a regression shows: the
+        #     literal 1e-3 px bar is MISSED on the eval outputs at this disparity range (measured 1.11e-3 ..
+        #     1.33e-3 px max over both arithmetic modes and both sizes) and met on the
+        #     train-mode heads (<= 5.9e-4 px), which are what the headline workload computes
+        assert e_hr32.max() <= (1.4e-3 if "eval" in k else 7e-4), line
+
+
+# ---------------------------------------------------------------------------------------------------
+# configs[1] at full size: 540->544x960, D = 192, TRAIN mode, psmnet_disp loss, backward (G13)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("overlap", [True, False])
+def test_full_size_train_step_matches_reference_golden(golden, overlap, capsys):
+    """BASELINE.json configs[1] for one pair through the imported reference (tools/make_goldens.py g13:
+    nets/psmnet/psmnet_3.py:144-220 in train mode, utils/losses.py:7-15, backward) in fp32 and fp64.
+    Predictions: every sampled pixel within 1e-3 px of ref32 outright (the train-mode heads are what the
+    headline workload computes) and a fixed ceiling on the measured maximum.  Loss: 1e-5 relative.
+    Gradients: e_ref = |g_ref32 - g_ref64| / |g_ref64| says how far a valid fp32 evaluation of that gradient
+    sits from the exact one (3e-5 for the classifier convs, 4-6e-3 for the first layers, whose gradients pass
+    ~85 train-mode BatchNorms); the HIP path must be within max(3 e_ref, 2e-4) of ref64 and of ref32 -- numbers
+    per tensor, not one loose bound.  Both backward schedules (weight gradients on the side stream / in order)."""
+    from activezero_amd.utils.disp_losses import psmnet_disp
+    g = golden("g13_psmnet3_train_d192")
+    md, st = int(g["maxdisp"]), int(g["pred_stride"])
+    model = load_procedural(psm3.PSMNet(md), "g11.").to(DEV).train()
+    if not overlap:
+        model.set_weight_grad_overlap(False)
+    il, ir = (torch.nn.functional.pad(seeded((1, 3, 540, 960), 1103 + i, -2.0, 2.0), (0, 0, 4, 0)).to(DEV) for i in range(2))
+    gt = seeded((1, 1, 544, 960), 1301, -12.0, 215.0).to(DEV)
+    mask = (gt < md) * (gt > 0)
+    assert int(mask.sum()) == int(g["n_mask"])
+    preds = model(il, ir)
+    loss = psmnet_disp(preds, gt, mask)
+    loss.backward()
+    torch.cuda.synchronize()
+    report = []
+    for p, k in zip(preds, ("pred3_", "pred2_", "pred1_")):
+        got = p.detach()[..., ::st, ::st].cpu().numpy()
+        e32, e64, err = _err(got, g[k + "32"]), _err(got, g[k + "64"]), _err(g[k + "32"], g[k + "64"])
+        report.append(f"{k} max|hip-ref32| {e32.max():.2e} max|hip-ref64| {e64.max():.2e} max|ref32-ref64| {err.max():.2e}")
+        assert e32.max() <= 7e-4 and e64.max() <= 7e-4, report[-1]
+        assert e64.mean() <= 1.1 * err.mean() + 1e-6, report[-1]
+    l32, l64 = float(g["loss32"]), float(g["loss64"])
+    report.append(f"loss hip {loss.item():.7f} ref32 {l32:.7f} ref64 {l64:.7f}")
+    assert abs(loss.item() - l64) <= 1e-5 * l64, report[-1]
+    params = dict(model.named_parameters())
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+    names = [k[5:] for k in g.files if k.startswith("g32::")]
+    assert len(names) == 14
+    for name in names:
+        r32, r64 = g["g32::" + name], g["g64::" + name]
+        full = params[name].grad
+        got = full.detach().cpu().numpy()
+        if got.shape != r32.shape:
+            got = got[tuple(slice(0, n) for n in r32.shape)]
+        e_ref, e_h64, e_h32 = rel(r32, r64), rel(got, r64), rel(got, r32)
+        tol = max(3.0 * e_ref, 2e-4)
+        report.append(f"grad {name:55s} hip-ref64 {e_h64:.2e} hip-ref32 {e_h32:.2e} ref32-ref64 {e_ref:.2e} tol {tol:.1e}")
+        assert e_h64 <= tol and e_h32 <= tol, report[-1]
+        n_ref = float(g["gn64::" + name])  # L2 norm of the WHOLE gradient tensor
+        assert abs(float(full.double().norm()) - n_ref) <= max(3.0 * e_ref, 2e-4) * n_ref, (name, float(full.double().norm()), n_ref)
+    bufs = dict(model.named_buffers())
+    for name in ("dres0.0.1.running_var", "dres4.conv6.1.running_mean"):
+        close(bufs[name], g["buf32::" + name], 1e-4, 1e-6)
+    with capsys.disabled():
+        print("\nG13 overlap=%s\n" % overlap + "\n".join(report))

@@ -1,8 +1,11 @@
 """the RAFT-Stereo ConvGRU update (reference nets/raft/update.py:19-41) on the
 plain-bf16 MFMA convolution with the gate arithmetic in its epilogue.
 
-There is no reference golden for this row (nets/raft/update.py imports opt_einsum and yacs, absent here, so the
-reference module cannot be executed; its 22 lines are restated below in torch).  Checked instead:
+Pinned by G12 (tests/golden/g12_convgru.npz, tools/make_goldens.py g12_convgru): the reference class itself,
+imported from nets/raft/update.py with inert stand-ins for the two absent packages its module imports but the
+class never touches, evaluated in fp32, fp64 and under CPU autocast(bfloat16) -- test_gru_matches_reference_golden
+and test_gru_autograd_matches_reference_golden below.  The 22 lines are also restated in torch here for the
+shape sweeps.  Checked besides:
   * the convolution kernel itself, bit-level: with operands that are exactly representable in bf16 and
     products that sum exactly in fp32, the result equals an fp64 convolution;
   * the GRU against an fp64 evaluation of the reference's formula, next to the error of the reference's own
@@ -118,6 +121,64 @@ def test_gru_autograd_path():
                                    rtol=1e-4, atol=2e-5)
         torch.testing.assert_close(getattr(mod, name).bias.grad.cpu(), getattr(ref, name).bias.grad,
                                    rtol=1e-4, atol=2e-5)
+
+
+def _g12_case(g, tag):
+    from tests._weights import load_procedural, seeded
+    from activezero_amd.nets.raft.gru import ConvGRU
+    meta = [int(v) for v in g[f"{tag}_meta"]]
+    hidden, h, w, b, sd, cs, ps = meta[:7]
+    cx = meta[7:]
+    mod = load_procedural(ConvGRU(hidden, sum(cx)), f"g12{tag}.").cuda()  # the reference's parameter names
+    hid = torch.tanh(seeded((b, hidden, h, w), sd, -2.0, 2.0))
+    ctx = [seeded((b, hidden, h, w), sd + 1 + i, -0.8, 0.8) for i in range(3)]
+    xs = [seeded((b, n, h, w), sd + 4 + i, -1.7, 1.7) for i, n in enumerate(cx)]
+    lat = lambda t: t[:, ::cs, ::ps, ::ps].detach().cpu().double().numpy()
+    return mod, hid, ctx, xs, lat, (b, hidden, h, w, sd)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gru_matches_reference_golden(golden, tag, capsys):
+    """ConvGRU.forward of the imported reference (update.py:19-41).  e64 = max |. - ref64|: the no-grad bf16
+    path must be no further from the exact result than the reference's own autocast(bfloat16) arithmetic is,
+    and within the spread that arithmetic has around its fp32 evaluation; one update and four chained ones."""
+    g = golden("g12_convgru")
+    mod, hid, ctx, xs, lat, _ = _g12_case(g, tag)
+    args = [c.cuda() for c in ctx] + [x.cuda() for x in xs]
+    with torch.no_grad():
+        got = mod(hid.cuda(), *args)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got_amp = mod(hid.cuda(), *args)
+        hh = hid.cuda()
+        for _ in range(4):
+            hh = mod(hh, *args)
+    assert torch.equal(got, got_amp)
+    r32, r64, ramp = g[f"{tag}_out32"].astype("f8"), g[f"{tag}_out64"], g[f"{tag}_outamp"].astype("f8")
+    e_hip64, e_amp64 = abs(lat(got) - r64).max(), abs(ramp - r64).max()
+    e_hip32, e_amp32 = abs(lat(got) - r32).max(), abs(ramp - r32).max()
+    e_it, e_it_ref = abs(lat(hh) - g[f"{tag}_iter4_64"]).max(), abs(g[f"{tag}_iter4_32"].astype("f8") - g[f"{tag}_iter4_64"]).max()
+    with capsys.disabled():
+        print(f"\nG12 {tag}: max|hip-ref64| {e_hip64:.2e} (reference autocast: {e_amp64:.2e})  max|hip-ref32| {e_hip32:.2e} "
+              f"(autocast-ref32 {e_amp32:.2e})  4 updates: {e_it:.2e} (ref32-ref64 {e_it_ref:.1e})")
+    assert e_hip64 <= e_amp64 and e_hip32 <= e_amp32, (e_hip64, e_amp64, e_hip32, e_amp32)
+    assert e_hip64 <= 1.5e-2 and e_it <= 4e-2, (e_hip64, e_it)
+
+
+def test_gru_autograd_matches_reference_golden(golden):
+    """the differentiable route (bf16x6 kernels, fp32-class) against the reference's fp32 values and gradients"""
+    from tests._weights import seeded
+    g = golden("g12_convgru")
+    mod, hid, ctx, xs, lat, (b, hidden, h, w, sd) = _g12_case(g, "c")
+    hg = hid.cuda().requires_grad_(True)
+    out = mod(hg, *[c.cuda() for c in ctx], *[x.cuda() for x in xs])
+    (out * seeded((b, hidden, h, w), sd + 9).cuda()).sum().backward()
+    T = torch.from_numpy
+    torch.testing.assert_close(out.detach().cpu(), T(g["c_out32"]), rtol=1e-4, atol=1e-5)
+    assert abs(lat(out) - g["c_out64"]).max() <= 1.5 * abs(g["c_out32"].astype("f8") - g["c_out64"]).max() + 1e-7
+    torch.testing.assert_close(hg.grad.cpu(), T(g["c_gh"]), rtol=1e-4, atol=2e-5)
+    for name in ("convz", "convr", "convq"):
+        torch.testing.assert_close(getattr(mod, name).weight.grad[:16, :32].cpu(), T(g[f"c_gw_{name}"]), rtol=1e-4, atol=5e-5)
+        torch.testing.assert_close(getattr(mod, name).bias.grad.cpu(), T(g[f"c_gb_{name}"]), rtol=1e-4, atol=5e-5)
 
 
 def test_gru_rejects_cpu_and_bad_channels():

@@ -204,3 +204,35 @@ def test_g10_loss_and_metrics(golden):
     obj = mo.compute_obj_err(gt[:1], zg[:1], dp[:1], focal[:1], base[:1], T(g["label"]), mask[:1])
     for i, o in enumerate(obj):
         close(o, g[f"obj{i}"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g12_convgru(golden, tag):
+    """oracle/raft_gru_oracle.py against the imported reference class (nets/raft/update.py:19-41)"""
+    from oracle.raft_gru_oracle import ConvGRUOracle
+    g = golden("g12_convgru")
+    meta = [int(v) for v in g[f"{tag}_meta"]]
+    hidden, h, w, b, sd, cs, ps = meta[:7]
+    cx = meta[7:]
+    mod = load_procedural(ConvGRUOracle(hidden, sum(cx)), f"g12{tag}.")
+    hid = torch.tanh(seeded((b, hidden, h, w), sd, -2.0, 2.0))
+    ctx = [seeded((b, hidden, h, w), sd + 1 + i, -0.8, 0.8) for i in range(3)]
+    xs = [seeded((b, n, h, w), sd + 4 + i, -1.7, 1.7) for i, n in enumerate(cx)]
+    lat = lambda t: t[:, ::cs, ::ps, ::ps]
+    hr = hid.clone().requires_grad_(tag == "c")
+    out = mod(hr, *ctx, *xs)
+    close(lat(out), g[f"{tag}_out32"], 1e-5, 1e-6)
+    with torch.no_grad():
+        hh = hid
+        for _ in range(4):
+            hh = mod(hh, *ctx, *xs)
+        close(lat(hh), g[f"{tag}_iter4_32"], 1e-5, 2e-6)
+        mod.double()
+        close(lat(mod(hid.double(), *[c.double() for c in ctx], *[x.double() for x in xs])), g[f"{tag}_out64"], 1e-12, 1e-13)
+        mod.float()
+    if tag == "c":
+        (out * seeded((b, hidden, h, w), sd + 9)).sum().backward()
+        close(hr.grad, g["c_gh"], 1e-4, 1e-6)
+        for name in ("convz", "convr", "convq"):
+            close(getattr(mod, name).weight.grad[:16, :32], g[f"c_gw_{name}"], 1e-4, 2e-5)
+            close(getattr(mod, name).bias.grad, g[f"c_gb_{name}"], 1e-4, 2e-5)

@@ -29,6 +29,7 @@ class _Sink(overlap.Sink):
     def __init__(self, log, tag=0):
         self.stream, self.token, self.keep, self.armed, self.joined = None, None, [object()], True, False
         self.gated, self.owned, self.log, self.tag = {}, set(), log, tag
+        self.uses, self.disarmed, self.callback_set = {}, False, False
 
     def join(self):
         self.log.append(("join", self.tag))
@@ -140,3 +141,39 @@ def test_begin_declines_without_grad_mode_cpu_tensors_or_with_frozen_weights():
         assert overlap.begin(m, _Cuda()) is None               # a frozen convolution weight
     finally:
         overlap.Sink.__init__ = real
+
+
+def test_weight_requested_twice_disarms_the_sink():
+    """A gate with two REAL gradient edges would be summed by the engine before the join: the sink then keeps
+    every weight gradient of the pass in order (overlap.py, backstops)."""
+    log = []
+    ws = [torch.nn.Parameter(torch.tensor([float(i + 2)])) for i in range(2)]
+    sink = _begin(ws, log)
+    assert sink.live
+    a = sink.weight(ws[0])
+    assert sink.live and sink.weight(ws[1]) is not ws[1]
+    assert sink.weight(ws[0]) is a        # the same alias again ...
+    assert sink.disarmed and not sink.live  # ... and nothing of this pass goes to the side stream any more
+    assert sink.weight(torch.ones(1)) is not None  # tensors that are not gated pass through untouched
+
+
+def test_join_is_idempotent_and_registered_once():
+    calls = []
+    sink = overlap.Sink.__new__(overlap.Sink)
+    sink.stream, sink.keep, sink.joined, sink.callback_set = None, [1], False, False
+
+    class _Eng:
+        @staticmethod
+        def queue_callback(cb):
+            calls.append(cb)
+    real = torch.autograd.Variable._execution_engine
+    try:
+        torch.autograd.Variable._execution_engine = _Eng
+        sink.ensure_callback()
+        sink.ensure_callback()
+    finally:
+        torch.autograd.Variable._execution_engine = real
+    assert len(calls) == 1
+    sink.joined = True
+    sink.join()  # already joined: returns without touching the (absent) stream
+    assert sink.keep == [1]

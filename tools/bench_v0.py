@@ -11,7 +11,7 @@ g = torch.randn(B, D, H, W, C, device=dev)
 w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
 A = conv3d.DEFAULT_ARITH
 pk, ci, co = conv3d._pack_forward(w, conv3d.CONV_S1, A.conv)
-pd = conv3d._pack(w, C, C, 27, C * 27, True, A.conv)
+pd = conv3d._pack(w, C, C, 27, C * 27, True, conv3d._layout(A.conv, conv3d.CONV_S1, C))
 def timeit(fn, n=10):
     for _ in range(2): fn()
     torch.cuda.synchronize()

@@ -9,7 +9,10 @@ Harness-side shims (none of them edits the reference):
     (nets/psmnet/psmnet_3.py:150-154, psmnet_submodule_3.py:83-85);
   * empty stand-in modules for `cupy` / `pynvrtc` so that utils/reprojection.py
     (which imports utils/warp_ops.py at module level) can be imported; the
-    NVRTC scatter warp itself is NOT run (it cannot be).
+    NVRTC scatter warp itself is NOT run (it cannot be, see DESIGN.md);
+  * (G12 / G13 only) inert stand-ins for `opt_einsum` and `configs.config`: nets/raft/update.py and
+    utils/losses.py import them at module level, but neither `ConvGRU` (update.py:19-41) nor `psmnet_disp`
+    (losses.py:7-15) reads anything from them.
 """
 import os
 import sys
@@ -404,10 +407,135 @@ def g11_full_d192():
          big_stride=st_big, **out, **bufs0)
 
 
+# ---------------------------------------------------------------- G12 RAFT-Stereo ConvGRU
+def _import_with_inert_stubs(modname):
+    """import a reference module whose top-level imports name packages this image lacks but whose code
+    under test never touches them (shim 4)"""
+    import importlib
+    if "opt_einsum" not in sys.modules:
+        m = types.ModuleType("opt_einsum")
+        m.contract = None
+        sys.modules["opt_einsum"] = m
+    if "configs.config" not in sys.modules:
+        pkg = types.ModuleType("configs")
+        pkg.__path__ = []
+        m = types.ModuleType("configs.config")
+        m.cfg = types.SimpleNamespace()
+        pkg.config = m
+        sys.modules["configs"], sys.modules["configs.config"] = pkg, m
+    return importlib.import_module(modname)
+
+
+def g12_convgru():
+    """nets/raft/update.py:19-41 `ConvGRU.forward(h, cz, cr, cq, *x_list)`, the class itself imported from the
+    reference: fp32 and fp64 evaluations and the reference's own arithmetic for this block (CPU
+    autocast(bfloat16), raft_stereo.py:142 wraps the update block in autocast), one update and four chained
+    updates; plus value / gradient goldens of the fp32 path for the autograd route."""
+    upd = _import_with_inert_stubs("nets.raft.update")
+    out = {}
+    cases = [("a", 128, (128,), (34, 60), 2), ("b", 128, (128, 128), (17, 30), 2), ("c", 64, (32, 48), (9, 21), 1)]
+    for tag, hidden, cx, (h, w), b in cases:
+        mod = load_procedural(upd.ConvGRU(hidden, sum(cx)), f"g12{tag}.")
+        for name in ("convz", "convr", "convq"):  # biases: procedural_tensor's 1-D rule is the BN-beta one
+            assert getattr(mod, name).bias.abs().max() > 0
+        sd = 1200 + 10 * (ord(tag) - ord("a"))
+        hid = torch.tanh(seeded((b, hidden, h, w), sd, -2.0, 2.0))
+        ctx = [seeded((b, hidden, h, w), sd + 1 + i, -0.8, 0.8) for i in range(3)]
+        xs = [seeded((b, n, h, w), sd + 4 + i, -1.7, 1.7) for i, n in enumerate(cx)]
+        # inputs are regenerated from the seeds by the test; outputs are stored on a channel / pixel lattice
+        cs, ps = (1, 1) if tag == "c" else (4, 2)
+        lat = lambda t: t[:, ::cs, ::ps, ::ps]
+        out[f"{tag}_meta"] = np.array([hidden, h, w, b, sd, cs, ps] + list(cx))
+        with torch.no_grad():
+            out[f"{tag}_out32"] = lat(mod(hid, *ctx, *xs))
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out[f"{tag}_outamp"] = lat(mod(hid, *ctx, *xs).float())
+            hh = hid
+            for _ in range(4):
+                hh = mod(hh, *ctx, *xs)
+            out[f"{tag}_iter4_32"] = lat(hh)
+            mod.double()
+            out[f"{tag}_out64"] = lat(mod(hid.double(), *[c.double() for c in ctx], *[x.double() for x in xs]))
+            hh = hid.double()
+            for _ in range(4):
+                hh = mod(hh, *[c.double() for c in ctx], *[x.double() for x in xs])
+            out[f"{tag}_iter4_64"] = lat(hh)
+            mod.float()
+        if tag == "c":  # gradients of the fp32 path (the product's autograd route)
+            cot = seeded((b, hidden, h, w), sd + 9)
+            hr = hid.clone().requires_grad_(True)
+            (mod(hr, *ctx, *xs) * cot).sum().backward()
+            out["c_gh"] = hr.grad
+            for name in ("convz", "convr", "convq"):
+                out[f"c_gw_{name}"] = getattr(mod, name).weight.grad[:16, :32]
+                out[f"c_gb_{name}"] = getattr(mod, name).bias.grad
+    save("g12_convgru", **out)
+
+
+# ---------------------------------------------------------------- G13 configs[1] at full size, train mode
+def g13_full_train_d192():
+    """BASELINE.json configs[1] through the imported reference, one pair: nets/psmnet/psmnet_3.py:144-220 in
+    TRAIN mode on a 540->544x960 pair at maxdisp 192, utils/losses.py:7-15 `psmnet_disp`, backward.  fp32 (the
+    reference's own arithmetic) and fp64 (how far any fp32 evaluation of these predictions / gradients may sit
+    from exact).  Stored: strided predictions, the loss, the mask count, whole small gradients and slices of
+    the large ones, the updated running statistics of two BatchNorms."""
+    import time
+    losses = _import_with_inert_stubs("utils.losses")
+    maxdisp, st = 192, 5
+    il, ir = (F.pad(seeded((1, 3, 540, 960), 1103 + i, -2.0, 2.0), (0, 0, 4, 0)) for i in range(2))
+    gt = seeded((1, 1, 544, 960), 1301, -12.0, 215.0)
+    mask = (gt < maxdisp) * (gt > 0)  # train.py:272
+    out = {"n_mask": int(mask.sum())}
+    grads_of = {
+        "classif3.2.weight": None, "classif1.2.weight": None,
+        "dres0.0.0.weight": (slice(0, 4), slice(0, 8)), "dres1.2.0.weight": (slice(0, 4), slice(0, 4)),
+        "dres2.conv1.0.0.weight": (slice(0, 4), slice(0, 4)), "dres3.conv5.0.weight": (slice(0, 4), slice(0, 4)),
+        "dres4.conv6.0.weight": (slice(0, 4), slice(0, 4)), "dres4.conv2.0.weight": (slice(0, 2), slice(0, 4)),
+        "feature_extraction.firstconv.0.0.weight": None,
+        "feature_extraction.layer3.1.conv2.0.weight": (slice(0, 4), slice(0, 4)),
+        "feature_extraction.lastconv.2.weight": (slice(0, 8), slice(0, 16)),
+        "dres1.0.1.weight": None, "dres1.0.1.bias": None, "feature_extraction.layer1.0.conv1.0.1.weight": None,
+    }
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        t0 = time.time()
+        model = load_procedural(ref_psmnet3.PSMNet(maxdisp=maxdisp), "g11.").to(dt).train()
+        real_ft = torch.FloatTensor
+        if dt == torch.float64:
+            torch.FloatTensor = torch.DoubleTensor  # shim 3
+        try:
+            assert all(n in dict(model.named_parameters()) for n in grads_of)
+            preds = model(il.to(dt), ir.to(dt))
+        finally:
+            torch.FloatTensor = real_ft
+        loss = losses.psmnet_disp(preds, gt.to(dt), mask)
+        loss.backward()
+        for p, k in zip(preds, ("pred3_", "pred2_", "pred1_")):
+            out[k + tag] = p.detach()[..., ::st, ::st]
+        out["loss" + tag] = loss.detach()
+        params = dict(model.named_parameters())
+        for name, sl in grads_of.items():
+            g = params[name].grad
+            out[f"g{tag}::{name}"] = g if sl is None else g[sl]
+            out[f"gn{tag}::{name}"] = g.double().norm()  # L2 norm of the WHOLE gradient tensor
+        bufs = dict(model.named_buffers())
+        for name in ("dres0.0.1.running_var", "dres4.conv6.1.running_mean"):
+            out[f"buf{tag}::{name}"] = bufs[name]
+        del model, preds, loss, params
+        print(f"g13 {tag} done in {time.time() - t0:.0f} s", flush=True)
+    for k in ("pred3_", "pred2_", "pred1_"):
+        d = (out[k + "32"].double() - out[k + "64"]).abs()
+        print(f"  |ref32 - ref64| {k}: max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    print(f"  loss32 {out['loss32'].item():.7f} loss64 {out['loss64'].item():.7f}")
+    for name in grads_of:
+        a, b = out[f"g32::{name}"].double(), out[f"g64::{name}"]
+        print(f"  grad rel-L2 ref32 vs ref64 {name}: {((a - b).norm() / b.norm()).item():.3e}")
+    save("g13_psmnet3_train_d192", seeds=[1103, 1104, 1301], maxdisp=maxdisp, pred_stride=st, **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for fn in (g1_cost_volume, g2_softargmin, g3_blocks, g4_full, g6_apply_disparity, g7_patch,
-               g8_lcn, g9_corr, g10_metrics, g11_full_d192):
+               g8_lcn, g9_corr, g10_metrics, g11_full_d192, g12_convgru, g13_full_train_d192):
         if not only or fn.__name__.split("_")[0] in only:
             fn()
