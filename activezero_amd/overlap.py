@@ -153,7 +153,8 @@ def begin(module, like):
     if not weights or not all(w.requires_grad and w.is_leaf for w in weights):
         return None  # (replicas of nn.DataParallel hold non-leaf copies: their gradients flow on through autograd)
     sink = Sink(like.device)
-    torch.cuda.current_stream(like.device).wait_stream(sink.stream)  # nothing un-joined survives into this pass
+    if sink.stream is not None:
+        torch.cuda.current_stream(like.device).wait_stream(sink.stream)  # nothing un-joined survives into this pass
     for w in weights:
         gw = _Gate.apply(w)
         sink.gated[id(w)] = (w, gw)
