@@ -17,6 +17,7 @@ struct ConvArgs {
     int relu;
     int map_mode;  // block->tile map: 0 linear, 1 XCD-chunked linear, 2 XCD-chunked + banded
     int nseg, seg_len;  // az_conv3d_roll.hip: depth segments per patch, output depths per segment
+    int stagger;        // az_conv3d_roll.hip: start offset between co-resident workgroups, in 4096-cycle units
 };
 
 // bf16x6, stride-1, 32 output channels, 8x16-voxel tile per wave (az_conv3d_m128.hip)

@@ -27,6 +27,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// timing-only ablation builds (tools/build_variant.sh): bit 0 no staging after the first stage, 1 no barriers,
+// 2 weights loaded once, 3 A fragments loaded once per row, 4 no epilogue.  0 = the shipped kernel.
+#ifndef R16_ABL
+#define R16_ABL 0
+#endif
+
 #define R_TY 8
 #define R_TX 16
 #define R_SY 10
@@ -74,6 +80,40 @@ __device__ __forceinline__ void r16_first(f32x4 &tnew, const float4 (&aq)[3], co
     tnew = t;
 }
 
+// 4x4 transpose across the four lanes of a quad: in: lane q holds M[q][0..3]; out: lane q holds M[0..3][q].
+// (C layout of the 16x16 MFMA: lane = output channel, registers = four x-adjacent voxels; after the transpose a
+//  lane holds four consecutive channels of ONE voxel: a 16-byte store, 64 contiguous bytes per quad.)
+template <int CTRL>
+__device__ __forceinline__ float r16_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ f32x4 r16_quad_transpose(const f32x4 &v, int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+    // 1x1 blocks between lanes q and q^1
+    const float s01 = r16_dpp<0xB1>(o1 ? v[0] : v[1]);  // quad_perm [1,0,3,2]
+    const float s23 = r16_dpp<0xB1>(o1 ? v[2] : v[3]);
+    const float a0 = o1 ? s01 : v[0], a1 = o1 ? v[1] : s01, a2 = o1 ? s23 : v[2], a3 = o1 ? v[3] : s23;
+    // 2x2 blocks between lanes q and q^2
+    const float t0 = r16_dpp<0x4E>(o2 ? a0 : a2);       // quad_perm [2,3,0,1]
+    const float t1 = r16_dpp<0x4E>(o2 ? a1 : a3);
+    return f32x4{o2 ? t0 : a0, o2 ? t1 : a1, o2 ? a2 : t0, o2 ? a3 : t1};
+}
+
+// Diagnostic build only (-DR16_STAMP): shader cycles per phase of the walk, summed over all waves into a buffer
+// nothing else reads (tools/roll_stamp_probe.py): [0] first barrier, [1] commit, [2] second barrier, [3] issue,
+// [4] rows, [5] after the rows up to the epilogue, [6] epilogue, [7] rotation + loop, [8] whole kernel, [9] waves.
+#ifdef R16_STAMP
+__device__ unsigned long long r16_stamp_sum[10];
+extern "C" int az_debug_roll_stamps(unsigned long long *out10, int reset) {
+    if (hipMemcpyFromSymbol(out10, HIP_SYMBOL(r16_stamp_sum), sizeof(r16_stamp_sum)) != hipSuccess) return AZ_ELAUNCH;
+    if (reset) { unsigned long long z[10] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(r16_stamp_sum), z, sizeof(z)) != hipSuccess) return AZ_ELAUNCH; }
+    return AZ_OK;
+}
+#define R16_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_[i] += now_ - tl_; tl_ = now_; } while (0)
+#else
+#define R16_T(i) do { } while (0)
+#endif
+
 template <int S> struct r16_slot { static constexpr int value = S; };
 
 template <int CIN, int EPI>
@@ -83,6 +123,11 @@ conv3d_roll_kernel(const ConvArgs a) {
     constexpr int TAPF4 = NCH * 2 * 3 * 64;  // float4 per tap in the packed image: [tap][cc][n16][part][lane]
     __shared__ __attribute__((aligned(16))) unsigned char slab[R_SLAB_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+#ifdef R16_STAMP
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+    unsigned long long tl_ = t0_;
+#endif
 
     // ---- block -> (batch, depth segment, patch): contiguous chunk of the linear order per XCD, x fastest,
     //      so that the workgroups resident on an XCD are a compact (y, x) region walking the same depths ----
@@ -100,6 +145,16 @@ conv3d_roll_kernel(const ConvArgs a) {
     const int ty0 = tiy * R_TY, tx0 = tix * R_TX;
     const int ih0 = ty0 - 1, iw0 = tx0 - 1;
 
+    // Workgroups that share a CU would otherwise run in lockstep for the whole walk (same program, same work, started
+    // together): every wave of the CU splits its slab at the same time while the matrix pipe idles, then all of
+    // them contend for it (measured: staging + epilogue fully exposed, 23 % of the kernel).  Blocks b and b + 256
+    // land on the same CU when the chip is filled round-robin (8 XCDs x 32 CUs): give the four residents of a CU
+    // four different phases, a quarter of a stage apart.  Speed only: nothing depends on the placement.
+    if (a.stagger) {
+        const int phase = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < phase * a.stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 x 64 cycles each
+    }
+
     f32x4 acc[3][8];  // [slot: kd = 0 -> output p+1, 1 -> p, 2 -> p-1][4x4-voxel tile of the 8x16 patch]
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -112,6 +167,9 @@ conv3d_roll_kernel(const ConvArgs a) {
     auto issue = [&](int p, int cc) {
         const float *plane0 = a.in + (((size_t)b * a.Di + p) * a.Hi) * a.Wi * CIN + cc * 32 + (tid & 7) * 4;
         int sy = 0, sx = tid >> 3;
+        // (opaque start: otherwise the 12 offsets and masks below are hoisted out of the walk as loop invariants
+        //  and live -- spilled -- through it; recomputing them costs ~100 VALU per stage)
+        asm volatile("" : "+v"(sx));
         okbits = 0;
 #pragma unroll
         for (int it = 0; it < R_NLD; ++it) {
@@ -126,6 +184,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     };
     auto commit = [&]() {
         int sy = 0, sx = tid >> 3;
+        asm volatile("" : "+v"(sx));  // as in issue()
         const int j = tid & 7;  // channels 4j..4j+3: octet j >> 1, 8-byte half j & 1
 #pragma unroll
         for (int it = 0; it < R_NLD; ++it) {
@@ -178,18 +237,23 @@ conv3d_roll_kernel(const ConvArgs a) {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
             __builtin_amdgcn_sched_barrier(0);
-            if (kw == 0) load_b(ring[2], wr + 2 * TAPF4);
-            else load_b(ring[kw - 1], wn_ + (kw - 1) * TAPF4);
+            if (!(R16_ABL & 4)) {
+                if (kw == 0) load_b(ring[2], wr + 2 * TAPF4);
+                else load_b(ring[kw - 1], wn_ + (kw - 1) * TAPF4);
+            }
 #pragma unroll
             for (int m = 0; m < 8; m += 2) {
                 __builtin_amdgcn_sched_barrier(0);  // program order as written: A fragments one tile ahead
-                load_a(a1, m + 1, kw);
+                if (!(R16_ABL & 8)) load_a(a1, m + 1, kw);
+                else { if (kw == 0 && m == 0) load_a(a1, 1, 0); asm volatile("" : "+v"(a0[0].x), "+v"(a1[0].x)); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kw == 0 && m == 0) r16_first(tq[0], a0, ring[kw]);
                 else r16_step(tq[0], a0, ring[kw], acc[S][(m + 7) & 7], tq[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (m + 2 < 8) load_a(a0, m + 2, kw);
-                else if (kw < 2) load_a(a0, 0, kw + 1);
+                if (!(R16_ABL & 8)) {
+                    if (m + 2 < 8) load_a(a0, m + 2, kw);
+                    else if (kw < 2) load_a(a0, 0, kw + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 r16_step(tq[1], a1, ring[kw], acc[S][m], tq[0]);
             }
@@ -200,27 +264,33 @@ conv3d_roll_kernel(const ConvArgs a) {
     };
 
     // ---- epilogue of a finished output depth (slot 2) ------------------------------------------------------
-    const int ch = wn * 16 + (lane & 15);  // this lane's output channel
-    const int vrow = lane >> 4;            // row of the 4x4 tile this lane's accumulator registers belong to
     auto finish = [&](int o) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // per-lane constants of the epilogue are rebuilt here, not kept through the walk
+        const int ch = wn * 16 + (ln & 15);  // this lane's output channel
+        const int vrow = ln >> 4;            // row of the 4x4 tile this lane's accumulator registers belong to
         const size_t plane_el = (((size_t)b * a.Do + o) * a.Ho) * a.Wo * 32;
         float *outp = a.out + plane_el;
+        // after the quad transpose this lane holds channels cq..cq+3 of the voxel (row vrow, x = lane & 3) of a tile
+        const int cq = wn * 16 + (ln & 12);
         if (EPI == 0) {
             const float *resp = a.res ? a.res + plane_el : nullptr;
-            const float sc = a.scale ? a.scale[ch] : 1.f, sf = a.shift ? a.shift[ch] : 0.f;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + cq);
+            if (a.shift) sf = *reinterpret_cast<const float4 *>(a.shift + cq);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const int oh = ty0 + 4 * (m >> 2) + vrow;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ow = tx0 + 4 * (m & 3) + r;
-                    if (oh >= a.Ho || ow >= a.Wo) continue;
-                    const unsigned off = (unsigned)(oh * a.Wo + ow) * 32 + ch;
-                    float y = acc[2][m][r] * sc + sf;
-                    if (resp) y += resp[off];
-                    if (a.relu) y = fmaxf(y, 0.f);
-                    outp[off] = y;
+                const int oh = ty0 + 4 * (m >> 2) + vrow, ow = tx0 + 4 * (m & 3) + (ln & 3);
+                const f32x4 v = r16_quad_transpose(acc[2][m], ln);
+                if (oh >= a.Ho || ow >= a.Wo) continue;
+                const unsigned off = (unsigned)(oh * a.Wo + ow) * 32 + cq;
+                float4 y = make_float4(v[0] * sc.x + sf.x, v[1] * sc.y + sf.y, v[2] * sc.z + sf.z, v[3] * sc.w + sf.w);
+                if (resp) {
+                    const float4 rr = *reinterpret_cast<const float4 *>(resp + off);
+                    y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
                 }
+                if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+                *reinterpret_cast<float4 *>(outp + off) = y;
             }
         } else {
             // raw output + BatchNorm partials at az_conv3d.hip's granularity: one (sum, centred M2, count) entry
@@ -234,18 +304,22 @@ conv3d_roll_kernel(const ConvArgs a) {
                 int nvalid = 0;
                 float sm = 0.f;
 #pragma unroll
-                for (int mx = 0; mx < 4; ++mx)
+                for (int mx = 0; mx < 4; ++mx) {
+                    const f32x4 vt = r16_quad_transpose(acc[2][my * 4 + mx], ln);
+                    const int owt = tx0 + 4 * mx + (ln & 3);
+                    if (oh < a.Ho && owt < a.Wo)
+                        *reinterpret_cast<float4 *>(outp + (unsigned)(oh * a.Wo + owt) * 32 + cq) =
+                            make_float4(vt[0], vt[1], vt[2], vt[3]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ow = tx0 + 4 * mx + r;
                         if (oh < a.Ho && ow < a.Wo) {
                             okmask |= 1u << (mx * 4 + r);
                             ++nvalid;
-                            const float v = acc[2][my * 4 + mx][r];
-                            outp[(unsigned)(oh * a.Wo + ow) * 32 + ch] = v;
-                            sm += v;
+                            sm += acc[2][my * 4 + mx][r];
                         }
                     }
+                }
                 nvalid += __shfl_xor(nvalid, 16); nvalid += __shfl_xor(nvalid, 32);
                 sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
                 const float mean = sm / (float)max(nvalid, 1);
@@ -282,14 +356,20 @@ conv3d_roll_kernel(const ConvArgs a) {
         if (p >= p_first && p <= p_last) {
             const int lo = kd_lo(p), hi = kd_hi(p);
             for (int cc = 0; cc < NCH; ++cc) {
-                __syncthreads();  // the previous slab has been consumed by both waves
-                commit();
-                __syncthreads();
+                const bool stage_it = !(R16_ABL & 1) || (p == p_first && cc == 0);
+                R16_T(7);
+                if (!(R16_ABL & 2)) __syncthreads();  // the previous slab has been consumed by both waves
+                R16_T(0);
+                if (stage_it) commit();
+                R16_T(1);
+                if (!(R16_ABL & 2)) __syncthreads();
+                R16_T(2);
                 // next stage in execution order (the last one re-requests itself: valid, cache-hot addresses)
                 int pn = p, ccn = cc + 1;
                 if (ccn == NCH) { ccn = 0; pn = p + 1; }
                 if (pn > p_last) { pn = p; ccn = cc; }
-                issue(pn, ccn);
+                if (!(R16_ABL & 1)) issue(pn, ccn);
+                R16_T(3);
                 const bool more = !(pn == p && ccn == cc);
                 const int lon = kd_lo(pn);
 #pragma unroll 1
@@ -301,9 +381,12 @@ conv3d_roll_kernel(const ConvArgs a) {
                     if (lo <= 1 && hi >= 1) row(r16_slot<1>{}, kh, wrow(1, kh, cc), hi >= 2 ? wrow(2, kh, cc) : after);
                     if (hi == 2) row(r16_slot<2>{}, kh, wrow(2, kh, cc), after);
                 }
+                R16_T(4);
             }
         }
-        if (p - 1 >= d0) finish(p - 1);
+        R16_T(5);
+        if (!(R16_ABL & 16) || p - 1 == d1 - 1) { if (p - 1 >= d0) finish(p - 1); }
+        R16_T(6);
         // rotate the depth slots: what was output p (slot 1) becomes output (p+1) - 1 of the next plane, ...
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -311,7 +394,16 @@ conv3d_roll_kernel(const ConvArgs a) {
             acc[1][m] = acc[0][m];
             acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        R16_T(7);
     }
+#ifdef R16_STAMP
+    R16_T(7);
+    if (lane == 0) {
+        for (int i = 0; i < 8; ++i) atomicAdd(&r16_stamp_sum[i], st_[i]);
+        atomicAdd(&r16_stamp_sum[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t0_);
+        atomicAdd(&r16_stamp_sum[9], 1ull);
+    }
+#endif
 }
 
 // ---- weight packing: [tap][cc32][n16][part(3)][lane(64)][8] bf16, element j of lane =
@@ -369,6 +461,11 @@ static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
 template <int CIN, int EPI>
 static int launch_roll(ConvArgs a, hipStream_t s) {
     roll_segments(a, a.nseg, a.seg_len);
+    {   // quarter of a stage in units of 4096 cycles: a stage is 27 x 48 x (CIN / 32) MFMAs of 16 cycles per wave,
+        // two waves per SIMD
+        const char *e = getenv("AZ_ROLL_STAGGER");
+        a.stagger = e ? atoi(e) : (27 * 48 * (CIN / 32) * 16 * 2 / 4) / 4096;
+    }
     const long long blocks = (long long)a.B * a.nseg * ((a.tiles_y + 1) / 2) * a.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI>), dim3((unsigned)blocks), dim3(128), 0, s, a);

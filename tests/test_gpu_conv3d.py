@@ -214,7 +214,9 @@ def test_fused_cost_volume_conv_equals_materialised(arith):
         y_fused = agg3d.conv_bn(lazy, unit, relu=True, arith=arith)
         vol = agg3d.volume_from_features(fl.to(DEV), fr.to(DEV), nd, lazy=False)
         y_mat = agg3d.conv_bn(vol, unit, relu=True, arith=arith)
-    assert torch.equal(y_fused, y_mat)
+    # (two kernels since round 3: the fused operand runs on the 32x32x16 kernel, the materialised volume on the
+    #  depth-rolling 16x16x32 one -- same arithmetic, K blocks of 16 vs 32: equal to rounding, not to the bit)
+    assert torch.allclose(y_fused, y_mat, rtol=1e-5, atol=2e-6 * float(y_mat.abs().max()))
     close(ncdhw(y_fused), ref, 1e-4, 2e-5)
 
 
