@@ -10,28 +10,33 @@
 //   * v_mfma_f32_16x16x32_bf16.  K = 32 per instruction = one 32-channel chunk per tap: one accumulate-add per
 //     element per 32-deep block (half the adds of the 32x32x16 form, and one accumulator rounding per K32 block
 //     instead of per K16 block); the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS item 7).
-//   * OUTPUT CHANNELS SPLIT OVER TWO WAVES.  16 output channels x 128 voxels per wave = 32 accumulator
-//     registers per depth slot, 96 for the three slots: the kernel keeps 2 waves per SIMD (the partner covers
-//     LDS / weight latency and the staging burst) although it carries three outputs.  The two waves of a
-//     workgroup stage the shared slab cooperatively (half the split work each) and read the same A fragments.
-//   * LDS slab: 10 x 18 voxels x [3 parts][32 ch] bf16 = 192 B per voxel, 34.5 KB, four workgroups per CU.  An
-//     M tile is a 4 x 4 voxel square: lane l reads voxel (l & 15) = (row l>>2 & 3, x l & 3), channel octet
-//     l >> 4.  Four x-adjacent voxels step through the four 64-B bank quarters (192 B = 3 quarters), and the
-//     octet index is XORed with 2 on odd slab rows, so that the 16-lane groups of a ds_read_b128
-//     ({0-3, 12-15, 20-27}, ...) touch every bank exactly once for ANY tap shift: conflict-free, no padding.
+//   * FOUR WAVES = 2 halves of the output channels x 2 halves of the patch.  A wave accumulates 16 channels x 64
+//     voxels x 3 depth slots = 48 registers, so the kernel keeps 2 waves per SIMD with room for the software
+//     pipeline (the first version of this file gave a wave 128 voxels: 96 accumulator registers, the prefetched
+//     slab spilled to scratch, and every reload waited -- vmcnt is one in-order counter -- for the output
+//     stores' acknowledgements: 40 % of the kernel was stage-boundary time, profiles/r03_roll_kernel_notes.md).
+//   * LDS slab: 10 x 18 voxels x [3 parts][32 ch] bf16 = 192 B per voxel, 34.5 KB, DOUBLE-BUFFERED (69 KB per
+//     workgroup, two workgroups per CU): the next plane is split and written while this one is multiplied, in
+//     the shadow of the MFMAs; one barrier per stage.  An M tile is a 4 x 4 voxel square: lane l reads voxel
+//     (l & 15) = (row l>>2 & 3, x l & 3), channel octet l >> 4.  Four x-adjacent voxels step through the four
+//     64-B bank quarters (192 B = 3 quarters) and the octet index is XORed with 2 on odd slab rows, so that the
+//     16-lane groups of a ds_read_b128 touch every bank exactly once for ANY tap shift (SQ_LDS_BANK_CONFLICT 0).
+//   * A STAGE (one plane x one 32-channel chunk: 27 taps x 4 tiles x 6 MFMAs per wave) IS STRAIGHT-LINE CODE:
+//     all three kd are always computed (at the two ends of a segment a slot then holds a partial sum that is
+//     never stored: 4 % more MFMAs at 48 planes), the epilogue of the finished depth sits inside the stage with
+//     lane validity expressed through buffer-instruction bounds (no branch), so hipcc counts vmcnt exactly:
+//     nothing waits for the slab prefetch or for store acknowledgements before it has to.
 //
 // Arithmetic: az_common.h's bf16x6 product (exact 3-way RNE split, six MFMAs per block summed from zero,
 // largest terms first, one VALU add per block into the fp32 accumulator).  Accumulation order per output:
 // input plane (kd) ascending, 32-channel chunk, kh, kw -- the order of az_conv3d_m128.hip with K32 blocks.
+#include <type_traits>
+
 #include "az_conv3d_args.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// timing-only ablation builds (tools/build_variant.sh): bit 0 no staging after the first stage, 1 no barriers,
-// 2 weights loaded once, 3 A fragments loaded once per row, 4 no epilogue.  0 = the shipped kernel.
-#ifndef R16_ABL
-#define R16_ABL 0
-#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define R_TY 8
 #define R_TX 16
@@ -40,7 +45,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define R_VB 192                          // bytes per slab voxel
 #define R_SLAB_BYTES (R_SY * R_SX * R_VB)  // 34 560
 #define R_NQ (R_SY * R_SX * 8)             // 16-byte fp32 pieces of one plane chunk (8 per voxel)
-#define R_NLD ((R_NQ + 127) / 128)         // 12 per thread
+#define R_NLD ((R_NQ + 255) / 256)         // 6 per thread
+#define R_OOB 0xffffff00u                  // a buffer offset beyond every tensor: loads return 0, stores are dropped
 
 #define R_MF(ACC, A, B) __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
         __builtin_bit_cast(az_bf16x8, aq[A]), __builtin_bit_cast(az_bf16x8, bq[B]), ACC, 0, 0, 0)
@@ -74,11 +80,6 @@ __device__ __forceinline__ void r16_step(f32x4 &tnew, const float4 (&aq)[3], con
     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
 }
-__device__ __forceinline__ void r16_first(f32x4 &tnew, const float4 (&aq)[3], const float4 (&bq)[3]) {
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    t = R_MF(t, 0, 0); t = R_MF(t, 0, 1); t = R_MF(t, 1, 0); t = R_MF(t, 1, 1); t = R_MF(t, 0, 2); t = R_MF(t, 2, 0);
-    tnew = t;
-}
 
 // 4x4 transpose across the four lanes of a quad: in: lane q holds M[q][0..3]; out: lane q holds M[0..3][q].
 // (C layout of the 16x16 MFMA: lane = output channel, registers = four x-adjacent voxels; after the transpose a
@@ -89,19 +90,16 @@ __device__ __forceinline__ float r16_dpp(float v) {
 }
 __device__ __forceinline__ f32x4 r16_quad_transpose(const f32x4 &v, int lane) {
     const bool o1 = lane & 1, o2 = lane & 2;
-    // 1x1 blocks between lanes q and q^1
     const float s01 = r16_dpp<0xB1>(o1 ? v[0] : v[1]);  // quad_perm [1,0,3,2]
     const float s23 = r16_dpp<0xB1>(o1 ? v[2] : v[3]);
     const float a0 = o1 ? s01 : v[0], a1 = o1 ? v[1] : s01, a2 = o1 ? s23 : v[2], a3 = o1 ? v[3] : s23;
-    // 2x2 blocks between lanes q and q^2
     const float t0 = r16_dpp<0x4E>(o2 ? a0 : a2);       // quad_perm [2,3,0,1]
     const float t1 = r16_dpp<0x4E>(o2 ? a1 : a3);
     return f32x4{o2 ? t0 : a0, o2 ? t1 : a1, o2 ? a2 : t0, o2 ? a3 : t1};
 }
 
-// Diagnostic build only (-DR16_STAMP): shader cycles per phase of the walk, summed over all waves into a buffer
-// nothing else reads (tools/roll_stamp_probe.py): [0] first barrier, [1] commit, [2] second barrier, [3] issue,
-// [4] rows, [5] after the rows up to the epilogue, [6] epilogue, [7] rotation + loop, [8] whole kernel, [9] waves.
+// Diagnostic build only (-DR16_STAMP): shader cycles per wave, summed into a buffer nothing else reads
+// (tools/roll_stamp_probe.py): [0] prologue, [1] stage bodies, [2] stage-end barriers, [3] tail, [8] kernel, [9] waves.
 #ifdef R16_STAMP
 __device__ unsigned long long r16_stamp_sum[10];
 extern "C" int az_debug_roll_stamps(unsigned long long *out10, int reset) {
@@ -114,17 +112,18 @@ extern "C" int az_debug_roll_stamps(unsigned long long *out10, int reset) {
 #define R16_T(i) do { } while (0)
 #endif
 
-template <int S> struct r16_slot { static constexpr int value = S; };
-
+// EPI: 0 = y = relu?(acc * scale + shift), 2 = the same + residual, 1 = raw output + BatchNorm partials
 template <int CIN, int EPI>
-__global__ void __launch_bounds__(128, 2)
+__global__ void __launch_bounds__(256, 2)
 conv3d_roll_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32;            // 32-channel chunks per plane
     constexpr int TAPF4 = NCH * 2 * 3 * 64;  // float4 per tap in the packed image: [tap][cc][n16][part][lane]
-    __shared__ __attribute__((aligned(16))) unsigned char slab[R_SLAB_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned char slab[2 * R_SLAB_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wv & 1, wm = wv >> 1;  // half of the output channels, half (4 rows) of the patch
 #ifdef R16_STAMP
-    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_[4] = {0, 0, 0, 0};
     const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
     unsigned long long tl_ = t0_;
 #endif
@@ -145,261 +144,255 @@ conv3d_roll_kernel(const ConvArgs a) {
     const int ty0 = tiy * R_TY, tx0 = tix * R_TX;
     const int ih0 = ty0 - 1, iw0 = tx0 - 1;
 
-    // Workgroups that share a CU would otherwise run in lockstep for the whole walk (same program, same work, started
-    // together): every wave of the CU splits its slab at the same time while the matrix pipe idles, then all of
-    // them contend for it (measured: staging + epilogue fully exposed, 23 % of the kernel).  Blocks b and b + 256
-    // land on the same CU when the chip is filled round-robin (8 XCDs x 32 CUs): give the four residents of a CU
-    // four different phases, a quarter of a stage apart.  Speed only: nothing depends on the placement.
-    if (a.stagger) {
-        const int phase = (blockIdx.x >> 8) & 3;
-        for (int i = 0; i < phase * a.stagger; ++i) __builtin_amdgcn_s_sleep(64);  // 64 x 64 cycles each
-    }
+    // buffer resources: lane validity (zero padding of the input, patches that overhang the volume, depths
+    // outside the segment) is an out-of-range offset, never a branch
+    const unsigned in_bytes = (unsigned)a.Di * a.Hi * a.Wi * CIN * 4u, out_bytes = (unsigned)a.Do * a.Ho * a.Wo * 32u * 4u;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in) + (size_t)b * (in_bytes / 4), 0, in_bytes, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * (out_bytes / 4), 0, out_bytes, 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(EPI == 2 ? a.res : a.out) + (size_t)b * (out_bytes / 4), 0, EPI == 2 ? out_bytes : 0u, 0x00020000);
+    const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.part : a.out, 0,
+                                                           EPI == 1 ? (unsigned)(a.ntiles * 32 * 2 * 4) : 0u, 0x00020000);
+    const auto rs_cnt = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.cnt : a.out, 0,
+                                                          EPI == 1 ? (unsigned)(a.ntiles * 4) : 0u, 0x00020000);
 
-    f32x4 acc[3][8];  // [slot: kd = 0 -> output p+1, 1 -> p, 2 -> p-1][4x4-voxel tile of the 8x16 patch]
+    f32x4 acc[3][4];  // [slot: kd = 0 -> output p+1, 1 -> p, 2 -> p-1][4x4-voxel tile of this wave's 4x16 half patch]
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc[s][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; ++m) acc[s][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- staging: one plane chunk = 10 x 18 voxels x 32 channels fp32 -> bf16 triplets in LDS -------------
-    float4 pre[R_NLD];
-    unsigned okbits = 0;
+    // piece idx = tid + 256 it: voxel idx >> 3 (sy = voxel / 18, sx = voxel % 18), channels 4 (idx & 7) ..
+    u32x4 pre[R_NLD];
     auto issue = [&](int p, int cc) {
-        const float *plane0 = a.in + (((size_t)b * a.Di + p) * a.Hi) * a.Wi * CIN + cc * 32 + (tid & 7) * 4;
-        int sy = 0, sx = tid >> 3;
-        // (opaque start: otherwise the 12 offsets and masks below are hoisted out of the walk as loop invariants
-        //  and live -- spilled -- through it; recomputing them costs ~100 VALU per stage)
-        asm volatile("" : "+v"(sx));
-        okbits = 0;
+        int sy = 0, sx = tid >> 3;  // (tid >> 3 is 0..31)
+        if (sx >= R_SX) { sx -= R_SX; ++sy; }
 #pragma unroll
         for (int it = 0; it < R_NLD; ++it) {
             const int ih = ih0 + sy, iw = iw0 + sx;
-            const int ihc = min(max(ih, 0), a.Hi - 1), iwc = min(max(iw, 0), a.Wi - 1);
-            const bool ok = (tid + 128 * it < R_NQ) && ih == ihc && iw == iwc;
-            pre[it] = *reinterpret_cast<const float4 *>(plane0 + (unsigned)(ihc * a.Wi + iwc) * CIN);
-            okbits |= ok ? (1u << it) : 0u;
-            sx += 16;
+            const bool ok = (tid + 256 * it < R_NQ) && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi &&
+                            (unsigned)p < (unsigned)a.Di;
+            const unsigned off = (unsigned)((p * a.Hi + ih) * a.Wi + iw) * (CIN * 4) + cc * 128 + (tid & 7) * 16;
+            pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : R_OOB, 0, 0);
+            sx += 14; ++sy;  // 32 voxels on = one slab row + 14
             if (sx >= R_SX) { sx -= R_SX; ++sy; }
         }
     };
-    auto commit = [&]() {
-        int sy = 0, sx = tid >> 3;
-        asm volatile("" : "+v"(sx));  // as in issue()
+    auto commit_piece = [&](int it, unsigned char *dstbuf) {
+        // (sy, sx) of piece `it`: static `it`, so this is a handful of integer instructions on tid.  The last
+        // piece exists for 160 of the 256 threads only; the others re-write their previous piece (same bytes, same
+        // place) instead of branching, so that a stage stays one basic block.
+        const bool live = (tid + 256 * it < R_NQ);
+        const int ite = (it > 0 && !live) ? it - 1 : it;
+        const int vox = (tid >> 3) + 32 * ite;
+        const int sy = vox / R_SX, sx = vox - sy * R_SX;
         const int j = tid & 7;  // channels 4j..4j+3: octet j >> 1, 8-byte half j & 1
-#pragma unroll
-        for (int it = 0; it < R_NLD; ++it) {
-            if (!((okbits >> it) & 1u)) pre[it] = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding
-            if (tid + 128 * it < R_NQ) {
-                uint2 hi, mid, lo;
-                az_split3_bf16x4(pre[it], hi, mid, lo);
-                unsigned char *dst = slab + (sy * R_SX + sx) * R_VB + ((((j >> 1) ^ ((sy & 1) << 1))) << 4) + (j & 1) * 8;
-                *reinterpret_cast<uint2 *>(dst) = hi;
-                *reinterpret_cast<uint2 *>(dst + 64) = mid;
-                *reinterpret_cast<uint2 *>(dst + 128) = lo;
-            }
-            sx += 16;
-            if (sx >= R_SX) { sx -= R_SX; ++sy; }
+        u32x4 raw = pre[it];
+        if (it > 0 && 256 * it + 255 >= R_NQ) {  // (static: only the last piece)
+            raw[0] = live ? raw[0] : pre[it - 1][0]; raw[1] = live ? raw[1] : pre[it - 1][1];
+            raw[2] = live ? raw[2] : pre[it - 1][2]; raw[3] = live ? raw[3] : pre[it - 1][3];
         }
+        uint2 hi, mid, lo;
+        az_split3_bf16x4(__builtin_bit_cast(float4, raw), hi, mid, lo);
+        unsigned char *dst = dstbuf + (sy * R_SX + sx) * R_VB + ((((j >> 1) ^ ((sy & 1) << 1))) << 4) + (j & 1) * 8;
+        *reinterpret_cast<uint2 *>(dst) = hi;
+        *reinterpret_cast<uint2 *>(dst + 64) = mid;
+        *reinterpret_cast<uint2 *>(dst + 128) = lo;
     };
 
     // ---- operands ------------------------------------------------------------------------------------------
     // A: lane -> voxel (row (lane >> 2) & 3, x lane & 3) of a 4x4 tile, channel octet lane >> 4; the octet
-    // swizzle depends on the slab row's parity = (kh + tile row) & 1 (tile origins are even rows)
+    // swizzle depends on the slab row's parity = (kh + tile row) & 1 (this wave's tile rows start at 4 wm: even)
     const int trow = (lane >> 2) & 3, tcol = lane & 3, oct = lane >> 4;
     unsigned abase[2];
-    abase[0] = (trow * R_SX + tcol) * R_VB + ((oct ^ ((trow & 1) << 1)) << 4);
-    abase[1] = (trow * R_SX + tcol) * R_VB + ((oct ^ (((trow + 1) & 1) << 1)) << 4);
-    // B: packed [tap][cc][n16][part][lane] float4 (conv3d_pack_r16_kernel), this wave's 16 output channels
-    const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp) + wn * 3 * 64 + lane;
-    auto load_b = [&](float4 (&bq)[3], const float4 *tap) {
+    abase[0] = ((4 * wm + trow) * R_SX + tcol) * R_VB + ((oct ^ ((trow & 1) << 1)) << 4);
+    abase[1] = ((4 * wm + trow) * R_SX + tcol) * R_VB + ((oct ^ (((trow + 1) & 1) << 1)) << 4);
+    // B: packed [tap][cc][n16][part][lane] float4 (conv3d_pack_r16_kernel), this wave's 16 output channels.  Read
+    // through a buffer resource: one lane-offset register, the tap's byte offset travels in an SGPR / the immediate
+    // (with flat addresses hipcc hoists the 27 x 64-bit tap addresses out of the walk and spills them)
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, 27u * CIN * 32u * 6u, 0x00020000);
+    const unsigned wlane = (unsigned)(wn * 3 * 64 + lane) * 16u;
+    auto load_b = [&](float4 (&bq)[3], int tap_f4) {  // tap_f4: float4 index of the tap's first fragment (static)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[p] = tap[p * 64];
+        for (int p = 0; p < 3; ++p)
+            bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, tap_f4 * 16 + p * 1024, 0));
     };
-    auto wrow = [&](int kd, int kh, int cc) -> const float4 * {  // first tap (kw = 0) of a (kd, kh) row
-        return wp4 + (size_t)((kd * 9 + kh * 3) * NCH + cc) * (2 * 3 * 64);
+    // execution order inside a stage: kd = 2 (order indices 0..8), kd = 1, kd = 0; packed tap of order index i
+    auto tap_of = [](int i) { return (2 - i / 9) * 9 + (i % 9); };
+
+    // per-channel epilogue constants, loaded once (four consecutive channels per lane after the quad transpose)
+    const int cq = wn * 16 + (lane & 12);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI != 1) {
+        if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + cq);
+        if (a.shift) sf = *reinterpret_cast<const float4 *>(a.shift + cq);
+    }
+    const float floor_ = a.relu ? 0.f : -__builtin_inff();
+
+    // ---- epilogue of a finished output depth (slot 2); `ok`: the depth belongs to this segment ---------------
+    auto finish = [&](int o, bool ok) {
+        const int oh = ty0 + 4 * wm + (lane >> 4);  // row of the 4x4 tiles this lane's accumulator registers belong to
+        const bool row_ok = ok && oh < a.Ho;
+        const unsigned row_off = (unsigned)((o * a.Ho + oh) * a.Wo) * 128u + (unsigned)cq * 4u;
+        if (EPI != 1) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int ow = tx0 + 4 * m + (lane & 3);
+                const f32x4 v = r16_quad_transpose(acc[2][m], lane);
+                const unsigned off = (row_ok && ow < a.Wo) ? row_off + (unsigned)ow * 128u : R_OOB;
+                float4 y = make_float4(v[0] * sc.x + sf.x, v[1] * sc.y + sf.y, v[2] * sc.z + sf.z, v[3] * sc.w + sf.w);
+                if (EPI == 2) {
+                    const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
+                    y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
+                }
+                y.x = fmaxf(y.x, floor_); y.y = fmaxf(y.y, floor_); y.z = fmaxf(y.z, floor_); y.w = fmaxf(y.w, floor_);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, off, 0, 0);
+            }
+        } else {
+            // raw output + BatchNorm partials at az_conv3d.hip's granularity: this wave's 4x16 half patch IS one
+            // canonical tile: one (sum, centred M2) entry per channel, one count per tile
+            const int tiy4 = 2 * tiy + wm;
+            unsigned okmask = 0;  // bit (m * 4 + r)
+            int nvalid = 0;
+            float sm = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 vt = r16_quad_transpose(acc[2][m], lane);
+                const int owt = tx0 + 4 * m + (lane & 3);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vt), rs_out,
+                                                       (row_ok && owt < a.Wo) ? row_off + (unsigned)owt * 128u : R_OOB, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool in = oh < a.Ho && tx0 + 4 * m + r < a.Wo;
+                    okmask |= in ? (1u << (m * 4 + r)) : 0u;
+                    nvalid += in ? 1 : 0;
+                    sm += in ? acc[2][m][r] : 0.f;
+                }
+            }
+            nvalid += __shfl_xor(nvalid, 16); nvalid += __shfl_xor(nvalid, 32);
+            sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+            const float mean = sm / (float)max(nvalid, 1);
+            float m2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dlt = acc[2][m][r] - mean;
+                    m2 += ((okmask >> (m * 4 + r)) & 1u) ? dlt * dlt : 0.f;
+                }
+            m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+            const bool tile_ok = ok && tiy4 < a.tiles_y;
+            const unsigned tile_id = (unsigned)(((b * a.Dt + o) * a.tiles_y + tiy4) * a.tiles_x + tix);
+            const unsigned ch = wn * 16 + (lane & 15);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(sm, m2)), rs_part,
+                                                  (tile_ok && lane < 16) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)nvalid), rs_cnt,
+                                                  (tile_ok && lane == 0 && wn == 0) ? tile_id * 4u : R_OOB, 0, 0);
+        }
     };
 
-    float4 ring[3][3];  // weights of kw = 0, 1, 2 of the row in progress; refilled two taps ahead
-    f32x4 tq[2];
+    float4 ring[3][3];  // weights of order index i in ring[i % 3] (27 per stage: static slots), two taps ahead
+    f32x4 tq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 
-    // one (kd, kh) row: 3 taps x 8 tiles x 6 MFMAs into accumulator slot S.  `wr` = this row's weights (ring[0],
-    // ring[1] already requested), `wn_` = the row that follows in execution order (its kw = 0, 1 are requested here).
-    auto row = [&](auto slot, int kh, const float4 *wr, const float4 *wn_) {
-        constexpr int S = decltype(slot)::value;
-        const unsigned char *ab = slab + abase[kh & 1] + kh * (R_SX * R_VB);
-        auto load_a = [&](float4 (&aq)[3], int m, int kw) {
-            const unsigned char *ap = ab + ((4 * (m >> 2)) * R_SX + 4 * (m & 3) + kw) * R_VB;
-#pragma unroll
-            for (int p = 0; p < 3; ++p) aq[p] = *reinterpret_cast<const float4 *>(ap + 64 * p);
-        };
+    // ---- one stage: plane p, chunk CC, slab in buffer `buf`; straight-line ------------------------------------
+    auto stage = [&](auto cc_tag, int p, int buf) {
+        constexpr int CC = decltype(cc_tag)::value;
+        constexpr bool LAST = (CC == NCH - 1);
+        constexpr int CCN = (CC + 1) % NCH;
+        const unsigned char *sl = slab + buf * R_SLAB_BYTES;
+        unsigned char *sn = slab + (buf ^ 1) * R_SLAB_BYTES;
+        constexpr int wcur = CC * (2 * 3 * 64), wnxt = CCN * (2 * 3 * 64);
+        const int pn = LAST ? p + 1 : p;
         float4 a0[3], a1[3];
-        load_a(a0, 0, 0);
+        auto load_a = [&](float4 (&aq)[3], int m, int kh, int kw) {
+            const unsigned char *ap = sl + abase[kh & 1] + (kh * R_SX + 4 * m + kw) * R_VB;
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
+            for (int q = 0; q < 3; ++q) aq[q] = *reinterpret_cast<const float4 *>(ap + 64 * q);
+        };
+        load_a(a0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 27; ++i) {
+            const int kd = 2 - i / 9, kh = (i % 9) / 3, kw = i % 3;
             __builtin_amdgcn_sched_barrier(0);
-            if (!(R16_ABL & 4)) {
-                if (kw == 0) load_b(ring[2], wr + 2 * TAPF4);
-                else load_b(ring[kw - 1], wn_ + (kw - 1) * TAPF4);
+            // weights two taps ahead (the last two taps request the first two of the next stage)
+            if (i + 2 < 27) load_b(ring[(i + 2) % 3], wcur + tap_of(i + 2) * TAPF4);
+            else load_b(ring[(i + 2) % 3], wnxt + tap_of(i + 2 - 27) * TAPF4);
+            if (i == 0) {
+                __builtin_amdgcn_sched_barrier(0);  // request order as written: the slab behind this tap's weights
+                issue(pn, CCN);
             }
 #pragma unroll
-            for (int m = 0; m < 8; m += 2) {
+            for (int m = 0; m < 4; m += 2) {
                 __builtin_amdgcn_sched_barrier(0);  // program order as written: A fragments one tile ahead
-                if (!(R16_ABL & 8)) load_a(a1, m + 1, kw);
-                else { if (kw == 0 && m == 0) load_a(a1, 1, 0); asm volatile("" : "+v"(a0[0].x), "+v"(a1[0].x)); }
+                load_a(a1, m + 1, kh, kw);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kw == 0 && m == 0) r16_first(tq[0], a0, ring[kw]);
-                else r16_step(tq[0], a0, ring[kw], acc[S][(m + 7) & 7], tq[1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(R16_ABL & 8)) {
-                    if (m + 2 < 8) load_a(a0, m + 2, kw);
-                    else if (kw < 2) load_a(a0, 0, kw + 1);
+                // (the temporary carried into a step belongs to the tile before: tile 3 of the previous tap, which
+                //  for the first tap of a kd block is the previous kd's slot -- all static in this straight line;
+                //  a stage starts with a zero temporary)
+                if (m == 0) {
+                    if (i % 9 == 0) r16_step(tq[0], a0, ring[i % 3], acc[i == 0 ? 2 : kd + 1][3], tq[1]);
+                    else r16_step(tq[0], a0, ring[i % 3], acc[kd][3], tq[1]);
+                } else {
+                    r16_step(tq[0], a0, ring[i % 3], acc[kd][m - 1], tq[1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                r16_step(tq[1], a1, ring[kw], acc[S][m], tq[0]);
+                if (m + 2 < 4) load_a(a0, m + 2, kh, kw);
+                else if (i + 1 < 27) load_a(a0, 0, ((i + 1) % 9) / 3, (i + 1) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                r16_step(tq[1], a1, ring[i % 3], acc[kd][m], tq[0]);
+                // the finished depth (kd = 2 of the plane's last chunk) leaves while kd = 1, 0 are multiplied
+                if (LAST && i == 9 && m == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(p - 1, p - 1 >= d0);
+                }
+            }
+            // the next slab: one piece every other tap from tap 15 on (requested at tap 0)
+            if (i >= 15 && i < 15 + 2 * R_NLD && ((i - 15) & 1) == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                commit_piece((i - 15) / 2, sn);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc[S][7] += tq[1];  // the row's last temporary
-        asm volatile("" : "+v"(acc[S][7]));
-    };
-
-    // ---- epilogue of a finished output depth (slot 2) ------------------------------------------------------
-    auto finish = [&](int o) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));  // per-lane constants of the epilogue are rebuilt here, not kept through the walk
-        const int ch = wn * 16 + (ln & 15);  // this lane's output channel
-        const int vrow = ln >> 4;            // row of the 4x4 tile this lane's accumulator registers belong to
-        const size_t plane_el = (((size_t)b * a.Do + o) * a.Ho) * a.Wo * 32;
-        float *outp = a.out + plane_el;
-        // after the quad transpose this lane holds channels cq..cq+3 of the voxel (row vrow, x = lane & 3) of a tile
-        const int cq = wn * 16 + (ln & 12);
-        if (EPI == 0) {
-            const float *resp = a.res ? a.res + plane_el : nullptr;
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + cq);
-            if (a.shift) sf = *reinterpret_cast<const float4 *>(a.shift + cq);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int oh = ty0 + 4 * (m >> 2) + vrow, ow = tx0 + 4 * (m & 3) + (ln & 3);
-                const f32x4 v = r16_quad_transpose(acc[2][m], ln);
-                if (oh >= a.Ho || ow >= a.Wo) continue;
-                const unsigned off = (unsigned)(oh * a.Wo + ow) * 32 + cq;
-                float4 y = make_float4(v[0] * sc.x + sf.x, v[1] * sc.y + sf.y, v[2] * sc.z + sf.z, v[3] * sc.w + sf.w);
-                if (resp) {
-                    const float4 rr = *reinterpret_cast<const float4 *>(resp + off);
-                    y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
-                }
-                if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-                *reinterpret_cast<float4 *>(outp + off) = y;
-            }
-        } else {
-            // raw output + BatchNorm partials at az_conv3d.hip's granularity: one (sum, centred M2, count) entry
-            // per 4x16 half of the patch and channel, under that kernel's canonical tile id
-#pragma unroll
-            for (int my = 0; my < 2; ++my) {
-                const int tiy4 = 2 * tiy + my;
-                if (tiy4 >= a.tiles_y) continue;  // workgroup-uniform: the lower half lies outside the volume
-                const int oh = ty0 + 4 * my + vrow;
-                unsigned okmask = 0;  // bit (mx * 4 + r)
-                int nvalid = 0;
-                float sm = 0.f;
-#pragma unroll
-                for (int mx = 0; mx < 4; ++mx) {
-                    const f32x4 vt = r16_quad_transpose(acc[2][my * 4 + mx], ln);
-                    const int owt = tx0 + 4 * mx + (ln & 3);
-                    if (oh < a.Ho && owt < a.Wo)
-                        *reinterpret_cast<float4 *>(outp + (unsigned)(oh * a.Wo + owt) * 32 + cq) =
-                            make_float4(vt[0], vt[1], vt[2], vt[3]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ow = tx0 + 4 * mx + r;
-                        if (oh < a.Ho && ow < a.Wo) {
-                            okmask |= 1u << (mx * 4 + r);
-                            ++nvalid;
-                            sm += acc[2][my * 4 + mx][r];
-                        }
-                    }
-                }
-                nvalid += __shfl_xor(nvalid, 16); nvalid += __shfl_xor(nvalid, 32);
-                sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-                const float mean = sm / (float)max(nvalid, 1);
-                float m2 = 0.f;
-#pragma unroll
-                for (int mx = 0; mx < 4; ++mx)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dlt = acc[2][my * 4 + mx][r] - mean;
-                        m2 += ((okmask >> (mx * 4 + r)) & 1u) ? dlt * dlt : 0.f;
-                    }
-                m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
-                const int tile_id = ((b * a.Dt + o) * a.tiles_y + tiy4) * a.tiles_x + tix;
-                if (vrow == 0)
-                    *reinterpret_cast<float2 *>(&a.part[((size_t)ch * a.ntiles + tile_id) * 2]) = make_float2(sm, m2);
-                if (tid == 0) a.cnt[tile_id] = (float)nvalid;
-            }
-        }
+        acc[0][3] += tq[1];  // the stage's last temporary
+        tq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        R16_T(1);
+        __syncthreads();  // next slab written by all four waves; this one no longer read
+        R16_T(2);
     };
 
     // ---- the walk ------------------------------------------------------------------------------------------
-    // planes p = d0-1 .. d1; plane p adds (kd) to output p + 1 - kd for the outputs of this segment; planes
-    // outside the volume are zero padding and skipped outright.  After plane p output p-1 is complete.
+    // planes p_first .. p_last (those of d0-1 .. d1 inside the volume); plane p adds kd to output p + 1 - kd.
     const int p_first = max(d0 - 1, 0), p_last = min(d1, a.Di - 1);
-    auto kd_lo = [&](int p) { return max(0, p + 2 - d1); };
-    auto kd_hi = [&](int p) { return min(2, p + 1 - d0); };
     issue(p_first, 0);
-    {
-        const float4 *w0 = wrow(kd_lo(p_first), 0, 0);
-        load_b(ring[0], w0);
-        load_b(ring[1], w0 + TAPF4);
-    }
-    for (int p = d0 - 1; p <= d1; ++p) {
-        if (p >= p_first && p <= p_last) {
-            const int lo = kd_lo(p), hi = kd_hi(p);
-            for (int cc = 0; cc < NCH; ++cc) {
-                const bool stage_it = !(R16_ABL & 1) || (p == p_first && cc == 0);
-                R16_T(7);
-                if (!(R16_ABL & 2)) __syncthreads();  // the previous slab has been consumed by both waves
-                R16_T(0);
-                if (stage_it) commit();
-                R16_T(1);
-                if (!(R16_ABL & 2)) __syncthreads();
-                R16_T(2);
-                // next stage in execution order (the last one re-requests itself: valid, cache-hot addresses)
-                int pn = p, ccn = cc + 1;
-                if (ccn == NCH) { ccn = 0; pn = p + 1; }
-                if (pn > p_last) { pn = p; ccn = cc; }
-                if (!(R16_ABL & 1)) issue(pn, ccn);
-                R16_T(3);
-                const bool more = !(pn == p && ccn == cc);
-                const int lon = kd_lo(pn);
-#pragma unroll 1
-                for (int kh = 0; kh < 3; ++kh) {
-                    // rows of this kh in execution order: kd = lo .. hi; the row after the last one is the first
-                    // row of the next kh, or of the next stage
-                    const float4 *after = (kh < 2) ? wrow(lo, kh + 1, cc) : (more ? wrow(lon, 0, ccn) : wrow(lo, 0, cc));
-                    if (lo == 0) row(r16_slot<0>{}, kh, wrow(0, kh, cc), hi >= 1 ? wrow(1, kh, cc) : after);
-                    if (lo <= 1 && hi >= 1) row(r16_slot<1>{}, kh, wrow(1, kh, cc), hi >= 2 ? wrow(2, kh, cc) : after);
-                    if (hi == 2) row(r16_slot<2>{}, kh, wrow(2, kh, cc), after);
-                }
-                R16_T(4);
-            }
+    load_b(ring[0], tap_of(0) * TAPF4);
+    load_b(ring[1], tap_of(1) * TAPF4);
+#pragma unroll
+    for (int it = 0; it < R_NLD; ++it) commit_piece(it, slab);
+    __syncthreads();
+    R16_T(0);
+    int buf = 0;
+    for (int p = p_first; p <= p_last; ++p) {
+        if (NCH == 1) {
+            stage(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+        } else {
+            stage(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+            stage(std::integral_constant<int, NCH - 1>{}, p, buf); buf ^= 1;
         }
-        R16_T(5);
-        if (!(R16_ABL & 16) || p - 1 == d1 - 1) { if (p - 1 >= d0) finish(p - 1); }
-        R16_T(6);
         // rotate the depth slots: what was output p (slot 1) becomes output (p+1) - 1 of the next plane, ...
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 4; ++m) {
             acc[2][m] = acc[1][m];
             acc[1][m] = acc[0][m];
             acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        R16_T(7);
     }
+    // the last output of a segment that ends at the volume's last plane has no plane behind it
+    if (p_last < d1) finish(p_last, p_last >= d0);
 #ifdef R16_STAMP
-    R16_T(7);
+    R16_T(3);
     if (lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&r16_stamp_sum[i], st_[i]);
+        for (int i = 0; i < 4; ++i) atomicAdd(&r16_stamp_sum[i], st_[i]);
         atomicAdd(&r16_stamp_sum[8], (unsigned long long)__builtin_amdgcn_s_memtime() - t0_);
         atomicAdd(&r16_stamp_sum[9], 1ull);
     }
@@ -436,8 +429,8 @@ int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long lo
     return az_launch_status();
 }
 
-// depth segments: one round of workgroups over the chip's 1024 slots (256 CUs x 4) if the patches allow it,
-// otherwise the split that minimises rounds x (planes staged per workgroup)
+// depth segments: one round of workgroups over the chip's 512 slots (256 CUs x 2) if the patches allow it,
+// otherwise the split that minimises rounds x (planes walked per workgroup)
 static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
     const long long patches = (long long)a.B * ((a.tiles_y + 1) / 2) * a.tiles_x;
     const char *e = getenv("AZ_ROLL_SEGLEN");
@@ -452,8 +445,8 @@ static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
         const int len = (a.Do + n - 1) / n;
         const int nn = (a.Do + len - 1) / len;
         if (nn != n) continue;
-        const long long rounds = (patches * n + 1023) / 1024;
-        const long long cost = rounds * (len + 2) * 3 + 4;  // +: fixed cost per workgroup
+        const long long rounds = (patches * n + 511) / 512;
+        const long long cost = rounds * (len + 2) * 3 + 2;  // +: fixed cost per workgroup
         if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
     }
 }
@@ -461,19 +454,17 @@ static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
 template <int CIN, int EPI>
 static int launch_roll(ConvArgs a, hipStream_t s) {
     roll_segments(a, a.nseg, a.seg_len);
-    {   // quarter of a stage in units of 4096 cycles: a stage is 27 x 48 x (CIN / 32) MFMAs of 16 cycles per wave,
-        // two waves per SIMD
-        const char *e = getenv("AZ_ROLL_STAGGER");
-        a.stagger = e ? atoi(e) : (27 * 48 * (CIN / 32) * 16 * 2 / 4) / 4096;
-    }
     const long long blocks = (long long)a.B * a.nseg * ((a.tiles_y + 1) / 2) * a.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI>), dim3((unsigned)blocks), dim3(128), 0, s, a);
+    // the kernel addresses one batch element of a tensor through a 32-bit buffer offset
+    if ((long long)a.Di * a.Hi * a.Wi * CIN * 4 >= 0xffffff00LL || a.ntiles * 256 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
+    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return az_launch_status();
 }
 
 int az_conv3d_roll_launch(const ConvArgs &a, int cin, int epi, hipStream_t s) {
-    if (cin == 32) return epi ? launch_roll<32, 1>(a, s) : launch_roll<32, 0>(a, s);
-    if (cin == 64) return epi ? launch_roll<64, 1>(a, s) : launch_roll<64, 0>(a, s);
+    const int e = epi ? 1 : (a.res ? 2 : 0);
+    if (cin == 32) return e == 1 ? launch_roll<32, 1>(a, s) : e == 2 ? launch_roll<32, 2>(a, s) : launch_roll<32, 0>(a, s);
+    if (cin == 64) return e == 1 ? launch_roll<64, 1>(a, s) : e == 2 ? launch_roll<64, 2>(a, s) : launch_roll<64, 0>(a, s);
     return AZ_EUNSUPPORTED;
 }

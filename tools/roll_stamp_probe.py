@@ -12,7 +12,7 @@ w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
 A = conv3d.DEFAULT_ARITH
 pk, ci, co = conv3d._pack_forward(w, 0, A.conv)
 pd = conv3d._pack(w, 32, 32, 27, 32 * 27, True, conv3d._layout(A.conv, 0, 32))
-names = ["barrier 1", "commit", "barrier 2", "issue", "rows", "rows->epilogue", "epilogue", "rotate+loop", "kernel", "waves"]
+names = ["prologue", "stage bodies", "stage barriers", "tail", "-", "-", "-", "-", "kernel", "waves"]
 for tag, fn in (("fwd+stats", lambda: conv3d._run_gather(x, pk, 0, ci, co, A.conv, stats=True)),
                 ("dgrad", lambda: conv3d._run_gather(x, pd, 0, 32, 32, A.conv, tag="dgrad"))):
     for _ in range(3): fn()
