@@ -92,7 +92,7 @@ def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=Non
     ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cm, cn, kh, kw)
     if ws_bytes < 0:
         raise RuntimeError(f"conv2d wgrad: unsupported channel counts {cm} x {cn}")
-    with overlap.scope(sink, gr, xr):
+    with overlap.scope(sink, gr, xr, gw):  # (gw too: the engine may drop it before the join, overlap.py)
         ws = xr.new_empty(ws_bytes // 4)
         with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
                             peak=PEAK_X6):
@@ -209,7 +209,7 @@ class _ConvS2Vol(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 g3 = conv3d._weight_grad(xv, gv, conv3d.CONV_S2, cin, cout, arith.wgrad, ctx.sink)
                 gw = g3.new_empty(cout, cin, 3, 3)
-                with overlap.scope(ctx.sink, g3):  # the slice reads g3 on the stream that wrote it
+                with overlap.scope(ctx.sink, g3, gw):  # the slice reads g3 on the stream that wrote it
                     gw.copy_(g3[:, :, 1])
         return gx, gw, None
 
@@ -261,7 +261,7 @@ class _ConvS2Patches(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 g2 = _wgrad(gr, patches, cout, kp, cout, 9 * cin, 1, 1, 1, tag="fe2d_first", sink=ctx.sink)  # [cout, 9cin,1,1]
                 gw = g2.new_empty(cout, cin, 3, 3)
-                with overlap.scope(ctx.sink, g2):
+                with overlap.scope(ctx.sink, g2, gw):
                     gw.copy_(g2.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2))
         gtok = gr.new_zeros(1) if ctx.needs_input_grad[3] else None
         return gx, gw, None, gtok, None

@@ -134,6 +134,7 @@ def _pack(weight, op_cin, op_cout, stride_out, stride_in, flip, precision, cache
     packed = torch.empty(n, dtype=torch.float32, device=w.device)
     _call("az_conv3d_pack_weights", _p(packed), _p(w), op_cin, op_cout, stride_out, stride_in,
           int(flip), precision, _stream())
+    packed.az_precision = precision  # the layout travels with the buffer: _run_gather launches what was packed
     if key is not None:
         _cache_put(_PACK_CACHE, key, (packed, weight), 256)
     return packed
@@ -201,11 +202,12 @@ def _run_gather(x, packed, mode, cin, cout, precision, scale=None, shift=None, r
         with profiler.scope(f"{tag}_costvol_m0_{cin}_{cout}", flops=_conv_flops(b, d * h * w, cin, cout, mode),
                             peak=_peak(precision)):
             _call("az_conv3d_fwd", _p(out), _p(x.fl), _p(x.fr), _p(packed), _p(scale), _p(shift),
-                  _p(residual), int(relu), mode, 1, precision, b, cin, cout, d, h, w, _stream())
+                  _p(residual), int(relu), mode, 1, getattr(packed, "az_precision", precision), b, cin, cout, d, h, w,
+                  _stream())
         return out
     b, d, h, w, c = _dims(x)
     assert c == cin, (c, cin)
-    precision = _layout(precision, mode, cout)  # `packed` was made by _pack_forward / _input_grad: same rule
+    precision = getattr(packed, "az_precision", precision)  # (BF16X6_R16 for the layers _layout() routes there)
     if mode == CONV_S2 and ((d % 2 and d != 1) or h % 2 or w % 2):
         raise RuntimeError("stride-2 layers need even D/H/W (as PSMNet's hourglass does; D = 1: a 2-D layer)")
     do, ho, wo = _out_dims(mode, d, h, w)
@@ -231,7 +233,7 @@ def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
     _, df, hf, wf, _ = _dims(fine)
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
     ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
-    with overlap.scope(sink, coarse, fine):
+    with overlap.scope(sink, coarse, fine, gw):  # (gw too: the engine may drop it before the join, overlap.py)
         ws = coarse.new_empty(ws_bytes // 4)
         with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
                             peak=_peak(precision)):
@@ -423,7 +425,7 @@ class _ConvLogits(torch.autograd.Function):
                     _call("az_conv3d_c1_dgrad", _p(gx), _p(g), _p(w), b, d, h, wd, _stream())
             if ctx.needs_input_grad[1]:
                 gw = torch.empty_like(w)
-                with overlap.scope(ctx.sink, x, g), \
+                with overlap.scope(ctx.sink, x, g, gw), \
                         profiler.scope("conv3d_c1_wgrad", bytes=4.0 * (x.numel() + g.numel()), bound="hbm"):
                     _call("az_conv3d_c1_wgrad", _p(gw), _p(x), _p(g), _p(scale), _p(shift), b, d, h, wd, _stream())
         return gx, gw, (g if ctx.has_add else None), None, None, None

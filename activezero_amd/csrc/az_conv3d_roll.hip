@@ -46,6 +46,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define R_SLAB_BYTES (R_SY * R_SX * R_VB)  // 34 560
 #define R_NQ (R_SY * R_SX * 8)             // 16-byte fp32 pieces of one plane chunk (8 per voxel)
 #define R_NLD ((R_NQ + 255) / 256)         // 6 per thread
+#ifndef R16_NOPART
+#define R16_NOPART 0  // timing-only build: BatchNorm partials not written
+#endif
 #define R_OOB 0xffffff00u                  // a buffer offset beyond every tensor: loads return 0, stores are dropped
 
 #define R_MF(ACC, A, B) __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
@@ -230,6 +233,24 @@ conv3d_roll_kernel(const ConvArgs a) {
     }
     const float floor_ = a.relu ? 0.f : -__builtin_inff();
 
+    // validity of the 16 accumulator elements of every lane for the BatchNorm partials -- the same for every depth:
+    // sixteen wave-wide lane masks (SGPR pairs), so that a masked sum costs one v_cndmask per element
+    unsigned long long st_lanes[16];
+    int st_n = 0;
+    if (EPI == 1) {
+        const int oh = ty0 + 4 * wm + (lane >> 4);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = oh < a.Ho && tx0 + 4 * m + r < a.Wo;
+                st_lanes[m * 4 + r] = __ballot(in);
+                st_n += in ? 1 : 0;
+            }
+        st_n += __shfl_xor(st_n, 16); st_n += __shfl_xor(st_n, 32);
+    }
+    const float st_inv = 1.f / (float)max(st_n, 1);
+
     // ---- epilogue of a finished output depth (slot 2); `ok`: the depth belongs to this segment ---------------
     auto finish = [&](int o, bool ok) {
         const int oh = ty0 + 4 * wm + (lane >> 4);  // row of the 4x4 tiles this lane's accumulator registers belong to
@@ -253,40 +274,34 @@ conv3d_roll_kernel(const ConvArgs a) {
             // raw output + BatchNorm partials at az_conv3d.hip's granularity: this wave's 4x16 half patch IS one
             // canonical tile: one (sum, centred M2) entry per channel, one count per tile
             const int tiy4 = 2 * tiy + wm;
-            unsigned okmask = 0;  // bit (m * 4 + r)
-            int nvalid = 0;
-            float sm = 0.f;
+            float sm = 0.f, m2 = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x4 vt = r16_quad_transpose(acc[2][m], lane);
                 const int owt = tx0 + 4 * m + (lane & 3);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vt), rs_out,
                                                        (row_ok && owt < a.Wo) ? row_off + (unsigned)owt * 128u : R_OOB, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool in = oh < a.Ho && tx0 + 4 * m + r < a.Wo;
-                    okmask |= in ? (1u << (m * 4 + r)) : 0u;
-                    nvalid += in ? 1 : 0;
-                    sm += in ? acc[2][m][r] : 0.f;
-                }
             }
-            nvalid += __shfl_xor(nvalid, 16); nvalid += __shfl_xor(nvalid, 32);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm += ((st_lanes[m * 4 + r] >> lane) & 1ull) ? acc[2][m][r] : 0.f;
             sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-            const float mean = sm / (float)max(nvalid, 1);
-            float m2 = 0.f;
+            const float mean = sm * st_inv;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dlt = acc[2][m][r] - mean;
-                    m2 += ((okmask >> (m * 4 + r)) & 1u) ? dlt * dlt : 0.f;
+                    const float dlt = ((st_lanes[m * 4 + r] >> lane) & 1ull) ? acc[2][m][r] - mean : 0.f;
+                    m2 = fmaf(dlt, dlt, m2);
                 }
             m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
+            const int nvalid = st_n;
             const bool tile_ok = ok && tiy4 < a.tiles_y;
             const unsigned tile_id = (unsigned)(((b * a.Dt + o) * a.tiles_y + tiy4) * a.tiles_x + tix);
             const unsigned ch = wn * 16 + (lane & 15);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(sm, m2)), rs_part,
-                                                  (tile_ok && lane < 16) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
+                                                  (tile_ok && lane < 16 && !R16_NOPART) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)nvalid), rs_cnt,
                                                   (tile_ok && lane == 0 && wn == 0) ? tile_id * 4u : R_OOB, 0, 0);
         }

@@ -23,8 +23,11 @@ convention:
     layer's node and the gate nothing reads the tensor: the gate's input buffer holds a single defined gradient,
     so the engine has nothing to add up early -- also when several forward passes of the same module are
     back-propagated together (each pass has its own gates, tail and join).
-  * Operands of side-stream kernels are kept referenced by the sink until the join, so the caching allocator
-    cannot hand their memory to later main-stream work while the side stream still reads it.
+  * Operands AND outputs of side-stream kernels are kept referenced by the sink until the join, so the caching
+    allocator cannot hand their memory to later main-stream work while the side stream still reads or writes it
+    (the outputs matter when the engine drops a weight gradient at once, `backward(inputs=[...])` on a subset:
+    tests/test_gpu_overlap.py::test_partial_backward_still_joins_the_side_stream failed with 1e34-sized BatchNorm
+    gradients before they were kept).
 Backstops, so that the scheme cannot silently corrupt memory outside the case it was designed around:
   * the first kernel a pass sends to the side stream registers `sink.join` as an end-of-backward callback of the
     autograd engine: the join also happens when the engine never reaches `_Tail` (`backward(inputs=[...])` or

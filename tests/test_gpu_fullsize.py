@@ -3,7 +3,7 @@ properties of the 3-D kernels where the CPU oracle would take minutes.
   * adjointness:  <conv(x), y> == <x, dgrad(y)>   (forward kernel vs input-gradient kernel)
   * bilinearity:  <conv_w(x), y> == <w, wgrad(x, y)>
   * train-mode BatchNorm: the normalised output has per-channel mean 0 / variance 1
-  * the fused cost-volume operand equals the materialised one
+  * the fused cost-volume operand equals the materialised one (to rounding: two kernels)
 One sample (B=1) keeps the memory footprint at a few GB."""
 import pytest
 import torch
@@ -55,8 +55,7 @@ def test_conv_adjoint_and_bilinear_identities_full_size(cin, cout, stride, dims)
     assert out.shape == raw_shape
     cot = _rand(*out.shape, seed=2)
     if stride == 1:
-        pk = conv3d._pack(w, cout, cin, 27, cin * 27, True, conv3d.DEFAULT_ARITH.conv)
-        gx = conv3d._run_gather(cot, pk, conv3d.CONV_S1, cout, cin, conv3d.DEFAULT_ARITH.conv)
+        gx = conv3d._input_grad(cot, w, conv3d.CONV_S1, cin, cout, conv3d.DEFAULT_ARITH.conv)
     else:
         pk = conv3d._pack(w, cout, cin, 27, cin * 27, False, conv3d.DEFAULT_ARITH.conv)
         gx = conv3d._run_gather(cot, pk, conv3d.DECONV_S2, cout, cin, conv3d.DEFAULT_ARITH.conv)
@@ -82,13 +81,15 @@ def test_deconv_identities_full_size():
     _same(lhs, _dot(w, gw), out, cot)
 
 
-def test_fused_cost_volume_full_size_bit_exact():
+def test_fused_cost_volume_full_size_equals_materialised():
     fl, fr = _rand(1, 136, 240, 32, seed=5), _rand(1, 136, 240, 32, seed=6)
     unit = psmnet_3.convbn_3d(64, 32, 3, 1, 1).to(DEV).eval()
     with torch.no_grad():
         y1 = conv3d.conv_bn(conv3d.LazyCostVolume(fl, fr, 48), unit[0], unit[1], conv3d.CONV_S1, True)
         y2 = conv3d.conv_bn(ops.cost_volume_ndhwc(fl, fr, 48), unit[0], unit[1], conv3d.CONV_S1, True)
-    assert torch.equal(y1, y2)
+    # (bit-equal while both ran on one kernel; since round 3 the materialised volume goes through the depth-rolling
+    #  16x16x32 kernel and the fused operand through the 32x32x16 one: same arithmetic, K blocks of 32 vs 16)
+    assert torch.allclose(y1, y2, rtol=1e-5, atol=2e-6 * float(y2.abs().max()))
 
 
 def test_classifier_identities_full_size():

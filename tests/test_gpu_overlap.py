@@ -146,7 +146,7 @@ def test_extractor_called_twice_with_one_sink_stays_in_order():
     torch.manual_seed(5)
     fe = sub.FeatureExtraction().to(DEV).train()
     ref = copy.deepcopy(fe)
-    a, b = torch.randn(1, 3, 128, 160, device=DEV), torch.randn(1, 3, 128, 192, device=DEV)  # unequal widths
+    a, b = torch.randn(1, 3, 256, 320, device=DEV), torch.randn(1, 3, 256, 384, device=DEV)  # unequal widths
     sink = overlap.begin(fe, a)
     arith = conv3d.DEFAULT_ARITH._replace(sink=sink)
     fa, fb = fe.forward_pair(a, b, arith)

@@ -206,7 +206,7 @@ def test_g10_loss_and_metrics(golden):
         close(o, g[f"obj{i}"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_g12_convgru(golden, tag):
     """oracle/raft_gru_oracle.py against the imported reference class (nets/raft/update.py:19-41)"""
     from oracle.raft_gru_oracle import ConvGRUOracle
@@ -219,7 +219,7 @@ def test_g12_convgru(golden, tag):
     ctx = [seeded((b, hidden, h, w), sd + 1 + i, -0.8, 0.8) for i in range(3)]
     xs = [seeded((b, n, h, w), sd + 4 + i, -1.7, 1.7) for i, n in enumerate(cx)]
     lat = lambda t: t[:, ::cs, ::ps, ::ps]
-    hr = hid.clone().requires_grad_(tag == "c")
+    hr = hid.clone().requires_grad_(tag == "d")
     out = mod(hr, *ctx, *xs)
     close(lat(out), g[f"{tag}_out32"], 1e-5, 1e-6)
     with torch.no_grad():
@@ -230,9 +230,9 @@ def test_g12_convgru(golden, tag):
         mod.double()
         close(lat(mod(hid.double(), *[c.double() for c in ctx], *[x.double() for x in xs])), g[f"{tag}_out64"], 1e-12, 1e-13)
         mod.float()
-    if tag == "c":
+    if tag == "d":
         (out * seeded((b, hidden, h, w), sd + 9)).sum().backward()
-        close(hr.grad, g["c_gh"], 1e-4, 1e-6)
+        close(hr.grad, g["d_gh"], 1e-4, 1e-6)
         for name in ("convz", "convr", "convq"):
-            close(getattr(mod, name).weight.grad[:16, :32], g[f"c_gw_{name}"], 1e-4, 2e-5)
-            close(getattr(mod, name).bias.grad, g[f"c_gb_{name}"], 1e-4, 2e-5)
+            close(getattr(mod, name).weight.grad[:16, :32], g[f"d_gw_{name}"], 1e-4, 2e-5)
+            close(getattr(mod, name).bias.grad, g[f"d_gb_{name}"], 1e-4, 2e-5)

@@ -38,7 +38,7 @@ def main():
         _call("az_bn3d_apply", _p(y), _p(x), _p(scale), _p(shift), None, 0, x.numel() // C, C, _stream())
         pk, cin, cout = conv3d._pack_forward(w, conv3d.CONV_S1, conv3d.DEFAULT_ARITH.conv)
         conv3d._run_gather(x, pk, conv3d.CONV_S1, cin, cout, conv3d.DEFAULT_ARITH.conv, stats=True)        # forward + BN partials
-        conv3d._run_gather(g, conv3d._pack(w, C, C, 27, C * 27, True, conv3d.DEFAULT_ARITH.conv), conv3d.CONV_S1, C, C, conv3d.DEFAULT_ARITH.conv, tag="dgrad")
+        conv3d._input_grad(g, w, conv3d.CONV_S1, C, C, conv3d.DEFAULT_ARITH.conv)
         conv3d._wgrad(g, x, 1, C, C, "conv", conv3d.DEFAULT_ARITH.wgrad)
         torch.cuda.synchronize()
     print("probe done", x.numel() * 4 / 1e6, "MB per tensor")

@@ -433,7 +433,8 @@ def g12_convgru():
     updates; plus value / gradient goldens of the fp32 path for the autograd route."""
     upd = _import_with_inert_stubs("nets.raft.update")
     out = {}
-    cases = [("a", 128, (128,), (34, 60), 2), ("b", 128, (128, 128), (17, 30), 2), ("c", 64, (32, 48), (9, 21), 1)]
+    cases = [("a", 128, (128,), (34, 60), 2), ("b", 128, (128, 128), (17, 30), 2), ("c", 64, (32, 48), (9, 21), 1),
+             ("d", 64, (64,), (12, 20), 1)]  # d: the gradient case (channel counts of the differentiable kernels)
     for tag, hidden, cx, (h, w), b in cases:
         mod = load_procedural(upd.ConvGRU(hidden, sum(cx)), f"g12{tag}.")
         for name in ("convz", "convr", "convq"):  # biases: procedural_tensor's 1-D rule is the BN-beta one
@@ -443,7 +444,7 @@ def g12_convgru():
         ctx = [seeded((b, hidden, h, w), sd + 1 + i, -0.8, 0.8) for i in range(3)]
         xs = [seeded((b, n, h, w), sd + 4 + i, -1.7, 1.7) for i, n in enumerate(cx)]
         # inputs are regenerated from the seeds by the test; outputs are stored on a channel / pixel lattice
-        cs, ps = (1, 1) if tag == "c" else (4, 2)
+        cs, ps = (1, 1) if tag in "cd" else (4, 2)
         lat = lambda t: t[:, ::cs, ::ps, ::ps]
         out[f"{tag}_meta"] = np.array([hidden, h, w, b, sd, cs, ps] + list(cx))
         with torch.no_grad():
@@ -461,14 +462,14 @@ def g12_convgru():
                 hh = mod(hh, *[c.double() for c in ctx], *[x.double() for x in xs])
             out[f"{tag}_iter4_64"] = lat(hh)
             mod.float()
-        if tag == "c":  # gradients of the fp32 path (the product's autograd route)
+        if tag == "d":  # gradients of the fp32 path (the product's autograd route)
             cot = seeded((b, hidden, h, w), sd + 9)
             hr = hid.clone().requires_grad_(True)
             (mod(hr, *ctx, *xs) * cot).sum().backward()
-            out["c_gh"] = hr.grad
+            out["d_gh"] = hr.grad
             for name in ("convz", "convr", "convq"):
-                out[f"c_gw_{name}"] = getattr(mod, name).weight.grad[:16, :32]
-                out[f"c_gb_{name}"] = getattr(mod, name).bias.grad
+                out[f"d_gw_{name}"] = getattr(mod, name).weight.grad[:16, :32]
+                out[f"d_gb_{name}"] = getattr(mod, name).bias.grad
     save("g12_convgru", **out)
 
 
