@@ -25,7 +25,8 @@
 //     all three kd are always computed (at the two ends of a segment a slot then holds a partial sum that is
 //     never stored: 4 % more MFMAs at 48 planes), the epilogue of the finished depth sits inside the stage with
 //     lane validity expressed through buffer-instruction bounds (no branch), so hipcc counts vmcnt exactly:
-//     nothing waits for the slab prefetch or for store acknowledgements before it has to.
+//     nothing waits for the slab prefetch or for store acknowledgements before it has to.  One A fragment read
+//     from LDS feeds the three kd (18 MFMAs).
 //
 // Arithmetic: az_common.h's bf16x6 product (exact 3-way RNE split, six MFMAs per block summed from zero,
 // largest terms first, one VALU add per block into the fp32 accumulator).  Accumulation order per output:
@@ -221,9 +222,6 @@ conv3d_roll_kernel(const ConvArgs a) {
         for (int p = 0; p < 3; ++p)
             bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, tap_f4 * 16 + p * 1024, 0));
     };
-    // execution order inside a stage: kd = 2 (order indices 0..8), kd = 1, kd = 0; packed tap of order index i
-    auto tap_of = [](int i) { return (2 - i / 9) * 9 + (i % 9); };
-
     // per-channel epilogue constants, loaded once (four consecutive channels per lane after the quad transpose)
     const int cq = wn * 16 + (lane & 12);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -307,11 +305,23 @@ conv3d_roll_kernel(const ConvArgs a) {
         }
     };
 
-    float4 ring[3][3];  // weights of order index i in ring[i % 3] (27 per stage: static slots), two taps ahead
-    f32x4 tq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto rotate = [&]() {  // what was output p (slot 1) becomes output (p+1) - 1 of the next plane, ...
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            acc[2][m] = acc[1][m];
+            acc[1][m] = acc[0][m];
+            acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
 
-    // ---- one stage: plane p, chunk CC, slab in buffer `buf`; straight-line ------------------------------------
-    auto stage = [&](auto cc_tag, int p, int buf) {
+    // ---- one stage: plane p, chunk CC, slab in buffer `buf`; straight-line -------------------------------------
+    // order: (kh, kw) outer, tile, kd inner: one A fragment load feeds the 18 MFMAs of the three kd (a third of the
+    // LDS reads of a kd-outer order: 1.47 -> 1.435 ms); the three kd weights of a (kh, kw) are double-buffered in
+    // registers, requested one (kh, kw) ahead (72 MFMAs).  Slot 2 is complete only at the end of the stage: its
+    // epilogue (and the rotation) open the NEXT plane's first stage, and its stores have that whole stage to land.
+    float4 wk[2][3][3];
+    f32x4 tq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto stage_s = [&](auto cc_tag, int p, int buf) {
         constexpr int CC = decltype(cc_tag)::value;
         constexpr bool LAST = (CC == NCH - 1);
         constexpr int CCN = (CC + 1) % NCH;
@@ -319,60 +329,60 @@ conv3d_roll_kernel(const ConvArgs a) {
         unsigned char *sn = slab + (buf ^ 1) * R_SLAB_BYTES;
         constexpr int wcur = CC * (2 * 3 * 64), wnxt = CCN * (2 * 3 * 64);
         const int pn = LAST ? p + 1 : p;
-        float4 a0[3], a1[3];
+        if (CC == 0) {
+            finish(p - 2, p - 2 >= d0);
+            rotate();
+        }
+        float4 av[2][3];
         auto load_a = [&](float4 (&aq)[3], int m, int kh, int kw) {
             const unsigned char *ap = sl + abase[kh & 1] + (kh * R_SX + 4 * m + kw) * R_VB;
 #pragma unroll
             for (int q = 0; q < 3; ++q) aq[q] = *reinterpret_cast<const float4 *>(ap + 64 * q);
         };
-        load_a(a0, 0, 0, 0);
+        load_a(av[0], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 27; ++i) {
-            const int kd = 2 - i / 9, kh = (i % 9) / 3, kw = i % 3;
+        for (int j = 0; j < 9; ++j) {
+            const int kh = j / 3, kw = j % 3;
             __builtin_amdgcn_sched_barrier(0);
-            // weights two taps ahead (the last two taps request the first two of the next stage)
-            if (i + 2 < 27) load_b(ring[(i + 2) % 3], wcur + tap_of(i + 2) * TAPF4);
-            else load_b(ring[(i + 2) % 3], wnxt + tap_of(i + 2 - 27) * TAPF4);
-            if (i == 0) {
-                __builtin_amdgcn_sched_barrier(0);  // request order as written: the slab behind this tap's weights
+            // the three kd weights of the next (kh, kw) -- of the next stage's first one at the end
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+                load_b(wk[(j + 1) & 1][kd], (j + 1 < 9 ? wcur + (kd * 9 + j + 1) * TAPF4 : wnxt + (kd * 9) * TAPF4));
+            if (j == 0) {
+                __builtin_amdgcn_sched_barrier(0);
                 issue(pn, CCN);
             }
 #pragma unroll
-            for (int m = 0; m < 4; m += 2) {
-                __builtin_amdgcn_sched_barrier(0);  // program order as written: A fragments one tile ahead
-                load_a(a1, m + 1, kh, kw);
+            for (int m = 0; m < 4; ++m) {
+                const int t = j * 4 + m;  // tile step of the stage: A buffers alternate
                 __builtin_amdgcn_sched_barrier(0);
-                // (the temporary carried into a step belongs to the tile before: tile 3 of the previous tap, which
-                //  for the first tap of a kd block is the previous kd's slot -- all static in this straight line;
-                //  a stage starts with a zero temporary)
-                if (m == 0) {
-                    if (i % 9 == 0) r16_step(tq[0], a0, ring[i % 3], acc[i == 0 ? 2 : kd + 1][3], tq[1]);
-                    else r16_step(tq[0], a0, ring[i % 3], acc[kd][3], tq[1]);
-                } else {
-                    r16_step(tq[0], a0, ring[i % 3], acc[kd][m - 1], tq[1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (m + 2 < 4) load_a(a0, m + 2, kh, kw);
-                else if (i + 1 < 27) load_a(a0, 0, ((i + 1) % 9) / 3, (i + 1) % 3);
-                __builtin_amdgcn_sched_barrier(0);
-                r16_step(tq[1], a1, ring[i % 3], acc[kd][m], tq[0]);
-                // the finished depth (kd = 2 of the plane's last chunk) leaves while kd = 1, 0 are multiplied
-                if (LAST && i == 9 && m == 0) {
+                if (m + 1 < 4) load_a(av[(t + 1) & 1], m + 1, kh, kw);
+                else if (j + 1 < 9) load_a(av[(t + 1) & 1], 0, (j + 1) / 3, (j + 1) % 3);
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const int st = t * 3 + kd;  // step of the stage: temporaries alternate
                     __builtin_amdgcn_sched_barrier(0);
-                    finish(p - 1, p - 1 >= d0);
+                    // the temporary carried in belongs to the step before: (m, kd-1), (m-1, 2) or the previous
+                    // (kh, kw)'s (3, 2); the stage starts with a zero temporary
+                    f32x4 &prev = kd > 0 ? acc[kd - 1][m] : (m > 0 ? acc[2][m - 1] : acc[2][3]);
+                    r16_step(tq[st & 1], av[t & 1], wk[j & 1][kd], prev, tq[(st + 1) & 1]);
                 }
-            }
-            // the next slab: one piece every other tap from tap 15 on (requested at tap 0)
-            if (i >= 15 && i < 15 + 2 * R_NLD && ((i - 15) & 1) == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                commit_piece((i - 15) / 2, sn);
+                if (j >= 5 && j < 8 && (m & 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    commit_piece((j - 5) * 2 + (m >> 1), sn);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc[0][3] += tq[1];  // the stage's last temporary
+        acc[2][3] += tq[1];  // the stage's last temporary (108 steps: the last one wrote tq[1])
         tq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // nine (kh, kw) per stage: the buffer the next stage's first weights landed in becomes buffer 0
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wk[0][kd][q] = wk[1][kd][q];
         R16_T(1);
-        __syncthreads();  // next slab written by all four waves; this one no longer read
+        __syncthreads();
         R16_T(2);
     };
 
@@ -380,8 +390,8 @@ conv3d_roll_kernel(const ConvArgs a) {
     // planes p_first .. p_last (those of d0-1 .. d1 inside the volume); plane p adds kd to output p + 1 - kd.
     const int p_first = max(d0 - 1, 0), p_last = min(d1, a.Di - 1);
     issue(p_first, 0);
-    load_b(ring[0], tap_of(0) * TAPF4);
-    load_b(ring[1], tap_of(1) * TAPF4);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) load_b(wk[0][kd], (kd * 9) * TAPF4);
 #pragma unroll
     for (int it = 0; it < R_NLD; ++it) commit_piece(it, slab);
     __syncthreads();
@@ -389,19 +399,15 @@ conv3d_roll_kernel(const ConvArgs a) {
     int buf = 0;
     for (int p = p_first; p <= p_last; ++p) {
         if (NCH == 1) {
-            stage(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+            stage_s(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
         } else {
-            stage(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
-            stage(std::integral_constant<int, NCH - 1>{}, p, buf); buf ^= 1;
-        }
-        // rotate the depth slots: what was output p (slot 1) becomes output (p+1) - 1 of the next plane, ...
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            acc[2][m] = acc[1][m];
-            acc[1][m] = acc[0][m];
-            acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            stage_s(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+            stage_s(std::integral_constant<int, NCH - 1>{}, p, buf); buf ^= 1;
         }
     }
+    // (output p-1 is finished at the top of stage p+1: the last processed plane's is still in slot 2)
+    finish(p_last - 1, p_last - 1 >= d0);
+    rotate();
     // the last output of a segment that ends at the volume's last plane has no plane behind it
     if (p_last < d1) finish(p_last, p_last >= d0);
 #ifdef R16_STAMP
