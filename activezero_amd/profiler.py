@@ -32,8 +32,9 @@ def joined():
 
 
 def start():
-    global _active
+    global _active, _side_depth, _side_pending
     _records.clear()
+    _side_depth, _side_pending = 0, False  # (a backward pass that died before its join leaves them set)
     _active = True
 
 
@@ -71,10 +72,10 @@ def stop():
 
 
 # profiler scope name -> kernel symbol in the rocprofv3 PMC summary
-_PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_m128_kernel<32, 1, 0>", "conv3d_gather_kernel<32, 32, 0, 1, 0, 1>",
-                                  "conv3d_gather_kernel<32, 32, 0, 1, 0, 0>"),
-              "dgrad_m0_32_32": ("conv3d_m128_kernel<32, 0, 0>", "conv3d_gather_kernel<32, 32, 0, 0, 0, 1>",
-                                 "conv3d_gather_kernel<32, 32, 0, 0, 0, 0>"),
+_PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_roll_kernel<32, 1>", "conv3d_m128_kernel<32, 1, 0>",
+                                  "conv3d_gather_kernel<32, 32, 0, 1, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 1, 0, 0>"),
+              "dgrad_m0_32_32": ("conv3d_roll_kernel<32, 0>", "conv3d_roll_kernel<32, 2>", "conv3d_m128_kernel<32, 0, 0>",
+                                 "conv3d_gather_kernel<32, 32, 0, 0, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 0, 0, 0>"),
               "conv_wgrad_s1_32_32": ("conv3d_wgrad_x6_kernel<32, 32, 1>", "conv3d_wgrad_kernel<32, 32, 1>")}
 
 
@@ -95,7 +96,10 @@ def pmc_traffic(scope_name, per_launch_work, pmc_json):
     probe_flops = 2.0 * 27 * 32 * 32 * data["tensor_bytes"] / (4 * 32)
     if not k or abs(probe_flops - per_launch_work) > 1e-6 * probe_flops:
         return None
-    return k["hbm_bytes"]
+    return {"hbm_bytes": k["hbm_bytes"], "read_bytes": k["read_bytes"], "write_bytes": k["write_bytes"],
+            "carried_from": "profiles/" + os.path.basename(pmc_json),
+            "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/kernel_probe.py at this launch "
+                    "shape on another box, units calibrated on bn_apply (a pure stream); not measured in this run"}
 
 
 def held_clock(scope_name, clock_json):
@@ -109,7 +113,8 @@ def held_clock(scope_name, clock_json):
     data = json.load(open(clock_json))["kernels"]
     for sym in _PMC_NAMES[scope_name]:
         if sym in data:
-            return data[sym]
+            return dict(data[sym], kernel=sym, carried_from="profiles/" + os.path.basename(clock_json),
+                        note="counter pass (tools/pmc_clock.sh) on another box; not measured in this run")
     return None
 
 
@@ -129,11 +134,17 @@ def roofline(prof, pmc_json=None, clock_json=None):
         peak, peak_basis = r["peak"]
     work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
     achieved = work / (r["avg_ms"] * 1e-3)
+    # the kernel with the largest total time OVERALL is usually one that shares the chip (side stream): named too
+    oname, orec = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    overall = {"kernel": oname, "total_ms": orec["total_ms"], "avg_ms": orec["avg_ms"], "launches": orec["launches"],
+               "overlapped": bool(orec.get("side_stream") or orec.get("beside_side_stream")),
+               "note": "event-to-event duration; overlapped = ran beside another stream's kernels, not a solo rate"}
     return {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak,
             "peak_basis": peak_basis, "unit": unit,
             "frac": achieved / peak,
             "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
             "selection": "largest total time among the kernels that run alone (not beside the side stream)",
+            "largest_total_time_overall": overall,
             "held_clock": held_clock(name, clock_json),
             "avg_launch_ms": r["avg_ms"],
             "launches_timed": r["launches"],

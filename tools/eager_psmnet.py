@@ -62,6 +62,11 @@ def _head(cost, maxdisp, h, w):  # psmnet_3.py:184-215 + psmnet_submodule_3.py:8
 def eager_forward(model, img_l, img_r):
     """model: activezero_amd.nets.psmnet.psmnet_3.PSMNet (its parameters / buffers are used and updated)."""
     fl, fr = _fe(model.feature_extraction, img_l), _fe(model.feature_extraction, img_r)
+    return eager_from_features(model, fl, fr, img_l.shape[-2:])
+
+
+def eager_from_features(model, fl, fr, size):
+    """psmnet_3.py:149-220: cost volume + 3-D aggregation + soft-argmin heads from the two feature maps"""
     cost = _cost_volume(fl, fr, model.maxdisp // 4)
     cost0 = model.dres0(cost)
     cost0 = model.dres1(cost0) + cost0
@@ -74,7 +79,7 @@ def eager_forward(model, img_l, img_r):
     cost1 = model.classif1(out1)
     cost2 = model.classif2(out2) + cost1
     cost3 = model.classif3(out3) + cost2
-    h, w = img_l.shape[-2:]
+    h, w = size
     pred3 = _head(cost3, model.maxdisp, h, w)
     if model.training:
         return pred3, _head(cost2, model.maxdisp, h, w), _head(cost1, model.maxdisp, h, w)
