@@ -411,6 +411,158 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
     }
 }
 
+// ---- bf16x6, stride 1: the same decomposition walked by FINE rows -------------------------------------------
+// conv3d_wgrad_x6_kernel walks coarse rows: per row it reads the coarse fragments once and the fine fragments of
+// all nine (kh, kw) taps -- 60 transposing LDS reads per 54 MFMAs, a third of the kernel's time in the ablation of
+// profiles/r02_clock_pipe_ablation.md section 7.  Fine row r meets coarse rows r+1, r, r-1 under kh = 0, 1, 2: walking
+// the FINE rows, one fragment triple of (row r, shift kw) feeds the three kh taps, and the three coarse rows sit in
+// a rolling LDS window: 36 reads per 54 MFMAs.  Staging per step is unchanged (one coarse row chunk, one fine row).
+template <int CM, int CN>
+__global__ void __launch_bounds__(64, 2)
+conv3d_wgrad_x6_fw_kernel(const WgArgs a) {
+    constexpr int WCH = X6_WCH, FW = WCH + 2;
+    constexpr int MT = CM / 32, NT = CN / 32, NCOMBO = 3 * MT * NT;
+    constexpr int NQA = WCH * 8, NLA = (NQA + 63) / 64;
+    constexpr int NQF = FW * 8, NLF = (NQF + 63) / 64;
+    __shared__ __attribute__((aligned(16))) unsigned short sa[3 * 3 * WCH * 32];  // [row mod 3][part][pos][32]
+    __shared__ __attribute__((aligned(16))) unsigned short sf[3 * FW * 32];       // [part][pos][32]
+
+    const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
+    const int grp = blockIdx.x / (8 * NCOMBO), rem = blockIdx.x % (8 * NCOMBO);
+    int combo = rem >> 3;
+    const int widx = grp * 8 + (rem & 7);
+    const int nt = combo % NT; combo /= NT;
+    const int mt = combo % MT;
+    const int kd = combo / MT;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tr_col = 16 * ((lane >> 4) & 1) + 4 * tp;
+    const int tr_row = 8 * (lane >> 5) + tq;
+    auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v) {
+        uint2 hi, mid, lo;
+        az_split3_bf16x4(v, hi, mid, lo);
+        *reinterpret_cast<uint2 *>(dst_part0) = hi;
+        *reinterpret_cast<uint2 *>(dst_part0 + part_stride) = mid;
+        *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = lo;
+    };
+    auto frag = [&](const unsigned short *img, int r0, int r1) -> bf16x8 {
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + r0 * 32 + tr_col));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + r1 * 32 + tr_col));
+        s16x8 v;
+        v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+        v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    for (long long item = widx; item < a.nitems; item += a.waves_per_combo) {
+        int wc, hs, cd, b;
+        wg_decode(a, item, wc, hs, cd, b);
+        const int fd = cd - 1 + kd;
+        if (fd < 0 || fd >= a.Df) continue;  // wave-uniform
+        const int cw0 = wc * WCH, fw0 = cw0 - 1;
+        const int h_beg = hs * a.hseg_rows, h_end = min((hs + 1) * a.hseg_rows, a.Hc);
+        const float *cbase = a.coarse + (((size_t)b * a.Dc + cd) * a.Hc) * a.Wc * CM + mt * 32;
+        const float *fbase = a.fine + (((size_t)b * a.Df + fd) * a.Hf) * a.Wf * CN + nt * 32;
+
+        // step r = fine row r; it needs coarse rows r-1 .. r+1 of this segment in the window: the step brings
+        // fine row r and coarse row r+1 (rows outside the segment / the plane are zero)
+        float4 pa[NLA], pf[NLF];
+        unsigned okbits = 0;
+        auto issue = [&](int r) {
+            okbits = 0;
+            const int ch = r + 1, chc = min(max(ch, 0), a.Hc - 1);
+            const bool ch_ok = ch >= h_beg && ch < h_end;
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                const int q = lane + 64 * it, pos = q >> 3, part = q & 7;
+                const int cw = cw0 + pos;
+                okbits |= ((q < NQA) && cw < a.Wc && ch_ok) ? (1u << it) : 0u;
+                pa[it] = *reinterpret_cast<const float4 *>(cbase + ((size_t)chc * a.Wc + min(cw, a.Wc - 1)) * CM + part * 4);
+            }
+            const int fhc = min(max(r, 0), a.Hf - 1);
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                const int q = lane + 64 * it, part = q & 7, lw = min(q >> 3, FW - 1);
+                const int fw = fw0 + lw, fwc = min(max(fw, 0), a.Wf - 1);
+                okbits |= ((q < NQF) && r == fhc && fw == fwc) ? (1u << (8 + it)) : 0u;
+                pf[it] = *reinterpret_cast<const float4 *>(fbase + ((size_t)fhc * a.Wf + fwc) * CN + part * 4);
+            }
+        };
+        auto commit = [&](int r) {
+            const int slot = (r + 1 + 3) % 3;
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                const int q = lane + 64 * it;
+                if (!((okbits >> it) & 1u)) pa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < NQA) split_store(&sa[(slot * 3 * WCH + (q >> 3)) * 32 + (q & 7) * 4], WCH * 32, pa[it]);
+            }
+#pragma unroll
+            for (int it = 0; it < NLF; ++it) {
+                const int q = lane + 64 * it;
+                if (!((okbits >> (8 + it)) & 1u)) pf[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < NQF) split_store(&sf[(q >> 3) * 32 + (q & 7) * 4], FW * 32, pf[it]);
+            }
+        };
+
+        __syncthreads();
+        // the window starts empty: rows h_beg-2, h_beg-1 (slots of r-1, r at the first step) are zero
+        for (int q = lane; q < 2 * 3 * WCH * 8; q += 64) {
+            const int sl = (q / (3 * WCH * 8) == 0) ? (h_beg - 2 + 3) % 3 : (h_beg - 1 + 3) % 3;
+            *reinterpret_cast<uint2 *>(&sa[sl * 3 * WCH * 32 + (q % (3 * WCH * 8)) * 4]) = make_uint2(0u, 0u);
+        }
+        issue(h_beg - 1);
+        for (int r = h_beg - 1; r <= h_end; ++r) {
+            __syncthreads();
+            commit(r);
+            __syncthreads();
+            if (r + 1 <= h_end) issue(r + 1);
+            if (r < 0 || r >= a.Hf) continue;  // a zero fine row adds nothing (wave-uniform)
+            // coarse fragments of rows r+1 (kh 0), r (kh 1), r-1 (kh 2): parts hi/mid/lo
+            bf16x8 af[3][3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned short *arow = sa + ((r + 1 - kh + 3) % 3) * 3 * WCH * 32;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[kh][p] = frag(arow + p * WCH * 32, tr_row, tr_row + 4);
+            }
+            const bool ok0 = r + 1 >= h_beg && r + 1 < h_end, ok1 = r >= h_beg && r < h_end, ok2 = r - 1 >= h_beg && r - 1 < h_end;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                bf16x8 bfr[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bfr[p] = frag(sf + p * FW * 32, tr_row + kw, tr_row + 4 + kw);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    if (!(kh == 0 ? ok0 : kh == 1 ? ok1 : ok2)) continue;  // coarse row outside the segment (wave-uniform)
+                    f32x16 c = acc[kh * 3 + kw];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh][2], bfr[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh][0], bfr[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh][1], bfr[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh][1], bfr[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh][0], bfr[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh][0], bfr[0], c, 0, 0, 0);
+                    acc[kh * 3 + kw] = c;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tap = kd * 9 + t;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int m = mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+            atomicAdd(&a.ws[((size_t)tap * CM + m) * CN + nt * 32 + row], acc[t][rg]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int cm, int cn) {
     const int idx = blockIdx.x * 256 + threadIdx.x;  // over [m][n][27]
@@ -456,7 +608,11 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
         if (order < 0) { const char *e = getenv("AZ_WGRAD_ORDER"); order = e ? atoi(e) : 1; }
         a.order = order;
     }
-    if (PREC == 1)
+    static int fine_walk = -1;  // AZ_WGRAD_FW=0: the coarse-row walk for the stride-1 layers too (A/B)
+    if (fine_walk < 0) { const char *e = getenv("AZ_WGRAD_FW"); fine_walk = e ? atoi(e) : 1; }
+    if (PREC == 1 && S == 1 && fine_walk)
+        hipLaunchKernelGGL((conv3d_wgrad_x6_fw_kernel<CM, CN>), dim3(a.waves_per_combo * NCOMBO), dim3(64), 0, s, a);
+    else if (PREC == 1)
         hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CM, CN, S>), dim3(a.waves_per_combo * NCOMBO),
                            dim3(64), 0, s, a);
     else

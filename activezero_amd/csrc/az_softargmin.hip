@@ -186,14 +186,18 @@ softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gou
                       const float *__restrict__ fwd_out, int d, int h, int w, int tiles_x) {
     extern __shared__ float smem[];
     float *tile = smem;
+    // gradient of the low-res tile: one PRIVATE image per wave (= per output row of the block), [wave][k][2 cell
+    // rows][SA_LX], written with plain stores -- within a wave every cell has exactly one writing lane -- and summed
+    // by the flush loop below.  (The four waves used to add into one shared image with ds_add_f32: 54 % of the
+    // kernel's wave cycles were SQ_WAIT_INST_LDS, profiles/r02_sq_softargmin_patch_reproj.md.)
     float *gtile = smem + d * SA_LY * SA_LX;
+    float *gmine = gtile + (threadIdx.x >> 6) * (d * 2 * SA_LX);
     const int H = 4 * h, W = 4 * w;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int b = blockIdx.y;
     const int ybase = ty * (SA_TY / 4) - 1, xbase = tx * (SA_TX / 4) - 1;
     const int ncell = d * SA_LY * SA_LX;
     sa_load_tile(tile, logits, b, d, h, w, ybase, xbase);
-    for (int e = threadIdx.x; e < ncell; e += blockDim.x) gtile[e] = 0.f;
     __syncthreads();
     const int Y = ty * SA_TY + (threadIdx.x >> 6), X = tx * SA_TX + (threadIdx.x & 63);
     const bool live = (X < W) && (Y < H);
@@ -262,23 +266,32 @@ softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gou
         if (r == 0 || edge_l || edge_r) {
             const float val = (r == 0) ? cell : (edge_l ? s_m1 : s_p1);
             const int col = (r == 0) ? cq : (edge_l ? cq - 1 : cq + 1);
-            float *gt = gtile + k * (SA_LY * SA_LX) + p.ly0 * SA_LX + col;
-#if defined(SA_DIAG) && (SA_DIAG & 1)
-            gt[0] = (1.f - p.wy1) * val; gt[SA_LX] = p.wy1 * val;
-#else
-            atomicAdd(gt, (1.f - p.wy1) * val);
-            atomicAdd(gt + SA_LX, p.wy1 * val);
-#endif
+            float *gt = gmine + k * (2 * SA_LX) + col;  // cell rows ly0 (slot 0) and ly0 + 1 (slot 1) of this wave
+            gt[0] = (1.f - p.wy1) * val;
+            gt[SA_LX] = p.wy1 * val;
         }
         acc0 = acc1;
     }
     __syncthreads();
+    // tile-local base cell row of each wave's output row (Y = SA_TY ty + wave; ybase = the tile's first cell row)
+    int ly0_of[SA_TY];
+#pragma unroll
+    for (int wv = 0; wv < SA_TY; ++wv) {
+        SaPix q;
+        sa_axis(ty * SA_TY + wv, ybase, q.ly0, q.wy1);
+        ly0_of[wv] = q.ly0;
+    }
     for (int e = threadIdx.x; e < ncell; e += blockDim.x) {
-        const float v = gtile[e];
-        if (v == 0.f) continue;
         const int lx = e % SA_LX;
         const int rr = e / SA_LX;
         const int ly = rr % SA_LY, k = rr / SA_LY;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < SA_TY; ++wv) {  // fixed order: the block's sum is deterministic
+            const int slot = ly - ly0_of[wv];
+            if (slot == 0 || slot == 1) v += gtile[(wv * d + k) * (2 * SA_LX) + slot * SA_LX + lx];
+        }
+        if (v == 0.f) continue;
         const int gy = min(max(ybase + ly, 0), h - 1);
         const int gx = min(max(xbase + lx, 0), w - 1);
 #if defined(SA_DIAG) && (SA_DIAG & 2)
@@ -292,7 +305,7 @@ softargmin_bwd_kernel(float *__restrict__ glogits, const float *__restrict__ gou
 static int sa_check(int B, int d, int h, int w) {
     if (!(B > 0 && d > 0 && h > 0 && w > 0)) return AZ_EINVAL;
     if (B > 65535) return AZ_EUNSUPPORTED;
-    if ((size_t)2 * d * SA_LY * SA_LX * sizeof(float) > 64 * 1024) return AZ_EUNSUPPORTED;
+    if (((size_t)d * SA_LY * SA_LX + (size_t)SA_TY * d * 2 * SA_LX) * sizeof(float) > 64 * 1024) return AZ_EUNSUPPORTED;
     return AZ_OK;
 }
 
@@ -318,7 +331,7 @@ extern "C" int az_softargmin_bwd(float *grad_logits, const float *grad_disp,
         return AZ_ELAUNCH;
     const int tiles_x = (4 * w + SA_TX - 1) / SA_TX, tiles_y = (4 * h) / SA_TY;
     hipLaunchKernelGGL(softargmin_bwd_kernel, dim3(tiles_x * tiles_y, B), dim3(256),
-                       (size_t)2 * d * SA_LY * SA_LX * sizeof(float), az_stream(stream),
+                       ((size_t)d * SA_LY * SA_LX + (size_t)SA_TY * d * 2 * SA_LX) * sizeof(float), az_stream(stream),
                        grad_logits, grad_disp, logits, reinterpret_cast<const float2 *>(stats), disp_fwd,
                        d, h, w, tiles_x);
     return az_launch_status();
