@@ -314,18 +314,33 @@ static bool pr_tiled_enabled() {
     if (on < 0) { const char *e = getenv("AZ_PATCH_TILED"); on = e ? atoi(e) : 1; }
     return on != 0;
 }
+template <int MODE, int PSM, int K>
+static bool pr_launch_tiled_k(double *acc, float *gdisp, const float *gloss, const float *L, const float *R,
+                              const float *disp, const uint8_t *mask, int B, int C, int H, int W, int ps, float sign,
+                              hipStream_t s);
 template <int MODE, int PSM>
 static bool pr_launch_tiled_ps(double *acc, float *gdisp, const float *gloss, const float *L, const float *R,
                                const float *disp, const uint8_t *mask, int B, int C, int H, int W, int ps, float sign,
                                hipStream_t s) {
-    constexpr int K = MODE == 0 ? 4 : 2;
+    static int kk = -1;
+    if (kk < 0) { const char *e = getenv("AZ_PATCH_K"); kk = e ? atoi(e) : 4; }  // 1: one pixel per thread (A/B: same forward time, slower backward)
+    if (kk == 1) return pr_launch_tiled_k<MODE, PSM, 1>(acc, gdisp, gloss, L, R, disp, mask, B, C, H, W, ps, sign, s);
+    return pr_launch_tiled_k<MODE, PSM, (MODE == 0 ? 4 : 2)>(acc, gdisp, gloss, L, R, disp, mask, B, C, H, W, ps, sign, s);
+}
+template <int MODE, int PSM, int K>
+static bool pr_launch_tiled_k(double *acc, float *gdisp, const float *gloss, const float *L, const float *R,
+                              const float *disp, const uint8_t *mask, int B, int C, int H, int W, int ps, float sign,
+                              hipStream_t s) {
     size_t lds = 0;
     const int tr = pr_band_rows(B, H, W, ps, K, &lds);
     if (tr <= 0) return false;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&patch_reproj_tiled_kernel<MODE, PSM, K>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) {
+            (void)hipGetLastError();  // (static + dynamic LDS must stay within the CU's 160 KB)
+            return false;
+        }
         attr_set = true;
     }
     const int nbands = (H + tr - 1) / tr;

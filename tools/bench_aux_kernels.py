@@ -53,7 +53,7 @@ out = ops.softargmin(lg)
 row("K6 `az_softargmin_fwd` (per head)", timeit(lambda: ops.softargmin(lg.detach())), 4.0 * B * (d * h * w + H * W), "VALU-issue bound: plane values in registers, one v_exp_f32 per disparity")
 go = torch.randn_like(out)
 glg = torch.empty_like(lg)
-row("K6 `az_softargmin_bwd` (per head)", timeit(lambda: ops._call("az_softargmin_bwd", glg.data_ptr(), go.data_ptr(), lg.data_ptr(), None, None, B, d, h, w, ops._stream())), 4.0 * B * (2 * d * h * w + H * W), "recompute + LDS/global float atomics")
+row("K6 `az_softargmin_bwd` (per head)", timeit(lambda: ops._call("az_softargmin_bwd", glg.data_ptr(), go.data_ptr(), lg.data_ptr(), None, None, B, d, h, w, ops._stream())), 4.0 * B * (2 * d * h * w + H * W), "recompute; per-wave private LDS gradient tiles, global float atomics")
 # K7 gather warp
 img = torch.randn(B, 1, H, W, device=dev)
 dsp = (8 * torch.rand(B, 1, H, W, device=dev)).requires_grad_()
@@ -64,7 +64,7 @@ pr = pl.roll(5, 3).contiguous()
 mask = torch.rand(B, 1, H, W, device=dev) < 0.9
 def k8f():
     return ops.patch_reprojection(pl, pr, dsp.detach(), mask, 11, want_vis=False)
-row("K8 `az_patch_reproj_fwd` (ps=11)", timeit(k8f), 4.0 * B * H * W * 3.25, "L1/L2-resident 12x12 window per pixel")
+row("K8 `az_patch_reproj_fwd` (ps=11)", timeit(k8f), 4.0 * B * H * W * 3.25, "band of rows at full width in LDS, four pixels per thread")
 loss, _, _ = ops.patch_reprojection(pl, pr, dsp, mask, 11, want_vis=False)
 def k8b():
     dsp.grad = None
