@@ -18,7 +18,7 @@ different `alt` variant; they are exported as explicit "not targeted" stubs so t
 """
 import torch
 
-from activezero_amd import _lib
+from activezero_amd import _lib, profiler
 from activezero_amd.ops import _call, _chk, _p, _stream
 
 
@@ -31,7 +31,8 @@ class _Volume(torch.autograd.Function):
         if f2.shape[:3] != f1.shape[:3]:
             raise RuntimeError("fmap1 / fmap2 must agree in batch, channels and height")
         corr = f1.new_empty(b, h, w1, w2)
-        with torch.cuda.device(f1.device):
+        with torch.cuda.device(f1.device), profiler.scope("corr1d_volume", flops=2.0 * b * h * w1 * w2 * c,
+                                                          bytes=4.0 * b * h * (c * (w1 + w2) + w1 * w2), bound="hbm"):
             _call("az_corr1d_volume", _p(corr), _p(f1), _p(f2), b, c, h, w1, w2, _stream())
         ctx.save_for_backward(f1, f2)
         return corr
@@ -44,7 +45,8 @@ class _Volume(torch.autograd.Function):
         w2 = f2.shape[3]
         g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
         g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(g.device):
+        with torch.cuda.device(g.device), profiler.scope("corr1d_volume_bwd", flops=4.0 * b * h * w1 * w2 * c,
+                                                         bytes=4.0 * b * h * (2 * c * (w1 + w2) + w1 * w2), bound="hbm"):
             _call("az_corr1d_volume_bwd", _p(g1), _p(g2), _p(g), _p(f1), _p(f2), b, c, h, w1, w2, _stream())
         return g1, g2
 

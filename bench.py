@@ -40,10 +40,12 @@ def parse():
     ap.add_argument("--height", type=int, default=H_IMG)
     ap.add_argument("--width", type=int, default=W_IMG)
     ap.add_argument("--maxdisp", type=int, default=MAXDISP)
-    ap.add_argument("--workload", choices=["supervised", "mixed"], default="supervised",
+    ap.add_argument("--workload", choices=["supervised", "mixed", "raft"], default="supervised",
                     help="supervised = BASELINE configs[1] (the headline metric); mixed = configs[2]/[3]: the "
                          "default.yaml iteration (train.py:220-432): sim step (disparity + temporal-IR patch "
-                         "reprojection loss) then real step (reprojection loss only), 6-channel PSMNet")
+                         "reprojection loss) then real step (reprojection loss only), 6-channel PSMNet; "
+                         "raft = configs[4]'s hot path: CorrBlock1D volume + pyramid at [B,256,H/4,W/4], then 22 x "
+                         "(4-level lookup + ConvGRU update at the 1/4 resolution), forward + backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager-steps", type=int, default=1,
                     help="timed steps of the same workload on stock PyTorch-ROCm operators (tools/eager_psmnet.py) "
@@ -307,6 +309,95 @@ def hbm_probe(device):
             "spec_GB/s": 8000.0}
 
 
+def raft_workload(args, rank, local_rank, world):
+    """BASELINE.json configs[4], the part of RAFT-Stereo that is on this path: the all-pairs
+    1-D correlation volume and its 4-level pyramid (nets/raft/corr.py:115-161) built ONCE from two [B,256,H/4,W/4]
+    feature maps, then raft_stereo.py:138-172's loop, 22 iterations of {lookup at the current coordinates, ConvGRU
+    update of the 1/4-resolution hidden state (update.py:19-41, hidden 128, input 256)}, forward + backward to the
+    feature maps and the GRU parameters.  The motion encoder / flow head (ordinary torch code, out of scope) are
+    replaced by fixed tensors: the 36 lookup channels enter the GRU input beside 220 constant context channels,
+    the coordinate update is the mean of the new state (detached, as RAFT detaches coords1)."""
+    from activezero_amd import dist as azdist, profiler
+    from activezero_amd.nets.raft.corr import CorrBlock1D
+    from activezero_amd.nets.raft.gru import ConvGRU
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(0 if args.single_device else local_rank)
+    device = torch.device("cuda", 0 if args.single_device else local_rank)
+    azdist.init(args.dist_backend)
+    hp = args.height + (-args.height) % 32
+    b, h, w, iters = args.batch, hp // 4, args.width // 4, 22
+    torch.manual_seed(1)
+    gru = ConvGRU(128, 256).to(device)
+    net = azdist.wrap(gru, device)
+    opt = torch.optim.Adam(gru.parameters(), lr=2e-4)
+    g = torch.Generator(device=device).manual_seed(azdist.rank_seed(4321, rank))
+    rnd = lambda *shape: torch.randn(*shape, device=device, generator=g)
+    f1, f2 = rnd(b, 256, h, w).requires_grad_(), rnd(b, 256, h, w).requires_grad_()
+    h0 = torch.tanh(rnd(b, 128, h, w))
+    cz, cr, cq = (0.5 * rnd(b, 128, h, w) for _ in range(3))
+    ctx = rnd(b, 220, h, w)
+    xs = torch.arange(w, device=device, dtype=torch.float32).view(1, 1, 1, w).expand(b, 1, h, w)
+    ys = torch.arange(h, device=device, dtype=torch.float32).view(1, 1, h, 1).expand(b, 1, h, w)
+    coords0 = torch.cat([xs, ys], 1).contiguous()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        f1.grad = f2.grad = None
+        corr_fn = CorrBlock1D(f1, f2, radius=4, num_levels=4)
+        state, coords, loss = h0, coords0 - 8.0, 0.0
+        for it in range(iters):
+            coords = coords.detach()
+            corr = corr_fn(coords)                                  # [B, 36, h, w]
+            state = net(state, cz, cr, cq, corr, ctx)
+            loss = loss + (0.9 ** (iters - 1 - it)) * state.abs().mean()   # sequence_loss-style weights
+            delta = state.mean(1, keepdim=True).detach()
+            coords = torch.cat([coords[:, :1] + delta, coords[:, 1:]], 1)  # stereo: x only
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    azdist.fence()
+    profiler.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    azdist.fence()
+    dt = time.perf_counter() - t0
+    prof = profiler.stop()
+    dt = azdist.max_over_ranks(dt, device)
+    if rank == 0:
+        vol = prof.get("corr1d_volume")
+        roof = None
+        if vol:
+            # K10: 2 B H W1 W2 C flop; HBM: both feature maps in, the volume out (SURVEY.md 8d)
+            nbytes = 4.0 * b * h * (2 * 256 * w + w * w)
+            roof = {"kernel": "corr1d_volume (az_corr1d.hip)", "bound": "hbm", "achieved": nbytes / 1e9 / (vol["avg_ms"] * 1e-3),
+                    "peak": 8000.0, "unit": "GB/s", "frac": nbytes / 1e9 / (vol["avg_ms"] * 1e-3) / 8000.0, "traffic": None,
+                    "avg_launch_ms": vol["avg_ms"], "per_launch_work": nbytes,
+                    "flops_per_launch": vol["flops"], "TFLOP/s": vol["flops"] / 1e12 / (vol["avg_ms"] * 1e-3),
+                    "note": "41 flop per byte moved: on the fp32 MFMA pipe (157 TFLOP/s) the contraction itself takes 0.10 ms, "
+                            "the 393 MB of operands and volume 0.05 ms at 8 TB/s -- priced against HBM; others: every scope of the step",
+                    "others": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]} for k, v in prof.items()
+                               if k != "corr1d_volume"}}
+        print(json.dumps({
+            "metric": "stereo pairs/sec (540x960) fwd+bwd, RAFT-Stereo correlation volume + 22 lookup/ConvGRU iterations",
+            "value": b * world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[4] hot path: CorrBlock1D on [B,256,{h},{w}] feature maps (volume + 4-level pyramid), "
+                                   f"{iters} x (lookup r=4 + ConvGRU(128, 256) update), fwd + loss + bwd + Adam, batch {b} per GPU; "
+                                   "motion encoder / flow head / extractors not included (out of scope)",
+                       "global_batch": b * world, "height": args.height, "width": args.width, "parallelism": f"dp{world}",
+                       "dist_backend": (args.dist_backend if world > 1 else None)},
+            "loss": float(loss.item()), "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
+            "roofline": roof, "cpu_baseline": None}), flush=True)
+    azdist.shutdown()
+
+
 def dry_run(args, rank, world):
     """The launch path of an N-rank run without a GPU: everything bench.py does around the step -- rendezvous from
     the torch.distributed.run environment, the world-size / backend assertions, per-rank synthetic data, the DDP
@@ -381,6 +472,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if args.dry_run:
         return dry_run(args, rank, world)
+    if args.workload == "raft":
+        return raft_workload(args, rank, local_rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.single_device:
