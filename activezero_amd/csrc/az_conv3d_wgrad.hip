@@ -580,7 +580,8 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
     // with its most loaded wave, so pick (row segments, waves per combo W) such that the item
     // count is (nearly) a multiple of W while W * NCOMBO stays close to the ~2048 resident
     // waves: score = balance * occupancy, >= 4 items per wave to amortise the per-item prologue.
-    const int slots = 256 * 8;
+    static int slots = -1;  // resident waves the launch may take (AZ_WGRAD_SLOTS: experiments with room left for the other stream)
+    if (slots < 0) { const char *e = getenv("AZ_WGRAD_SLOTS"); slots = e ? atoi(e) : 256 * 8; }
     const int wmax = max(8, (slots / NCOMBO) & ~7);
     const long long base_items = (long long)a.B * a.Dc * a.nwchunk;
     double best = -1.0;
