@@ -58,7 +58,8 @@ def parse():
                          "by default runs as eager_gpu.tuned (carried_from)")
     ap.add_argument("--no-stage-bench", action="store_true",
                     help="skip the cost-volume + 3-D aggregation + soft-argmin stage comparison (eager_stage)")
-    ap.add_argument("--cpu-sample", choices=["full", "crop"], default="crop")
+    ap.add_argument("--cpu-sample", choices=["full", "crop"], default="full",
+                    help="CPU baseline sample: one full-size pair (about 20 s on 16 cores) or the 256x512 crop scaled by the pixel ratio")
     ap.add_argument("--dist-backend", default="nccl",
                     help="rehearsal only: 'gloo' lets several ranks share ONE GPU (with --single-device)")
     ap.add_argument("--single-device", action="store_true",
@@ -138,8 +139,8 @@ def cpu_baseline(args):
       config1 -- BASELINE.json configs[0] exactly: one 256x512 pair, D=64, eval forward (SURVEY.md 8d);
       value   -- the metric's unit: one pair, fwd+loss+bwd, on the reference's training crop (256x512,
                  configs/config.py:9-10) at the full D=192, scaled to 544x960 pairs by the pixel ratio
-                 (every stage of the path is linear in H*W).  A full-size pair takes > 6 min on 16 cores,
-                 too long for a default run (--cpu-sample full times it anyway)."""
+                 (every stage of the path is linear in H*W) with --cpu-sample crop; the default times one FULL-size
+                 pair, unscaled (19.5 s on 16 cores, profiles/r03_bench_b4_cpu_full_sample.json)."""
     from oracle import psmnet_oracle as po
 
     # the GPU box exposes every host CPU (256) but one GPU's share is 16 cores; more
