@@ -622,6 +622,9 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
     return az_launch_status();
 }
 
+// all 27 taps per wave on 16x16x32 tiles, four waves sharing one staged set (az_conv3d_wgrad16.hip)
+int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int D, int H, int W, hipStream_t s);
+
 extern "C" long long az_conv3d_wgrad_workspace(int cm, int cn) {
     if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32) return AZ_EINVAL;
     return 27LL * cm * cn * (long long)sizeof(float);
@@ -644,6 +647,17 @@ extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long worksp
     a.coarse = coarse; a.fine = fine; a.ws = workspace;
     a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;
     int rc = AZ_EUNSUPPORTED;
+    {
+        static int r16 = -1;  // AZ_WGRAD_R16=0: the one-kd-per-wave kernels for the V0 layers too (A/B)
+        if (r16 < 0) { const char *e = getenv("AZ_WGRAD_R16"); r16 = e ? atoi(e) : 1; }
+        if (r16 && precision == 1 && stride == 1 && cm == 32 && cn == 32 && Dc == Df && Hc == Hf && Wc == Wf) {
+            rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, Dc, Hc, Wc, s);
+            if (rc != AZ_OK) return rc;
+            const int total = cm * cn * 27;
+            hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm, cn);
+            return az_launch_status();
+        }
+    }
 #define WG_CASE(M, N)                                                                        \
     if (cm == M && cn == N)                                                                  \
         rc = precision == 0                                                                  \
