@@ -425,7 +425,9 @@ class _ConvLogits(torch.autograd.Function):
                     _call("az_conv3d_c1_dgrad", _p(gx), _p(g), _p(w), b, d, h, wd, _stream())
             if ctx.needs_input_grad[1]:
                 gw = torch.empty_like(w)
-                with overlap.scope(ctx.sink, x, g, gw), \
+                # (scale / shift too: 32-float saved tensors that the engine frees right after this node -- the main
+                #  stream's next small allocation would overwrite them before the queued side-stream kernel reads them)
+                with overlap.scope(ctx.sink, x, g, gw, scale, shift), \
                         profiler.scope("conv3d_c1_wgrad", bytes=4.0 * (x.numel() + g.numel()), bound="hbm"):
                     _call("az_conv3d_c1_wgrad", _p(gw), _p(x), _p(g), _p(scale), _p(shift), b, d, h, wd, _stream())
         return gx, gw, (g if ctx.has_add else None), None, None, None

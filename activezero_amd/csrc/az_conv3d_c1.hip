@@ -294,8 +294,13 @@ c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const c1_f2 g2 = {r[j + 2 - kw], r[j + 2 - kw]};
-                            a01[t] = C1_FMA2(x01[j], g2, a01[t]);
-                            a23[t] = C1_FMA2(x23[j], g2, a23[t]);
+                            // (the broadcast factor FIRST: hipcc keeps the operand order, and v_pk_fma_f32 with the
+                            //  high register of a pair selected for src1 -- op_sel:[0,1,0], what an odd-numbered g
+                            //  register becomes in second place -- returns wrong values in lanes 48..63 while a wave of
+                            //  another kernel issues MFMAs on the same SIMD: tools/probes/pkfma_corun.hip,
+                            //  profiles/r03_pkfma_corun.md; tests/test_isa_lint_cpu.py keeps the form out of the library)
+                            a01[t] = C1_FMA2(g2, x01[j], a01[t]);
+                            a23[t] = C1_FMA2(g2, x23[j], a23[t]);
                         }
                     }
                 }
