@@ -263,6 +263,10 @@ int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
         if (score > best_score + 1e-9) { best_score = score; best = w; }
     }
     if (a.ncols < 128) best = (int)a.ncols;
+    if (const char *e = getenv("AZ_WGRAD_R16_WGS")) {  // experiment: fewer resident workgroups leave room for the other stream
+        const int cap = atoi(e);
+        if (cap > 0 && cap < best) best = cap;
+    }
     a.wgs = best;
     hipLaunchKernelGGL(conv3d_wgrad_r16_kernel, dim3(a.wgs), dim3(256), 0, s, a);
     return az_launch_status();
