@@ -14,6 +14,8 @@
 //   az_bn3d_bwd_finalize: fp64 merge -> dgamma, dbeta, and the two per-channel
 //      coefficients of the apply pass
 //   az_bn3d_bwd_apply: dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); optional dz out.
+#include <stdlib.h>
+
 #include "az_common.h"
 
 // Block-wide fp64 sum in two barriers: DPP/shuffle inside each wave, one LDS slot per wave, then every thread
@@ -228,21 +230,41 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
     const float4 mu = reinterpret_cast<const float4 *>(mean)[c4];
     const float4 is = reinterpret_cast<const float4 *>(invstd)[c4];
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-    for (long long v = (long long)blockIdx.x * VPB + vl; v < nvox; v += (long long)gridDim.x * VPB) {
-        const size_t i = (size_t)v * C4 + c4;
-        float4 g = bn_ld4<NT>(reinterpret_cast<const float4 *>(dy) + i);
-        const float4 xx = bn_ld4<NT>(reinterpret_cast<const float4 *>(x) + i);
+    auto body = [&](const float4 gin, const float4 xx, const float4 yin, float4 &t1, float4 &t2) {
+        float4 g = gin;
         if (relu) {
-            float4 yy;
+            float4 yy = yin;
             if (remask) yy = make_float4(fmaf(xx.x, sc.x, sh.x), fmaf(xx.y, sc.y, sh.y), fmaf(xx.z, sc.z, sh.z), fmaf(xx.w, sc.w, sh.w));
-            else yy = bn_ld4<NT>(reinterpret_cast<const float4 *>(y) + i);
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
-        s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-        s2.x += g.x * ((xx.x - mu.x) * is.x); s2.y += g.y * ((xx.y - mu.y) * is.y);
-        s2.z += g.z * ((xx.z - mu.z) * is.z); s2.w += g.w * ((xx.w - mu.w) * is.w);
+        t1.x += g.x; t1.y += g.y; t1.z += g.z; t1.w += g.w;
+        t2.x += g.x * ((xx.x - mu.x) * is.x); t2.y += g.y * ((xx.y - mu.y) * is.y);
+        t2.z += g.z * ((xx.z - mu.z) * is.z); t2.w += g.w * ((xx.w - mu.w) * is.w);
+    };
+    // two voxels per thread in flight (the grid is capped so that the partials stay L2-sized: bn_bwd_apply_kernel)
+    const long long stride = (long long)gridDim.x * VPB;
+    float4 u1 = make_float4(0, 0, 0, 0), u2 = make_float4(0, 0, 0, 0);
+    const float4 zero4 = make_float4(0, 0, 0, 0);
+    long long v = (long long)blockIdx.x * VPB + vl;
+    for (; v + stride < nvox; v += 2 * stride) {
+        const size_t i = (size_t)v * C4 + c4, i2 = (size_t)(v + stride) * C4 + c4;
+        const float4 ga = bn_ld4<NT>(reinterpret_cast<const float4 *>(dy) + i), gb = bn_ld4<NT>(reinterpret_cast<const float4 *>(dy) + i2);
+        const float4 xa = bn_ld4<NT>(reinterpret_cast<const float4 *>(x) + i), xb = bn_ld4<NT>(reinterpret_cast<const float4 *>(x) + i2);
+        float4 ya = zero4, yb = zero4;
+        if (relu && !remask) { ya = bn_ld4<NT>(reinterpret_cast<const float4 *>(y) + i); yb = bn_ld4<NT>(reinterpret_cast<const float4 *>(y) + i2); }
+        body(ga, xa, ya, s1, s2);
+        body(gb, xb, yb, u1, u2);
     }
+    if (v < nvox) {
+        const size_t i = (size_t)v * C4 + c4;
+        const float4 ga = bn_ld4<NT>(reinterpret_cast<const float4 *>(dy) + i), xa = bn_ld4<NT>(reinterpret_cast<const float4 *>(x) + i);
+        float4 ya = zero4;
+        if (relu && !remask) ya = bn_ld4<NT>(reinterpret_cast<const float4 *>(y) + i);
+        body(ga, xa, ya, s1, s2);
+    }
+    s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+    s2.x += u2.x; s2.y += u2.y; s2.z += u2.z; s2.w += u2.w;
     // block sum per channel quad: lanes with equal (lane % C4) through cross-lane shuffles, then the four waves through
     // 2 x 4 x C4 float4 of LDS.  (The first version staged all 256 threads' sums: 8 KB per block -- which does not fit
     // beside two workgroups of the 69-79 KB matrix kernels of the other stream, so this kernel, first in line after
@@ -300,30 +322,84 @@ bn_bwd_finalize_kernel(float *__restrict__ dgamma, float *__restrict__ dbeta,
     }
 }
 
+// `partial` given: the finalize step runs HERE, in every block's prologue, instead of in a kernel of its own -- the
+// reduce kernel then writes at most BN_BWD_PARTIAL_FLOATS floats of partials per statistic group (128 KB, L2-resident),
+// each block merges them (fp64 per thread, cross-lane, four waves through 2C floats of LDS) and block (0, g) also writes
+// coef / dgamma / dbeta.  One launch less per BatchNorm backward (85 per step), and the one that went away was a
+// 32-block kernel that, beside the other stream's matrix kernels, waited ~60 us for a free wave slot each time
+// (5 ms per step on the main stream, profiles/r03a_bench_b4_summary.md).
+#define BN_BWD_PARTIAL_FLOATS 32768
 template <int C, bool NT>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
                     const float4 *__restrict__ dy, const float4 *__restrict__ y,
                     const float4 *__restrict__ x, const float *__restrict__ mean,
-                    const float *__restrict__ invstd, const float *__restrict__ coef,
+                    const float *__restrict__ invstd, float *__restrict__ coef,
                     const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                    long long total4) {
+                    long long total4, const float *__restrict__ partial, int nblocks, const float *__restrict__ gamma,
+                    float *__restrict__ dgamma, float *__restrict__ dbeta, double nvox) {
     constexpr int C4 = C / 4;
     __shared__ float smu[C], sis[C], k0[C], k1[C], k2[C], ssc[C], ssh[C];
     const bool remask = relu && scale != nullptr;  // see bn_bwd_reduce_kernel
+    const int grp = blockIdx.y;
     {   // blockIdx.y = statistic group
-        const long long go = (long long)blockIdx.y * total4;
+        const long long go = (long long)grp * total4;
         dx += go; dy += go; x += go; if (relu && !remask) y += go; if (dz_out) dz_out += go;
-        mean += blockIdx.y * C; invstd += blockIdx.y * C; coef += blockIdx.y * C * 3;
-        if (remask) { scale += blockIdx.y * C; shift += blockIdx.y * C; }
+        mean += grp * C; invstd += grp * C; coef += grp * C * 3;
+        if (remask) { scale += grp * C; shift += grp * C; }
     }
     if (remask && threadIdx.x < C) { ssc[threadIdx.x] = scale[threadIdx.x]; ssh[threadIdx.x] = shift[threadIdx.x]; }
     if (threadIdx.x < C) {
         smu[threadIdx.x] = mean[threadIdx.x];
         sis[threadIdx.x] = invstd[threadIdx.x];
-        k0[threadIdx.x] = coef[threadIdx.x * 3 + 0];
-        k1[threadIdx.x] = coef[threadIdx.x * 3 + 1];
-        k2[threadIdx.x] = coef[threadIdx.x * 3 + 2];
+    }
+    if (partial == nullptr) {
+        if (threadIdx.x < C) {
+            k0[threadIdx.x] = coef[threadIdx.x * 3 + 0];
+            k1[threadIdx.x] = coef[threadIdx.x * 3 + 1];
+            k2[threadIdx.x] = coef[threadIdx.x * 3 + 2];
+        }
+    } else {
+        // one partial row = 2C floats = COLS float4; thread (r, j) sums column j of rows r, r + ROWS, ...
+        constexpr int COLS = C / 2, ROWS = 256 / COLS;
+        static_assert(COLS <= 64 && 64 % COLS == 0, "a partial row must tile a wave");
+        __shared__ float wsum[4][2 * C];
+        const int j = threadIdx.x % COLS, r = threadIdx.x / COLS, wave = threadIdx.x >> 6;
+        const bool writer = blockIdx.x == 0;
+        // block (0, 0) also needs the other groups' sums (dgamma / dbeta are summed over the groups)
+        const int g_lo = (writer && grp == 0) ? 0 : grp, g_hi = (writer && grp == 0) ? (int)gridDim.y : grp + 1;
+        double dg_tot = 0.0, db_tot = 0.0;
+        for (int g = g_lo; g < g_hi; ++g) {
+            const float4 *p4 = reinterpret_cast<const float4 *>(partial) + (size_t)g * nblocks * COLS;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int blk = r; blk < nblocks; blk += ROWS) {
+                const float4 v = p4[(size_t)blk * COLS + j];
+                a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+            }
+#pragma unroll
+            for (int off = COLS; off < 64; off <<= 1) {
+                a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+            }
+            __syncthreads();  // wsum may still be read (previous group)
+            if ((threadIdx.x & 63) < COLS) {
+                wsum[wave][4 * j + 0] = (float)a0; wsum[wave][4 * j + 1] = (float)a1;
+                wsum[wave][4 * j + 2] = (float)a2; wsum[wave][4 * j + 3] = (float)a3;
+            }
+            __syncthreads();
+            if (threadIdx.x < C) {
+                const int c = threadIdx.x;
+                const double sa = ((double)wsum[0][2 * c] + (double)wsum[1][2 * c]) + ((double)wsum[2][2 * c] + (double)wsum[3][2 * c]);
+                const double sb = ((double)wsum[0][2 * c + 1] + (double)wsum[1][2 * c + 1]) + ((double)wsum[2][2 * c + 1] + (double)wsum[3][2 * c + 1]);
+                db_tot += sa; dg_tot += sb;
+                if (g == grp) {  // dx = k0 * (dz - k1 - xhat * k2)
+                    k0[c] = gamma[c] * sis[c];
+                    k1[c] = (float)(sa / nvox);
+                    k2[c] = (float)(sb / nvox);
+                    if (writer) { coef[c * 3 + 0] = k0[c]; coef[c * 3 + 1] = k1[c]; coef[c * 3 + 2] = k2[c]; }
+                }
+            }
+        }
+        if (writer && grp == 0 && threadIdx.x < C) { dbeta[threadIdx.x] = (float)db_tot; dgamma[threadIdx.x] = (float)dg_tot; }
     }
     __syncthreads();
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
@@ -427,6 +503,19 @@ sum4_kernel(float4 *__restrict__ y, const float4 *__restrict__ a, const float4 *
 }
 
 #define BN_GRID(total) az_grid_for((total), 256)
+// finalize folded into the apply kernel's prologue (AZ_BN_BWD_FUSED=0: the three-kernel sequence, for A/B runs)
+static bool bn_bwd_fused() {
+    static const int on = [] { const char *e = getenv("AZ_BN_BWD_FUSED"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+static int bn_bwd_fused_blocks(int blocks, int C) {
+    const int cap = BN_BWD_PARTIAL_FLOATS / (2 * C);  // 512 / 256 / 128 reduce blocks for 32 / 64 / 128 channels
+    return blocks < cap ? blocks : cap;
+}
+static unsigned bn_bwd_apply_grid(long long total4) {
+    const unsigned g = az_grid_for(total4, 256);
+    return g < 1024u ? g : 1024u;  // every block re-reads the partials: 1024 x 128 KB of L2 traffic at most
+}
 // KERNEL<C, NT> for the three channel counts, NT chosen at run time
 #define BN_LAUNCH(KERNEL, C, NT, GRID, STREAM, ...)                                                             \
     do {                                                                                                        \
@@ -511,15 +600,24 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
     const long long need = az_bn3d_bwd_workspace(nvox, C);
     if (need < 0) return (int)need;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
-    const int blocks = (int)(need / (C * 2 * sizeof(float)));
+    int blocks = (int)(need / (C * 2 * sizeof(float)));
     const long long total4 = nvox * C / 4;
     hipStream_t s = az_stream(stream);
     const bool nt = total4 * 16 >= BN_NT_BYTES;
+    if (bn_bwd_fused()) {
+        blocks = bn_bwd_fused_blocks(blocks, C);
+        BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox);
+        BN_LAUNCH(bn_bwd_apply_kernel, C, nt, dim3(bn_bwd_apply_grid(total4)), s, (float4 *)dx, (float4 *)dz_out, (const float4 *)dy,
+                  (const float4 *)y, (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4,
+                  (const float *)workspace, blocks, gamma, dgamma, dbeta, (double)nvox);
+        return az_launch_status();
+    }
     BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef,
                        workspace, gamma, invstd, blocks, C, (double)nvox, 1);
     BN_LAUNCH(bn_bwd_apply_kernel, C, nt, dim3(BN_GRID(total4)), s, (float4 *)dx, (float4 *)dz_out, (const float4 *)dy,
-              (const float4 *)y, (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4);
+              (const float4 *)y, (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4,
+              (const float *)nullptr, 0, gamma, dgamma, dbeta, (double)nvox);
     return az_launch_status();
 }
 
@@ -632,16 +730,25 @@ static void bn2d_bwd_launch(float *dx, float *dz, float *dgamma, float *dbeta, f
                             const float *y, const float *x, const float *mean, const float *invstd,
                             const float *gamma, const float *scale, const float *shift, int relu, int groups,
                             long long nvox, hipStream_t s) {
-    const int blocks = bn2d_blocks(nvox, C);
-    float *partial = ws, *coef = ws + (size_t)groups * blocks * C * 2;
+    int blocks = bn2d_blocks(nvox, C);
+    float *partial = ws, *coef = ws + (size_t)groups * blocks * C * 2;  // (coef behind the UNCAPPED partial area)
+    const long long total4 = nvox * C / 4;
+    if (bn_bwd_fused()) {
+        blocks = bn_bwd_fused_blocks(blocks, C);
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<C, false>), dim3(blocks, groups), dim3(256), 0, s, partial, dy, y, x, mean,
+                           invstd, scale, shift, relu, nvox);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<C, false>), dim3(bn_bwd_apply_grid(total4), groups), dim3(256), 0, s, (float4 *)dx,
+                           (float4 *)dz, (const float4 *)dy, (const float4 *)y, (const float4 *)x, mean, invstd,
+                           coef, scale, shift, relu, total4, (const float *)partial, blocks, gamma, dgamma, dbeta, (double)nvox);
+        return;
+    }
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<C, false>), dim3(blocks, groups), dim3(256), 0, s, partial, dy, y, x, mean,
                        invstd, scale, shift, relu, nvox);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef, partial, gamma,
                        invstd, blocks, C, (double)nvox, groups);
-    const long long total4 = nvox * C / 4;
     hipLaunchKernelGGL((bn_bwd_apply_kernel<C, false>), dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)dx,
                        (float4 *)dz, (const float4 *)dy, (const float4 *)y, (const float4 *)x, mean, invstd,
-                       coef, scale, shift, relu, total4);
+                       coef, scale, shift, relu, total4, (const float *)nullptr, 0, gamma, dgamma, dbeta, (double)nvox);
 }
 
 /* backward of az_bn2d_fwd; dgamma/dbeta [C] are summed over the groups; dz_out may be NULL */
