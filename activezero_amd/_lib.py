@@ -50,6 +50,7 @@ _SIGS = {
     "az_conv3d_packed_floats": [_INT, _INT, _INT],
     "az_conv3d_pack_weights": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
     "az_conv3d_num_tiles": [_INT] * 5,
+    "az_conv3d_stats_tiles": [_INT] * 8,
     "az_conv3d_fwd": [_PTR] * 7 + [_INT] * 10 + [_PTR],
     "az_conv3d_fwd_stats": [_PTR] * 6 + [_INT] * 9 + [_PTR],
     "az_conv3d_wgrad_workspace": [_INT, _INT],
@@ -82,7 +83,7 @@ _SIGS = {
     "az_corr1d_lookup_fwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
     "az_corr1d_lookup_bwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
 }
-_RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_packed_floats": _LL,
+_RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_stats_tiles": _LL, "az_conv3d_packed_floats": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL,
             "az_bn3d_stats_tiles": _LL, "az_bn2d_workspace": _LL,
             "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL, "az_ir_pattern_workspace": _LL,

@@ -215,7 +215,9 @@ def _run_gather(x, packed, mode, cin, cout, precision, scale=None, shift=None, r
     flops = _conv_flops(b, do * ho * wo, cin, cout, mode)
     name = f"{tag}_m{mode}_{cin}_{cout}"
     if stats:
-        ntiles = _lib.lib().az_conv3d_num_tiles(mode, b, d, h, w)
+        ntiles = _lib.lib().az_conv3d_stats_tiles(mode, precision, b, cin, cout, d, h, w)
+        if ntiles <= 0:
+            raise RuntimeError(f"az_conv3d_stats_tiles: {ntiles}")
         part = x.new_empty(cout, ntiles, 2)
         cnt = x.new_empty(ntiles)
         with profiler.scope(name, flops=flops, peak=_peak(precision)):

@@ -674,6 +674,18 @@ extern "C" int az_conv3d_fwd(float *out, const float *in, const float *in2,
     return dispatch_mode<0>(a, mode, precision, cin, cout, src, az_stream(stream));
 }
 
+// rows of the partial buffers az_conv3d_fwd_stats fills when called with the same arguments (the depth-rolling
+// kernel of precision 2 writes one entry per depth SEGMENT and tile, the others one per output depth and tile)
+extern "C" long long az_conv3d_stats_tiles(int mode, int precision, int B, int cin, int cout, int Di, int Hi, int Wi) {
+    if (precision == 2) {
+        if (mode != 0 || cout != 32) return AZ_EUNSUPPORTED;
+        ConvArgs a{};
+        if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
+        return az_conv3d_roll_stats_tiles(a);
+    }
+    return az_conv3d_num_tiles(mode, B, Di, Hi, Wi);
+}
+
 extern "C" int az_conv3d_fwd_stats(float *out, float *partials, float *counts, const float *in,
                                    const float *in2, const float *packed_w, int mode, int src,
                                    int precision, int B, int cin, int cout, int Di, int Hi,
@@ -684,6 +696,7 @@ extern "C" int az_conv3d_fwd_stats(float *out, float *partials, float *counts, c
     ConvArgs a{};
     if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, src)) return e;
     a.in = in; a.in2 = in2; a.wp = packed_w; a.out = out; a.part = partials; a.cnt = counts;
-    a.ntiles = az_conv3d_num_tiles(mode, B, Di, Hi, Wi);
+    a.ntiles = az_conv3d_stats_tiles(mode, precision, B, cin, cout, Di, Hi, Wi);
+    if (a.ntiles < 0) return (int)a.ntiles;
     return dispatch_mode<1>(a, mode, precision, cin, cout, src, az_stream(stream));
 }

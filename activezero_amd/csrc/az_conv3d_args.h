@@ -26,6 +26,7 @@ int az_conv3d_m128_launch(const ConvArgs &a, int cin, int epi, int src, hipStrea
 // bf16x6 on the 16x16x32 MFMA, stride 1, 32 output channels, depth-rolling workgroups (az_conv3d_roll.hip);
 // weights in that kernel's own packed layout (az_conv3d_pack_r16 = az_conv3d_pack_weights precision 2)
 int az_conv3d_roll_launch(const ConvArgs &a, int cin, int epi, hipStream_t s);
+long long az_conv3d_roll_stats_tiles(const ConvArgs &a);  // rows of the BatchNorm partial buffers of an EPI-1 launch
 int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long long stride_out, long long stride_in,
                        int flip, hipStream_t s);
 

@@ -231,23 +231,24 @@ conv3d_roll_kernel(const ConvArgs a) {
     }
     const float floor_ = a.relu ? 0.f : -__builtin_inff();
 
-    // validity of the 16 accumulator elements of every lane for the BatchNorm partials -- the same for every depth:
-    // sixteen wave-wide lane masks (SGPR pairs), so that a masked sum costs one v_cndmask per element
-    unsigned long long st_lanes[16];
-    int st_n = 0;
-    if (EPI == 1) {
-        const int oh = ty0 + 4 * wm + (lane >> 4);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool in = oh < a.Ho && tx0 + 4 * m + r < a.Wo;
-                st_lanes[m * 4 + r] = __ballot(in);
-                st_n += in ? 1 : 0;
-            }
-        st_n += __shfl_xor(st_n, 16); st_n += __shfl_xor(st_n, 32);
-    }
-    const float st_inv = 1.f / (float)max(st_n, 1);
+    // validity of the 16 accumulator elements of every lane for the BatchNorm partials -- the same for every depth: the
+    // lane's row is inside the volume and element e = 4 m + r (its x offset in the patch) is left of the right edge,
+    // i.e. e < st_nv with ONE per-lane count (sixteen 64-bit lane masks in SGPRs made hipcc spill scalars into the stage)
+    int st_nv = 0;
+    if (EPI == 1) st_nv = (ty0 + 4 * wm + (lane >> 4) < a.Ho) ? min(max(a.Wo - tx0, 0), 16) : 0;
+    // BatchNorm partials (EPI 1): ONE entry per channel for the wave's 4x16 half patch over the whole depth segment.
+    // Every lane keeps running sums of its 16 accumulator elements about a shift of its own (the first valid value
+    // it sees: shifted-data algorithm, no cancellation in sum-of-squares minus squared-sum) -- 64 VALU instructions per
+    // finished plane and no cross-lane traffic; lanes and row groups are merged once, after the walk (Chan's formula).
+    // The first version reduced every plane to a (sum, centred M2) entry of its own (~100 VALU and four cross-lane sums
+    // per plane, 9 spilled registers, 97 920 partial rows per V0 layer for the finalize kernels to merge; this form: no
+    // spills, 4 080 rows, no pre-merge launch).  Both cost nothing measurable in the kernel itself: 1.42 ms with or
+    // without statistics (profiles/r03_roll_kernel_notes.md section 6 -- the 0.2 ms "epilogue gap" quoted earlier was
+    // the timing script measuring this kernel first, before the clocks had settled).
+    const int st_nl = st_nv;  // this lane's valid elements per plane
+    float st_k = 0.f, st_s1 = 0.f, st_s2 = 0.f;
+    int st_planes = 0;
+    bool st_first = true;
 
     // ---- epilogue of a finished output depth (slot 2); `ok`: the depth belongs to this segment ---------------
     auto finish = [&](int o, bool ok) {
@@ -269,10 +270,7 @@ conv3d_roll_kernel(const ConvArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, off, 0, 0);
             }
         } else {
-            // raw output + BatchNorm partials at az_conv3d.hip's granularity: this wave's 4x16 half patch IS one
-            // canonical tile: one (sum, centred M2) entry per channel, one count per tile
-            const int tiy4 = 2 * tiy + wm;
-            float sm = 0.f, m2 = 0.f;
+            // raw output; BatchNorm running sums (see st_k above)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x4 vt = r16_quad_transpose(acc[2][m], lane);
@@ -280,29 +278,44 @@ conv3d_roll_kernel(const ConvArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vt), rs_out,
                                                        (row_ok && owt < a.Wo) ? row_off + (unsigned)owt * 128u : R_OOB, 0, 0);
             }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sm += ((st_lanes[m * 4 + r] >> lane) & 1ull) ? acc[2][m][r] : 0.f;
-            sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
-            const float mean = sm * st_inv;
+            st_k = (ok && st_first) ? acc[2][0][0] : st_k;  // (element (0,0) is valid whenever any of the lane's is)
+            st_first = st_first && !ok;
+            st_planes += ok ? 1 : 0;
+            const int nv_p = ok ? st_nv : 0;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dlt = ((st_lanes[m * 4 + r] >> lane) & 1ull) ? acc[2][m][r] - mean : 0.f;
-                    m2 = fmaf(dlt, dlt, m2);
+                    const float dlt = (m * 4 + r < nv_p) ? acc[2][m][r] - st_k : 0.f;
+                    st_s1 += dlt;
+                    st_s2 = fmaf(dlt, dlt, st_s2);
                 }
-            m2 += __shfl_xor(m2, 16); m2 += __shfl_xor(m2, 32);
-            const int nvalid = st_n;
-            const bool tile_ok = ok && tiy4 < a.tiles_y;
-            const unsigned tile_id = (unsigned)(((b * a.Dt + o) * a.tiles_y + tiy4) * a.tiles_x + tix);
-            const unsigned ch = wn * 16 + (lane & 15);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(sm, m2)), rs_part,
-                                                  (tile_ok && lane < 16 && !R16_NOPART) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)nvalid), rs_cnt,
-                                                  (tile_ok && lane == 0 && wn == 0) ? tile_id * 4u : R_OOB, 0, 0);
         }
+    };
+
+    // after the walk: merge the lanes of a channel (the four row groups of the 16x16 C layout) and write the entry
+    auto flush_stats = [&]() {
+        float n = (float)(st_nl * st_planes);
+        float mean = n > 0.f ? st_k + st_s1 / n : 0.f;
+        float m2 = n > 0.f ? st_s2 - st_s1 * st_s1 / n : 0.f;
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            const float n_o = __shfl_xor(n, off), mean_o = __shfl_xor(mean, off), m2_o = __shfl_xor(m2, off);
+            const float nn = n + n_o;
+            const float dlt = mean_o - mean;
+            const float w_o = nn > 0.f ? n_o / nn : 0.f;
+            m2 = m2 + m2_o + dlt * dlt * n * w_o;
+            mean = mean + dlt * w_o;
+            n = nn;
+        }
+        const int tiy4 = 2 * tiy + wm;
+        const bool tile_ok = tiy4 < a.tiles_y;
+        const unsigned tile_id = (unsigned)(((b * a.nseg + seg) * a.tiles_y + tiy4) * a.tiles_x + tix);
+        const unsigned ch = wn * 16 + (lane & 15);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(n * mean, fmaxf(m2, 0.f))), rs_part,
+                                              (tile_ok && lane < 16 && !R16_NOPART) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, n), rs_cnt,
+                                              (tile_ok && lane == 0 && wn == 0) ? tile_id * 4u : R_OOB, 0, 0);
     };
 
     auto rotate = [&]() {  // what was output p (slot 1) becomes output (p+1) - 1 of the next plane, ...
@@ -410,6 +423,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     rotate();
     // the last output of a segment that ends at the volume's last plane has no plane behind it
     if (p_last < d1) finish(p_last, p_last >= d0);
+    if (EPI == 1) flush_stats();
 #ifdef R16_STAMP
     R16_T(3);
     if (lane == 0) {
@@ -472,9 +486,17 @@ static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
     }
 }
 
+// rows of the BatchNorm partial buffers of a roll launch: one per (batch, depth segment, 4x16 tile)
+long long az_conv3d_roll_stats_tiles(const ConvArgs &a) {
+    int nseg, seg_len;
+    roll_segments(a, nseg, seg_len);
+    return (long long)a.B * nseg * a.tiles_y * a.tiles_x;
+}
+
 template <int CIN, int EPI>
 static int launch_roll(ConvArgs a, hipStream_t s) {
     roll_segments(a, a.nseg, a.seg_len);
+    if (EPI == 1) a.ntiles = (long long)a.B * a.nseg * a.tiles_y * a.tiles_x;
     const long long blocks = (long long)a.B * a.nseg * ((a.tiles_y + 1) / 2) * a.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     // the kernel addresses one batch element of a tensor through a 32-bit buffer offset

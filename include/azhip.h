@@ -147,8 +147,11 @@ long long az_conv3d_packed_floats(int cin, int cout, int precision);
 int az_conv3d_pack_weights(float *packed, const float *w, int cin, int cout,
                            long long stride_out, long long stride_in, int flip, int precision,
                            void *stream);
-/* number of wavefront tiles a launch uses = rows of the BN partial buffers */
+/* number of wavefront tiles a launch uses = rows of the BN partial buffers of the precision 0 / 1 kernels */
 long long az_conv3d_num_tiles(int mode, int B, int Di, int Hi, int Wi);
+/* rows of the BN partial buffers az_conv3d_fwd_stats fills for these arguments (precision 2, the depth-rolling
+ * kernel, writes one entry per depth segment and tile; otherwise = az_conv3d_num_tiles) */
+long long az_conv3d_stats_tiles(int mode, int precision, int B, int cin, int cout, int Di, int Hi, int Wi);
 /* out = relu?( conv(in)*scale[c] + shift[c] + residual ); scale/shift/residual may be
  * NULL (eval-mode BatchNorm folded into scale/shift, or a plain convolution). */
 int az_conv3d_fwd(float *out, const float *in, const float *in2, const float *packed_w,

@@ -21,7 +21,13 @@ def timeit(fn, n=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 gf = 2.0 * 27 * C * C * B * D * H * W / 1e9
+# (the first kernel timed after start-up runs ~10 % slower than the same kernel timed later -- clocks / power state --,
+#  which for two rounds looked like a 0.2 ms cost of the BatchNorm-partials epilogue: warm up with 40 launches first)
+for _ in range(40):
+    conv3d._run_gather(g, pd, conv3d.CONV_S1, C, C, A.conv, tag="dgrad")
+torch.cuda.synchronize()
 for name, fn in (("fwd+stats", lambda: conv3d._run_gather(x, pk, conv3d.CONV_S1, ci, co, A.conv, stats=True)),
+                 ("fwd plain", lambda: conv3d._run_gather(x, pk, conv3d.CONV_S1, ci, co, A.conv)),
                  ("dgrad", lambda: conv3d._run_gather(g, pd, conv3d.CONV_S1, C, C, A.conv, tag="dgrad")),
                  ("wgrad", lambda: conv3d._wgrad(g, x, 1, C, C, "conv", A.wgrad))):
     ms = timeit(fn)
