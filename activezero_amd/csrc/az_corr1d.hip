@@ -9,14 +9,24 @@
 //            x = coords[b,0,h,w1] / 2^lvl + (k - r), zero outside, the align_corners=True
 //            convention of bilinear_sampler (corr.py:132-151)
 //
-// The three dense contractions (volume, d/d f1, d/d f2) are one strided batched GEMM on
-// fp32 MFMA:  D[m][n] = scale * sum_k A(k,m) * B(k,n), every operand addressed through
-// (k-stride, m|n-stride), so NCHW feature maps and the [w1][w2] volume are read in place:
+// The three dense contractions (volume, d/d f1, d/d f2) are one strided batched GEMM,
+//   D[m][n] = scale * sum_k A(k,m) * B(k,n), every operand addressed through (k-stride, m|n-stride), so NCHW
+// feature maps and the [w1][w2] volume are read in place:
 //   volume : m=w1, n=w2, k=c   A=f1, B=f2
 //   d f1   : m=w1, n=c,  k=w2  A=G,  B=f2
 //   d f2   : m=w2, n=c,  k=w1  A=G,  B=f1
-// Workgroup = 4 waves, 64x64 output tile, K chunks of 32 staged in LDS; each wave owns a
-// 32x32 accumulator (v_mfma_f32_32x32x2_f32: lane = column, the two K slices = lane halves).
+// on the bf16x6 arithmetic of the rest of the library (exact 3-way bf16 split of both operands, six
+// v_mfma_f32_32x32x16_bf16 per 16-deep block summed from zero, az_common.h): bgemm_x6_kernel.  Workgroup = 4 waves,
+// 64x64 output tile (a 32x32 accumulator per wave), K chunks of 32.  A thread fetches 8 consecutive k of one row of
+// each operand -- eight loads that are each coalesced across the lanes when the row index is the unit-stride one
+// (feature maps), two 16-byte loads when k is (the volume's last axis) --, splits them and writes one 16-byte piece
+// per part: LDS holds [part][row][32 k] bf16 with an 80-byte row pitch (16 lanes of a fragment read cover the 64
+// banks once).  Chunk s+1 travels global -> registers under the MFMAs of chunk s; one 30 KB buffer, so that five
+// workgroups share a CU: the kernel is bound by HBM latency, which occupancy hides and a one-chunk prefetch does not.  (Rounds 1-2 ran these GEMMs on v_mfma_f32_32x32x2_f32 with scalar LDS
+// staging: 0.45 ms for the volume at [4,256,136,240], 11 % of its HBM bound; bgemm_tn_kernel is kept for
+// AZ_CORR_FP32=1.)
+#include <stdlib.h>
+
 #include "az_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -80,10 +90,132 @@ bgemm_tn_kernel(const GemmArgs g) {
     }
 }
 
+// ---- bf16x6 version -------------------------------------------------------------------------------------
+#define GX_PITCH 80                      // bytes per (row, part): 32 k x bf16 + 16 pad
+#define GX_PART (G_TM * GX_PITCH)        // one part of one operand tile
+#define GX_OPER (3 * GX_PART)            // one operand tile: 15 360 B
+#define GX_BUF (2 * GX_OPER)             // A + B: 30 720 B per buffer
+template <bool A_KFAST, bool B_KFAST>
+__global__ void __launch_bounds__(256, 4)
+bgemm_x6_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[GX_BUF];
+    const int batch = blockIdx.z;
+    const int b = batch / g.H, h = batch - b * g.H;
+    const float *A = g.A + b * g.bA0 + h * g.bA1;
+    const float *B = g.B + b * g.bB0 + h * g.bB1;
+    float *D = g.D + b * g.bD0 + h * g.bD1;
+    const int m0 = blockIdx.y * G_TM, n0 = blockIdx.x * G_TN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = lane & 31, half = lane >> 5;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int sr = threadIdx.x & 63, kg = threadIdx.x >> 6;  // staging role: tile row, group of 8 k
+    // 16-byte loads along k need aligned rows (true for the volume axis of the shapes the model uses)
+    const bool a_vec = A_KFAST && (g.sAm % 4 == 0) && (g.bA0 % 4 == 0) && (g.bA1 % 4 == 0) && (g.K % 4 == 0);
+    const bool b_vec = B_KFAST && (g.sBn % 4 == 0) && (g.bB0 % 4 == 0) && (g.bB1 % 4 == 0) && (g.K % 4 == 0);
+    // operands through buffer resources over this (b, h) slab: the per-lane byte offset of the thread's row is computed
+    // once, the k offset travels in the scalar offset / immediate, validity is an out-of-range offset (no 64-bit
+    // address arithmetic and no branches per element: the kernel is VALU-issue bound in its staging)
+    const unsigned OOB = 0xffffff00u;
+    auto slab_bytes = [&](long long sk, long long sr_stride, int R) {
+        const long long last = (long long)(g.K - 1) * sk + (long long)(R - 1) * sr_stride + 1;
+        return (unsigned)(last * 4 < 0xfffffff0LL ? last * 4 : 0xfffffff0LL);
+    };
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, slab_bytes(g.sAk, g.sAm, g.M), 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, slab_bytes(g.sBk, g.sBn, g.N), 0x00020000);
+    const unsigned ra_off = (m0 + sr < g.M) ? (unsigned)((long long)(m0 + sr) * g.sAm * 4) : OOB;
+    const unsigned rb_off = (n0 + sr < g.N) ? (unsigned)((long long)(n0 + sr) * g.sBn * 4) : OOB;
+    float xa[8], xb[8];
+    auto fetch = [&](float (&x)[8], decltype(rs_a) rs, unsigned row_off, long long sk, bool kfast, bool vec, int k0) {
+        const int kk = k0 + kg * 8;  // wave-uniform
+        if (kfast && vec) {
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ u = __builtin_amdgcn_raw_buffer_load_b128(rs, kk < g.K ? row_off : OOB, kk * 4, 0);
+            const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rs, kk + 4 < g.K ? row_off : OOB, kk * 4 + 16, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] = __uint_as_float(u[j]); x[4 + j] = __uint_as_float(v[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                x[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, kk + j < g.K ? row_off : OOB,
+                                                                            (int)((long long)(kk + j) * sk * 4), 0));
+        }
+    };
+    auto commit = [&](const float (&x)[8], unsigned char *oper) {
+        uint2 h0, m0_, l0, h1, m1, l1;
+        az_split3_bf16x4(make_float4(x[0], x[1], x[2], x[3]), h0, m0_, l0);
+        az_split3_bf16x4(make_float4(x[4], x[5], x[6], x[7]), h1, m1, l1);
+        unsigned char *dst = oper + sr * GX_PITCH + kg * 16;
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4 *>(dst + GX_PART) = make_uint4(m0_.x, m0_.y, m1.x, m1.y);
+        *reinterpret_cast<uint4 *>(dst + 2 * GX_PART) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    };
+    az_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    fetch(xa, rs_a, ra_off, g.sAk, A_KFAST, a_vec, 0);
+    fetch(xb, rs_b, rb_off, g.sBk, B_KFAST, b_vec, 0);
+    for (int k0 = 0; k0 < g.K; k0 += G_TK) {
+        commit(xa, lds);
+        commit(xb, lds + GX_OPER);
+        __syncthreads();
+        if (k0 + G_TK < g.K) {  // the next chunk travels while this one is multiplied
+            fetch(xa, rs_a, ra_off, g.sAk, A_KFAST, a_vec, k0 + G_TK);
+            fetch(xb, rs_b, rb_off, g.sBk, B_KFAST, b_vec, k0 + G_TK);
+        }
+        const unsigned char *ta = lds + (wm + row) * GX_PITCH + half * 16;
+        const unsigned char *tb = lds + GX_OPER + (wn + row) * GX_PITCH + half * 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 aq[3], bq[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                aq[p] = *reinterpret_cast<const float4 *>(ta + p * GX_PART + q * 32);
+                bq[p] = *reinterpret_cast<const float4 *>(tb + p * GX_PART + q * 32);
+            }
+            az_mfma6_now(acc, aq, bq);
+        }
+        __syncthreads();  // (single buffer: five workgroups per CU hide the HBM latency that one chunk of prefetch
+                          //  distance cannot; the double-buffered version with two per CU ran 0.33 ms, latency-bound)
+    }
+    // C layout of the 32x32 MFMA: lane = column n, register r = row (r & 3) + 8 (r >> 2) + 4 half
+    const int n = n0 + wn + row;
+    if (n < g.N) {
+        if (g.sDm == 1) {  // rows contiguous in memory: four at a time
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int m = m0 + wm + 8 * r4 + 4 * half;
+                float *dst = D + (long long)n * g.sDn + m;
+                if (m + 3 < g.M && (reinterpret_cast<size_t>(dst) & 15) == 0) {
+                    *reinterpret_cast<float4 *>(dst) = make_float4(acc[4 * r4] * g.scale, acc[4 * r4 + 1] * g.scale,
+                                                                   acc[4 * r4 + 2] * g.scale, acc[4 * r4 + 3] * g.scale);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (m + i < g.M) dst[i] = acc[4 * r4 + i] * g.scale;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < g.M) D[(long long)m * g.sDm + (long long)n * g.sDn] = acc[r] * g.scale;
+            }
+        }
+    }
+}
+
 static int launch_gemm(const GemmArgs &g, int batches, hipStream_t s) {
     if (batches <= 0 || batches > 65535) return AZ_EUNSUPPORTED;
     dim3 grid((g.N + G_TN - 1) / G_TN, (g.M + G_TM - 1) / G_TM, batches);
-    hipLaunchKernelGGL(bgemm_tn_kernel, grid, dim3(256), 0, s, g);
+    static const int fp32 = [] { const char *e = getenv("AZ_CORR_FP32"); return e ? atoi(e) : 0; }();
+    if (fp32) {
+        hipLaunchKernelGGL(bgemm_tn_kernel, grid, dim3(256), 0, s, g);
+        return az_launch_status();
+    }
+    const bool ak = g.sAk == 1 && g.sAm != 1, bk = g.sBk == 1 && g.sBn != 1;
+    if (ak && bk) hipLaunchKernelGGL((bgemm_x6_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (ak) hipLaunchKernelGGL((bgemm_x6_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (bk) hipLaunchKernelGGL((bgemm_x6_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((bgemm_x6_kernel<false, false>), grid, dim3(256), 0, s, g);
     return az_launch_status();
 }
 
