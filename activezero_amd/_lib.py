@@ -43,6 +43,11 @@ _SIGS = {
     "az_bn2d_fwd": [_PTR] * 12 + [_LL, _INT, _INT, _LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR, _PTR, _LL, _PTR],
     "az_conv2d_stats_tiles": [_INT] * 4,
     "az_conv2d_fwd_stats": [_PTR] * 5 + [_INT] * 11 + [_PTR],
+    "az_conv2d_roll_packed_floats": [_INT] * 2,
+    "az_conv2d_roll_pack": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _PTR],
+    "az_conv2d_roll_fwd": [_PTR] * 6 + [_INT] * 6 + [_PTR],
+    "az_conv2d_roll_stats_rows": [_INT] * 6,
+    "az_conv2d_roll_fwd_stats": [_PTR] * 5 + [_INT] * 6 + [_PTR],
     "az_bn2d_bwd": [_PTR] * 5 + [_LL] + [_PTR] * 8 + [_INT, _INT, _LL, _INT, _PTR],
     "az_disp_loss_fwd": [_PTR] * 6 + [_C.c_float, _C.c_float, _C.c_longlong, _PTR],
     "az_disp_loss_bwd": [_PTR] * 8 + [_C.c_float, _C.c_float, _PTR, _PTR] + [_C.c_float] * 3 + [_C.c_longlong, _PTR],
@@ -83,7 +88,7 @@ _SIGS = {
     "az_corr1d_lookup_fwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
     "az_corr1d_lookup_bwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
 }
-_RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_stats_tiles": _LL, "az_conv3d_packed_floats": _LL,
+_RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_stats_tiles": _LL, "az_conv2d_roll_packed_floats": _LL, "az_conv2d_roll_stats_rows": _LL, "az_conv3d_packed_floats": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL,
             "az_bn3d_stats_tiles": _LL, "az_bn2d_workspace": _LL,
             "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL, "az_ir_pattern_workspace": _LL,

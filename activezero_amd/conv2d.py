@@ -9,12 +9,16 @@ triplet image made per call (memoised between no_grad forwards).
 
     layer geometry                         forward                     input gradient            weight gradient
     3x3 / 1x1 / 3x5, stride 1, "same"      az_conv2d_fwd               az_conv2d_fwd, flipped    az_conv2d_wgrad
+    3x3 d1 with 32/64 -> 32/64 channels    az_conv2d_roll_fwd          the same, flipped         az_conv2d_wgrad
+       (firstconv[1..2], layer1, layer2: the batch-walking kernel of az_conv2d_roll.hip; AZ_CONV2D_ROLL=0: off)
     3x3 stride 2, 32/64 channels           3-D gather kernel, mode 1   mode 2 (transposed)       3-D wgrad kernel, stride 2
        (layer2.0.conv1; the image is a depth-1 volume)
     3x3 stride 2 on a 3/6-channel image    az_im2col_s2k3 + 1x1        1x1 flipped + az_col2im   1x1 wgrad on the patches
        (firstconv.0)
     1x1 stride 2 (layer2.0.downsample)     subsample + 1x1             (autograd of the slice)   1x1 wgrad
 """
+import os
+
 import torch
 
 from . import _lib, conv3d, overlap, profiler
@@ -57,6 +61,45 @@ def _pack(weight, cin, cout, ci_real, co_real, s_out, s_in, kh, kw, flip, cache=
 
 def _up(n, m):
     return (n + m - 1) // m * m
+
+
+_ROLL2D = os.environ.get("AZ_CONV2D_ROLL", "1") != "0"
+
+
+def _roll_ok(xr, cin, cout, kh, kw, dil, res=None):
+    """the layer is one az_conv2d_roll.hip takes: 3x3, dilation 1, 32 / 64 channels on both sides, dense tensors"""
+    return (_ROLL2D and kh == 3 and kw == 3 and dil == 1 and cin in (32, 64) and cout in (32, 64) and xr.shape[-1] == cin
+            and (res is None or res.shape[-1] == cout))
+
+
+def _pack_roll(weight, cin, cout, s_out, s_in, flip):
+    w = _chk(weight.detach().contiguous(), "weight")
+    packed = torch.empty(int(_lib.lib().az_conv2d_roll_packed_floats(cin, cout)), dtype=torch.float32, device=w.device)
+    _call("az_conv2d_roll_pack", _p(packed), _p(w), cin, cout, s_out, s_in, int(flip), _stream())
+    return packed
+
+
+def _run_roll(xr, packed, cin, cout, scale=None, shift=None, res=None, relu=False, tag="conv2d"):
+    b, h, w, _ = xr.shape
+    out = xr.new_empty(b, h, w, cout)
+    with profiler.scope(f"{tag}_3x3d1_{cin}_{cout}", flops=2.0 * 9 * cin * cout * b * h * w, peak=PEAK_X6):
+        _call("az_conv2d_roll_fwd", _p(out), _p(xr), _p(packed), _p(scale), _p(shift), _p(res), int(relu), b, h, w,
+              cin, cout, _stream())
+    return out
+
+
+def _run_roll_stats(xr, packed, cin, cout, stats):
+    b, h, w, _ = xr.shape
+    out = xr.new_empty(b, h, w, cout)
+    nrows = int(_lib.lib().az_conv2d_roll_stats_rows(stats.groups, b, h, w, cin, cout))
+    if nrows <= 0:
+        raise RuntimeError(f"az_conv2d_roll_stats_rows: {nrows}")
+    part, cnt = xr.new_empty(stats.groups, cout, nrows, 2), xr.new_empty(stats.groups, nrows)
+    with profiler.scope(f"conv2d_3x3d1_{cin}_{cout}", flops=2.0 * 9 * cin * cout * b * h * w, peak=PEAK_X6):
+        _call("az_conv2d_roll_fwd_stats", _p(out), _p(part), _p(cnt), _p(xr), _p(packed), stats.groups, b, h, w,
+              cin, cout, _stream())
+    stats.part, stats.cnt, stats.tiles = part, cnt, nrows
+    return out
 
 
 def _run(xr, packed, cin, cout, kh, kw, dil, scale=None, shift=None, res=None, relu=False, tag="conv2d"):
@@ -127,11 +170,16 @@ class _ConvSame(torch.autograd.Function):
         cout, cin, kh, kw = weight.shape
         xr = _chk(rows(x), "x")
         with torch.cuda.device(x.device):
-            pk = _pack(weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False)
-            if stats is not None and (kh, kw) in ((3, 3), (1, 1)) and xr.shape[0] % stats.groups == 0:
-                y = _run_stats(xr, pk, cin, cout, kh, kw, dil, stats)  # + the BatchNorm partials of y (bn2d.Partials)
+            want_stats = stats is not None and (kh, kw) in ((3, 3), (1, 1)) and xr.shape[0] % stats.groups == 0
+            if _roll_ok(xr, cin, cout, kh, kw, dil):
+                pk = _pack_roll(weight, cin, cout, cin * 9, 9, False)
+                y = _run_roll_stats(xr, pk, cin, cout, stats) if want_stats else _run_roll(xr, pk, cin, cout)
             else:
-                y = _run(xr, pk, cin, cout, kh, kw, dil)
+                pk = _pack(weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False)
+                if want_stats:
+                    y = _run_stats(xr, pk, cin, cout, kh, kw, dil, stats)  # + the BatchNorm partials of y (bn2d.Partials)
+                else:
+                    y = _run(xr, pk, cin, cout, kh, kw, dil)
         ctx.save_for_backward(xr, weight)
         ctx.dil = dil
         ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero tensor
@@ -150,9 +198,13 @@ class _ConvSame(torch.autograd.Function):
         gx = gw = None
         with torch.cuda.device(gy.device):
             if ctx.needs_input_grad[0]:  # the same convolution, taps flipped, channel roles swapped
-                pk = _pack(weight, cout, cin, cout, cin, kh * kw, cin * kh * kw, kh, kw, True)
                 sk = _chk(rows(gskip), "grad_skip") if gskip is not None else None
-                gx = image(_run(gr, pk, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
+                if _roll_ok(gr, cout, cin, kh, kw, dil, sk):
+                    pk = _pack_roll(weight, cout, cin, 9, cin * 9, True)
+                    gx = image(_run_roll(gr, pk, cout, cin, res=sk, tag="dgrad2d"))
+                else:
+                    pk = _pack(weight, cout, cin, cout, cin, kh * kw, cin * kh * kw, kh, kw, True)
+                    gx = image(_run(gr, pk, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
             if ctx.needs_input_grad[1]:
                 gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil, sink=ctx.sink)
         return gx, gw, None, None, None, None

@@ -1,0 +1,402 @@
+// K13r -- the 3x3, stride-1, dilation-1 Conv2d layers of the feature extractor with 32 or 64 input AND output
+// channels (reference nets/psmnet/psmnet_submodule_3.py:92-147: firstconv[1..2], layer1, layer2) and their input
+// gradients, on the machinery of the depth-rolling 3-D kernel (az_conv3d_roll.hip) with the BATCH as the walk axis:
+//
+//   * a workgroup owns an 8x16 (y, x) patch and WALKS the images of its statistic group: image p+1 is fetched, split
+//     into its bf16 triplet and written to the other half of a double-buffered LDS slab while image p is multiplied;
+//     the per-workgroup costs that bound az_conv2d.hip on these small layers -- first slab with the full memory
+//     latency in front of it, weight ring refill, descriptor set-up, the drain of the epilogue stores -- are paid
+//     once per (patch, group) instead of once per (patch, image), and a stage (image x 32-channel chunk: 216 MFMAs per
+//     wave) is ONE basic block with exact vmcnt bookkeeping (validity through buffer-instruction bounds);
+//   * v_mfma_f32_16x16x32_bf16, four waves = four 4x8-voxel quarters of the patch, each for all 32 output channels of
+//     the launch's channel group (2 M tiles x 2 N tiles = 16 accumulator registers): an A fragment read from LDS
+//     feeds both N tiles (12 MFMAs) -- with one N tile per wave, as in the 3-D kernel where the three kd share the
+//     fragment, a 2-D stage would need 3 KB of LDS reads per 96 matrix cycles on every SIMD: all of the LDS bandwidth;
+//   * 64 output channels = two channel groups in the grid (the slab is staged once per group: the split is hidden in
+//     the MFMA stream either way);
+//   * BatchNorm partials (EPI 1): per-lane running sums about a per-lane shift, one row per (wave quarter, group
+//     segment), in az_bn2d_fwd's layout [group][cout][rows][2] / [group][rows].
+// Arithmetic: az_common.h's bf16x6 product; accumulation order per output: 32-channel chunk, kh, kw.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "az_roll_common.h"
+
+struct C2RArgs {
+    const float *in;    // [G*N, H, W, CIN] dense channels-last
+    const float *wp;    // packed [cout/32][tap 9][CIN/32][n16 2][part 3][lane 64][8 bf16]
+    float *out;         // [G*N, H, W, out_cs]
+    const float *scale, *shift, *res;  // optional epilogue operands (res: pixel stride res_cs floats)
+    float *part, *cnt;  // EPI 1: [G][cout][rows][2], [G][rows]
+    int G, N, H, W;     // statistic groups, images per group
+    int cout, out_cs, res_cs;
+    int tiles_yb, tiles_x;  // 8-row patch rows, 16-column patch columns
+    int nseg, seg_len;      // image segments per group
+    int rows;               // partial rows per group = nseg * tiles_yb * tiles_x * 4
+    int relu;
+};
+
+// EPI: 0 = y = relu?(acc * scale + shift), 2 = the same + residual, 1 = raw output + BatchNorm partials
+template <int CIN, int EPI>
+__global__ void __launch_bounds__(256, 2)
+conv2d_roll_kernel(const C2RArgs a) {
+    constexpr int NCH = CIN / 32;
+    constexpr int TAPF4 = NCH * 2 * 3 * 64;  // float4 per tap of one channel group: [tap][cc][n16][part][lane]
+    __shared__ __attribute__((aligned(16))) unsigned char slab[2 * R_SLAB_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 1, wc = wv & 1;  // this wave's quarter: rows 4 wr .., columns 8 wc ..
+
+    // ---- block -> (channel group, statistic group, segment, patch): contiguous chunk of the linear order per XCD ----
+    int lin = blockIdx.x;
+    {
+        const int nblk = gridDim.x, xcd = blockIdx.x & 7, q8 = nblk >> 3, r8 = nblk & 7;
+        lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    }
+    const int ngrp = a.cout >> 5;
+    const int cg = lin % ngrp; lin /= ngrp;
+    const int tix = lin % a.tiles_x; lin /= a.tiles_x;
+    const int tiy = lin % a.tiles_yb; lin /= a.tiles_yb;
+    const int seg = lin % a.nseg;
+    const int g = lin / a.nseg;
+    const int d0 = seg * a.seg_len, d1 = min(d0 + a.seg_len, a.N);  // images [d0, d1) of group g
+    const int ty0 = tiy * R_TY, tx0 = tix * R_TX;
+    const int ih0 = ty0 - 1, iw0 = tx0 - 1;
+    const int ch0 = cg * 32;
+
+    const unsigned in_bytes = (unsigned)a.N * a.H * a.W * CIN * 4u, out_bytes = (unsigned)a.N * a.H * a.W * a.out_cs * 4u;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in) + (size_t)g * (in_bytes / 4), 0, in_bytes, 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)g * (out_bytes / 4), 0, out_bytes, 0x00020000);
+    const unsigned res_bytes = (unsigned)a.N * a.H * a.W * a.res_cs * 4u;
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(EPI == 2 ? a.res + (size_t)g * (res_bytes / 4) : a.in), 0, EPI == 2 ? res_bytes : 0u, 0x00020000);
+    const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.part : a.out, 0,
+                                                           EPI == 1 ? (unsigned)((size_t)a.G * a.cout * a.rows * 8) : 0u, 0x00020000);
+    const auto rs_cnt = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.cnt : a.out, 0,
+                                                          EPI == 1 ? (unsigned)((size_t)a.G * a.rows * 4) : 0u, 0x00020000);
+
+    f32x4 acc[2][2];  // [M tile: columns 4 m .. of the quarter][N tile: channels 16 n ..]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging: one image chunk = 10 x 18 pixels x 32 channels fp32 -> bf16 triplets in LDS (az_conv3d_roll.hip) ----
+    u32x4 pre[R_NLD];
+    auto issue = [&](int p, int cc) {
+        int sy = 0, sx = tid >> 3;
+        if (sx >= R_SX) { sx -= R_SX; ++sy; }
+#pragma unroll
+        for (int it = 0; it < R_NLD; ++it) {
+            const int ih = ih0 + sy, iw = iw0 + sx;
+            const bool ok = (tid + 256 * it < R_NQ) && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W &&
+                            (unsigned)p < (unsigned)a.N;
+            const unsigned off = (unsigned)((p * a.H + ih) * a.W + iw) * (CIN * 4) + cc * 128 + (tid & 7) * 16;
+            pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : R_OOB, 0, 0);
+            sx += 14; ++sy;
+            if (sx >= R_SX) { sx -= R_SX; ++sy; }
+        }
+    };
+    auto commit_piece = [&](int it, unsigned char *dstbuf) {
+        const bool live = (tid + 256 * it < R_NQ);
+        const int ite = (it > 0 && !live) ? it - 1 : it;
+        const int vox = (tid >> 3) + 32 * ite;
+        const int sy = vox / R_SX, sx = vox - sy * R_SX;
+        const int j = tid & 7;
+        u32x4 raw = pre[it];
+        if (it > 0 && 256 * it + 255 >= R_NQ) {
+            raw[0] = live ? raw[0] : pre[it - 1][0]; raw[1] = live ? raw[1] : pre[it - 1][1];
+            raw[2] = live ? raw[2] : pre[it - 1][2]; raw[3] = live ? raw[3] : pre[it - 1][3];
+        }
+        uint2 hi, mid, lo;
+        az_split3_bf16x4(__builtin_bit_cast(float4, raw), hi, mid, lo);
+        unsigned char *dst = dstbuf + (sy * R_SX + sx) * R_VB + ((((j >> 1) ^ ((sy & 1) << 1))) << 4) + (j & 1) * 8;
+        *reinterpret_cast<uint2 *>(dst) = hi;
+        *reinterpret_cast<uint2 *>(dst + 64) = mid;
+        *reinterpret_cast<uint2 *>(dst + 128) = lo;
+    };
+
+    // ---- operands ----
+    const int trow = (lane >> 2) & 3, tcol = lane & 3, oct = lane >> 4;
+    unsigned abase[2];
+    abase[0] = ((4 * wr + trow) * R_SX + 8 * wc + tcol) * R_VB + ((oct ^ ((trow & 1) << 1)) << 4);
+    abase[1] = ((4 * wr + trow) * R_SX + 8 * wc + tcol) * R_VB + ((oct ^ (((trow + 1) & 1) << 1)) << 4);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp) + (size_t)cg * (9 * TAPF4 * 4), 0,
+                                                        9u * TAPF4 * 16u, 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto load_b = [&](float4 (&bq)[3], int n, int tap_f4) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, tap_f4 * 16 + n * 3072 + p * 1024, 0));
+    };
+    // per-channel epilogue constants (four consecutive channels per lane and N tile after the quad transpose)
+    const int cq = lane & 12;
+    float4 sc[2], sf[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        sc[n] = make_float4(1.f, 1.f, 1.f, 1.f); sf[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI != 1) {
+            if (a.scale) sc[n] = *reinterpret_cast<const float4 *>(a.scale + ch0 + 16 * n + cq);
+            if (a.shift) sf[n] = *reinterpret_cast<const float4 *>(a.shift + ch0 + 16 * n + cq);
+        }
+    }
+    const float floor_ = a.relu ? 0.f : -__builtin_inff();
+
+    // BatchNorm partials: see az_conv3d_roll.hip -- element e = 4 m + r of a lane (its x offset in the quarter) is valid
+    // iff e < st_nv; two channels per lane (N tiles 0, 1)
+    const int oh_l = ty0 + 4 * wr + (lane >> 4);
+    int st_nv = 0;
+    if (EPI == 1) st_nv = (oh_l < a.H) ? min(max(a.W - (tx0 + 8 * wc), 0), 8) : 0;
+    float st_k[2] = {0.f, 0.f}, st_s1[2] = {0.f, 0.f}, st_s2[2] = {0.f, 0.f};
+    int st_planes = 0;
+    bool st_first = true;
+
+    auto finish = [&](int o, bool ok) {
+        const bool row_ok = ok && oh_l < a.H;
+        const unsigned pix_row = (unsigned)((o * a.H + oh_l) * a.W);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int ow = tx0 + 8 * wc + 4 * m + (lane & 3);
+                const f32x4 v = r16_quad_transpose(acc[m][n], lane);
+                const bool vok = row_ok && ow < a.W;
+                const unsigned off = vok ? (pix_row + (unsigned)ow) * (unsigned)(a.out_cs * 4) + (unsigned)(ch0 + 16 * n + cq) * 4u : R_OOB;
+                float4 y = make_float4(v[0] * sc[n].x + sf[n].x, v[1] * sc[n].y + sf[n].y, v[2] * sc[n].z + sf[n].z, v[3] * sc[n].w + sf[n].w);
+                if (EPI == 2) {
+                    const unsigned roff = vok ? (pix_row + (unsigned)ow) * (unsigned)(a.res_cs * 4) + (unsigned)(ch0 + 16 * n + cq) * 4u : R_OOB;
+                    const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0));
+                    y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
+                }
+                if (EPI != 1) { y.x = fmaxf(y.x, floor_); y.y = fmaxf(y.y, floor_); y.z = fmaxf(y.z, floor_); y.w = fmaxf(y.w, floor_); }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, off, 0, 0);
+            }
+        if (EPI == 1) {
+            const int nv_p = ok ? st_nv : 0;
+            st_planes += ok ? 1 : 0;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                st_k[n] = (ok && st_first) ? acc[0][n][0] : st_k[n];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dlt = (m * 4 + r < nv_p) ? acc[m][n][r] - st_k[n] : 0.f;
+                        st_s1[n] += dlt;
+                        st_s2[n] = fmaf(dlt, dlt, st_s2[n]);
+                    }
+            }
+            st_first = st_first && !ok;
+        }
+    };
+    auto flush_stats = [&]() {
+        const unsigned row_id = (unsigned)(((seg * a.tiles_yb + tiy) * a.tiles_x + tix) * 4 + wv);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float cnt = (float)(st_nv * st_planes);
+            float mean = cnt > 0.f ? st_k[n] + st_s1[n] / cnt : 0.f;
+            float m2 = cnt > 0.f ? st_s2[n] - st_s1[n] * st_s1[n] / cnt : 0.f;
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                const float n_o = __shfl_xor(cnt, off), mean_o = __shfl_xor(mean, off), m2_o = __shfl_xor(m2, off);
+                const float nn = cnt + n_o;
+                const float dlt = mean_o - mean;
+                const float w_o = nn > 0.f ? n_o / nn : 0.f;
+                m2 = m2 + m2_o + dlt * dlt * cnt * w_o;
+                mean = mean + dlt * w_o;
+                cnt = nn;
+            }
+            const unsigned ch = (unsigned)(ch0 + 16 * n + (lane & 15));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(cnt * mean, fmaxf(m2, 0.f))), rs_part,
+                                                  lane < 16 ? (unsigned)((((size_t)g * a.cout + ch) * a.rows + row_id) * 8) : R_OOB, 0, 0);
+            if (n == 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cnt), rs_cnt,
+                                                      (lane == 0 && cg == 0) ? (unsigned)(((size_t)g * a.rows + row_id) * 4) : R_OOB, 0, 0);
+        }
+    };
+
+    // ---- one stage: image p, chunk CC, slab in buffer `buf`; straight-line ----
+    float4 wk[2][2][3];
+    f32x4 tq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto stage_s = [&](auto cc_tag, int p, int buf) {
+        constexpr int CC = decltype(cc_tag)::value;
+        constexpr bool LAST = (CC == NCH - 1);
+        constexpr int CCN = (CC + 1) % NCH;
+        const unsigned char *sl = slab + buf * R_SLAB_BYTES;
+        unsigned char *sn = slab + (buf ^ 1) * R_SLAB_BYTES;
+        constexpr int wcur = CC * (2 * 3 * 64), wnxt = CCN * (2 * 3 * 64);
+        const int pn = LAST ? p + 1 : p;
+        if (CC == 0) {  // the image before is complete: its epilogue opens this stage, its stores have the stage to land
+            finish(p - 1, p - 1 >= d0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float4 av[2][3];
+        auto load_a = [&](float4 (&aq)[3], int m, int kh, int kw) {
+            const unsigned char *ap = sl + abase[kh & 1] + (kh * R_SX + 4 * m + kw) * R_VB;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) aq[q] = *reinterpret_cast<const float4 *>(ap + 64 * q);
+        };
+        load_a(av[0], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int kh = j / 3, kw = j % 3;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                load_b(wk[(j + 1) & 1][n], n, (j + 1 < 9 ? wcur + (j + 1) * TAPF4 : wnxt));
+            if (j == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue(pn, CCN);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int t = j * 2 + m;
+                __builtin_amdgcn_sched_barrier(0);
+                if (m + 1 < 2) load_a(av[(t + 1) & 1], m + 1, kh, kw);
+                else if (j + 1 < 9) load_a(av[(t + 1) & 1], 0, (j + 1) / 3, (j + 1) % 3);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int st = t * 2 + n;
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 &prev = n > 0 ? acc[m][n - 1] : (m > 0 ? acc[m - 1][1] : acc[1][1]);
+                    r16_step(tq[st & 1], av[t & 1], wk[j & 1][n], prev, tq[(st + 1) & 1]);
+                }
+                if (m == 1 && j >= 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    commit_piece(j - 3, sn);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1][1] += tq[1];  // 36 steps: the last one wrote tq[1]
+        tq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wk[0][n][q] = wk[1][n][q];
+        __syncthreads();
+    };
+
+    // ---- the walk over the images of the segment ----
+    issue(d0, 0);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) load_b(wk[0][n], n, 0);
+#pragma unroll
+    for (int it = 0; it < R_NLD; ++it) commit_piece(it, slab);
+    __syncthreads();
+    int buf = 0;
+    for (int p = d0; p < d1; ++p) {
+        if (NCH == 1) {
+            stage_s(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+        } else {
+            stage_s(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+            stage_s(std::integral_constant<int, NCH - 1>{}, p, buf); buf ^= 1;
+        }
+    }
+    finish(d1 - 1, true);
+    if (EPI == 1) flush_stats();
+}
+
+// ---- weight packing: [cout/32][tap 9][cin/32][n16 2][part 3][lane 64][8] bf16; element j of lane =
+//      part p of src(co = 32 cg + 16 n16 + (lane & 15), ci = 32 cc + 8 (lane >> 4) + j, tap)
+__global__ void __launch_bounds__(256)
+conv2d_pack_r16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, int cin, int cout,
+                       long long sn, long long sk, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    int r = idx >> 9;
+    const int p = r % 3; r /= 3;
+    const int n = r & 1; r >>= 1;
+    const int nch = cin / 32;
+    const int cc = r % nch; r /= nch;
+    const int tap = r % 9;
+    const int cg = r / 9;
+    const int co = cg * 32 + n * 16 + (lane & 15);
+    const int ci = cc * 32 + 8 * (lane >> 4) + j;
+    const float x = src[co * sn + ci * sk + (flip ? 8 - tap : tap)];
+    dst[idx] = az_split3_part(x, p);
+}
+
+static bool c2r_shape_ok(int cin, int cout) { return (cin == 32 || cin == 64) && (cout == 32 || cout == 64); }
+
+extern "C" long long az_conv2d_roll_packed_floats(int cin, int cout) {
+    if (!c2r_shape_ok(cin, cout)) return AZ_EUNSUPPORTED;
+    return 9LL * cin * cout * 3 / 2;
+}
+
+extern "C" int az_conv2d_roll_pack(float *packed, const float *w, int cin, int cout, long long stride_out,
+                                   long long stride_in, int flip, void *stream) {
+    AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w);
+    if (!c2r_shape_ok(cin, cout)) return AZ_EUNSUPPORTED;
+    const int total = 9 * cin * cout * 3;
+    hipLaunchKernelGGL(conv2d_pack_r16_kernel, dim3((total + 255) / 256), dim3(256), 0, az_stream(stream),
+                       reinterpret_cast<unsigned short *>(packed), w, cin, cout, stride_out, stride_in, flip, total);
+    return az_launch_status();
+}
+
+// image segments per group: one round of workgroups over the chip's 512 slots if the patches allow it
+static void c2r_segments(const C2RArgs &a, int &nseg, int &seg_len) {
+    const long long patches = (long long)a.G * a.tiles_yb * a.tiles_x * (a.cout / 32);
+    long long best = -1;
+    nseg = 1; seg_len = a.N;
+    for (int n = 1; n <= a.N; ++n) {
+        const int len = (a.N + n - 1) / n;
+        if ((a.N + len - 1) / len != n) continue;
+        const long long rounds = (patches * n + 511) / 512;
+        const long long cost = rounds * (len * 3 + 2);  // stages per workgroup + its fixed cost
+        if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
+    }
+}
+
+static int c2r_setup(C2RArgs &a, int groups, int B, int H, int W, int cin, int cout) {
+    if (!c2r_shape_ok(cin, cout)) return AZ_EUNSUPPORTED;
+    if (groups <= 0 || B <= 0 || B % groups || H <= 0 || W <= 0) return AZ_EINVAL;
+    a.G = groups; a.N = B / groups; a.H = H; a.W = W; a.cout = cout;
+    a.tiles_yb = (H + R_TY - 1) / R_TY; a.tiles_x = (W + R_TX - 1) / R_TX;
+    c2r_segments(a, a.nseg, a.seg_len);
+    a.rows = a.nseg * a.tiles_yb * a.tiles_x * 4;
+    // one group of one tensor is addressed through a 32-bit buffer offset
+    if ((long long)a.N * H * W * 64 * 4 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
+    return AZ_OK;
+}
+
+extern "C" long long az_conv2d_roll_stats_rows(int groups, int B, int H, int W, int cin, int cout) {
+    C2RArgs a{};
+    if (int e = c2r_setup(a, groups, B, H, W, cin, cout)) return e;
+    return a.rows;
+}
+
+template <int EPI>
+static int c2r_launch(const C2RArgs &a, int cin, hipStream_t s) {
+    const long long blocks = (long long)a.G * a.nseg * a.tiles_yb * a.tiles_x * (a.cout / 32);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
+    if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return az_launch_status();
+}
+
+// out = relu?( conv(in) * scale[c] + shift[c] + residual ): dense [B,H,W,cin] -> [B,H,W,cout]; scale / shift / residual optional
+extern "C" int az_conv2d_roll_fwd(float *out, const float *in, const float *packed, const float *scale, const float *shift,
+                                  const float *residual, int relu, int B, int H, int W, int cin, int cout, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed);
+    C2RArgs a{};
+    if (int e = c2r_setup(a, 1, B, H, W, cin, cout)) return e;
+    a.in = in; a.wp = packed; a.out = out; a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu;
+    a.out_cs = cout; a.res_cs = cout;
+    return residual ? c2r_launch<2>(a, cin, az_stream(stream)) : c2r_launch<0>(a, cin, az_stream(stream));
+}
+
+// out = conv(in) (raw) + BatchNorm partials [groups][cout][rows][2], counts [groups][rows], rows = az_conv2d_roll_stats_rows
+extern "C" int az_conv2d_roll_fwd_stats(float *out, float *partials, float *counts, const float *in, const float *packed,
+                                        int groups, int B, int H, int W, int cin, int cout, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts);
+    C2RArgs a{};
+    if (int e = c2r_setup(a, groups, B, H, W, cin, cout)) return e;
+    a.in = in; a.wp = packed; a.out = out; a.part = partials; a.cnt = counts;
+    a.out_cs = cout; a.res_cs = cout;
+    return c2r_launch<1>(a, cin, az_stream(stream));
+}

@@ -283,6 +283,23 @@ long long az_conv2d_stats_tiles(int B, int H, int W, int groups);
 int az_conv2d_fwd_stats(float *out, float *partials, float *counts, const float *in, const float *packed_w,
                         int groups, int B, int H, int W, int cin, int cout, int in_cstride, int out_cstride,
                         int kh, int kw, int dilation, void *stream);
+
+/* ---- K13r: 3x3 stride-1 dilation-1 Conv2d with cin, cout in {32, 64} as a walk over the batch (az_conv2d_roll.hip;
+ * replaces az_conv2d_fwd / az_conv2d_fwd_stats for psmnet_submodule_3.py:92-147 firstconv[1..2], layer1, layer2 and
+ * their input gradients).  Dense channels-last tensors [B,H,W,cin] -> [B,H,W,cout]. ---- */
+long long az_conv2d_roll_packed_floats(int cin, int cout);
+/* weights w[co * stride_out + ci * stride_in + tap] -> packed image; flip: taps reversed (input gradient) */
+int az_conv2d_roll_pack(float *packed, const float *w, int cin, int cout, long long stride_out, long long stride_in,
+                        int flip, void *stream);
+/* out = relu?( conv(in) * scale[c] + shift[c] + residual ); scale / shift / residual may be NULL */
+int az_conv2d_roll_fwd(float *out, const float *in, const float *packed, const float *scale, const float *shift,
+                       const float *residual, int relu, int B, int H, int W, int cin, int cout, void *stream);
+/* rows per statistic group of the partial buffers az_conv2d_roll_fwd_stats fills */
+long long az_conv2d_roll_stats_rows(int groups, int B, int H, int W, int cin, int cout);
+/* out = conv(in) (raw); partials [groups][cout][rows][2] = (sum, centred sum of squares), counts [groups][rows]:
+ * what az_bn2d_fwd accepts in place of its own statistics pass (groups = consecutive B / groups images each) */
+int az_conv2d_roll_fwd_stats(float *out, float *partials, float *counts, const float *in, const float *packed,
+                             int groups, int B, int H, int W, int cin, int cout, void *stream);
 /* plain-bf16 twin of az_conv2d_fwd for 3x3 layers (one MFMA per 16-deep block, operands rounded to bf16,
  * fp32 accumulation and fp32 tensors): the arithmetic of the reference's autocast region around the RAFT-Stereo
  * GRU update (nets/raft/raft_stereo.py:142-172 calling nets/raft/update.py:19-41 ConvGRU).
