@@ -8,12 +8,13 @@
 //     latency in front of it, weight ring refill, descriptor set-up, the drain of the epilogue stores -- are paid
 //     once per (patch, group) instead of once per (patch, image), and a stage (image x 32-channel chunk: 216 MFMAs per
 //     wave) is ONE basic block with exact vmcnt bookkeeping (validity through buffer-instruction bounds);
-//   * v_mfma_f32_16x16x32_bf16, four waves = four 4x8-voxel quarters of the patch, each for all 32 output channels of
-//     the launch's channel group (2 M tiles x 2 N tiles = 16 accumulator registers): an A fragment read from LDS
-//     feeds both N tiles (12 MFMAs) -- with one N tile per wave, as in the 3-D kernel where the three kd share the
-//     fragment, a 2-D stage would need 3 KB of LDS reads per 96 matrix cycles on every SIMD: all of the LDS bandwidth;
-//   * 64 output channels = two channel groups in the grid (the slab is staged once per group: the split is hidden in
-//     the MFMA stream either way);
+//   * v_mfma_f32_16x16x32_bf16, four waves = four 4x8-voxel quarters of the patch, each for ALL output channels
+//     (2 M tiles x NT N tiles of 16 channels: NT = 2 for 32 output channels, 4 for 64 -- 16 / 32 accumulator
+//     registers): an A fragment read from LDS feeds every N tile (12 / 24 MFMAs) -- with one N tile per wave, as in the
+//     3-D kernel where the three kd share the fragment, a 2-D stage would need 3 KB of LDS reads per 96 matrix cycles
+//     on every SIMD: all of the LDS bandwidth -- and the slab is staged once per patch whatever the channel count
+//     (AZ_CONV2D_ROLL_NT4=0: 64 channels as two workgroups per patch, for A/B runs: 104 vs 102 us alone, 0.106 /
+//     0.123 vs 0.098 / 0.111 ms forward / input gradient in the step);
 //   * BatchNorm partials (EPI 1): per-lane running sums about a per-lane shift, one row per (wave quarter, group
 //     segment), in az_bn2d_fwd's layout [group][cout][rows][2] / [group][rows].
 // Arithmetic: az_common.h's bf16x6 product; accumulation order per output: 32-channel chunk, kh, kw.
@@ -37,7 +38,7 @@ struct C2RArgs {
 };
 
 // EPI: 0 = y = relu?(acc * scale + shift), 2 = the same + residual, 1 = raw output + BatchNorm partials
-template <int CIN, int EPI>
+template <int CIN, int EPI, int NT>
 __global__ void __launch_bounds__(256, 2)
 conv2d_roll_kernel(const C2RArgs a) {
     constexpr int NCH = CIN / 32;
@@ -53,7 +54,7 @@ conv2d_roll_kernel(const C2RArgs a) {
         const int nblk = gridDim.x, xcd = blockIdx.x & 7, q8 = nblk >> 3, r8 = nblk & 7;
         lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     }
-    const int ngrp = a.cout >> 5;
+    const int ngrp = a.cout / (16 * NT);  // channel groups in the grid (NT = 4: one workgroup does all 64 channels)
     const int cg = lin % ngrp; lin /= ngrp;
     const int tix = lin % a.tiles_x; lin /= a.tiles_x;
     const int tiy = lin % a.tiles_yb; lin /= a.tiles_yb;
@@ -62,7 +63,7 @@ conv2d_roll_kernel(const C2RArgs a) {
     const int d0 = seg * a.seg_len, d1 = min(d0 + a.seg_len, a.N);  // images [d0, d1) of group g
     const int ty0 = tiy * R_TY, tx0 = tix * R_TX;
     const int ih0 = ty0 - 1, iw0 = tx0 - 1;
-    const int ch0 = cg * 32;
+    const int ch0 = cg * 16 * NT;
 
     const unsigned in_bytes = (unsigned)a.N * a.H * a.W * CIN * 4u, out_bytes = (unsigned)a.N * a.H * a.W * a.out_cs * 4u;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in) + (size_t)g * (in_bytes / 4), 0, in_bytes, 0x00020000);
@@ -75,11 +76,11 @@ conv2d_roll_kernel(const C2RArgs a) {
     const auto rs_cnt = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.cnt : a.out, 0,
                                                           EPI == 1 ? (unsigned)((size_t)a.G * a.rows * 4) : 0u, 0x00020000);
 
-    f32x4 acc[2][2];  // [M tile: columns 4 m .. of the quarter][N tile: channels 16 n ..]
+    f32x4 acc[2][NT];  // [M tile: columns 4 m .. of the quarter][N tile: channels 16 n ..]
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- staging: one image chunk = 10 x 18 pixels x 32 channels fp32 -> bf16 triplets in LDS (az_conv3d_roll.hip) ----
     u32x4 pre[R_NLD];
@@ -121,25 +122,24 @@ conv2d_roll_kernel(const C2RArgs a) {
     unsigned abase[2];
     abase[0] = ((4 * wr + trow) * R_SX + 8 * wc + tcol) * R_VB + ((oct ^ ((trow & 1) << 1)) << 4);
     abase[1] = ((4 * wr + trow) * R_SX + 8 * wc + tcol) * R_VB + ((oct ^ (((trow + 1) & 1) << 1)) << 4);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp) + (size_t)cg * (9 * TAPF4 * 4), 0,
-                                                        9u * TAPF4 * 16u, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp) + (size_t)cg * (NT / 2) * (9 * TAPF4 * 4), 0,
+                                                        (unsigned)(NT / 2) * 9u * TAPF4 * 16u, 0x00020000);
     const unsigned wlane = (unsigned)lane * 16u;
     auto load_b = [&](float4 (&bq)[3], int n, int tap_f4) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-            bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, tap_f4 * 16 + n * 3072 + p * 1024, 0));
+            bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_w, wlane, (n >> 1) * (9 * TAPF4 * 16) + tap_f4 * 16 + (n & 1) * 3072 + p * 1024, 0));
     };
     // per-channel epilogue constants (four consecutive channels per lane and N tile after the quad transpose)
     const int cq = lane & 12;
-    float4 sc[2], sf[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        sc[n] = make_float4(1.f, 1.f, 1.f, 1.f); sf[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto epi_consts = [&](int n, float4 &sc, float4 &sf) {  // (L2-resident; not held across the walk: registers)
+        sc = make_float4(1.f, 1.f, 1.f, 1.f); sf = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI != 1) {
-            if (a.scale) sc[n] = *reinterpret_cast<const float4 *>(a.scale + ch0 + 16 * n + cq);
-            if (a.shift) sf[n] = *reinterpret_cast<const float4 *>(a.shift + ch0 + 16 * n + cq);
+            if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + ch0 + 16 * n + cq);
+            if (a.shift) sf = *reinterpret_cast<const float4 *>(a.shift + ch0 + 16 * n + cq);
         }
-    }
+    };
     const float floor_ = a.relu ? 0.f : -__builtin_inff();
 
     // BatchNorm partials: see az_conv3d_roll.hip -- element e = 4 m + r of a lane (its x offset in the quarter) is valid
@@ -147,7 +147,9 @@ conv2d_roll_kernel(const C2RArgs a) {
     const int oh_l = ty0 + 4 * wr + (lane >> 4);
     int st_nv = 0;
     if (EPI == 1) st_nv = (oh_l < a.H) ? min(max(a.W - (tx0 + 8 * wc), 0), 8) : 0;
-    float st_k[2] = {0.f, 0.f}, st_s1[2] = {0.f, 0.f}, st_s2[2] = {0.f, 0.f};
+    float st_k[NT], st_s1[NT], st_s2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { st_k[n] = 0.f; st_s1[n] = 0.f; st_s2[n] = 0.f; }
     int st_planes = 0;
     bool st_first = true;
 
@@ -155,14 +157,16 @@ conv2d_roll_kernel(const C2RArgs a) {
         const bool row_ok = ok && oh_l < a.H;
         const unsigned pix_row = (unsigned)((o * a.H + oh_l) * a.W);
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < NT; ++n) {
+            float4 sc, sf;
+            epi_consts(n, sc, sf);
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int m = 0; m < 2; ++m) {
                 const int ow = tx0 + 8 * wc + 4 * m + (lane & 3);
                 const f32x4 v = r16_quad_transpose(acc[m][n], lane);
                 const bool vok = row_ok && ow < a.W;
                 const unsigned off = vok ? (pix_row + (unsigned)ow) * (unsigned)(a.out_cs * 4) + (unsigned)(ch0 + 16 * n + cq) * 4u : R_OOB;
-                float4 y = make_float4(v[0] * sc[n].x + sf[n].x, v[1] * sc[n].y + sf[n].y, v[2] * sc[n].z + sf[n].z, v[3] * sc[n].w + sf[n].w);
+                float4 y = make_float4(v[0] * sc.x + sf.x, v[1] * sc.y + sf.y, v[2] * sc.z + sf.z, v[3] * sc.w + sf.w);
                 if (EPI == 2) {
                     const unsigned roff = vok ? (pix_row + (unsigned)ow) * (unsigned)(a.res_cs * 4) + (unsigned)(ch0 + 16 * n + cq) * 4u : R_OOB;
                     const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, 0, 0));
@@ -171,11 +175,12 @@ conv2d_roll_kernel(const C2RArgs a) {
                 if (EPI != 1) { y.x = fmaxf(y.x, floor_); y.y = fmaxf(y.y, floor_); y.z = fmaxf(y.z, floor_); y.w = fmaxf(y.w, floor_); }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, off, 0, 0);
             }
+        }
         if (EPI == 1) {
             const int nv_p = ok ? st_nv : 0;
             st_planes += ok ? 1 : 0;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 st_k[n] = (ok && st_first) ? acc[0][n][0] : st_k[n];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -192,7 +197,7 @@ conv2d_roll_kernel(const C2RArgs a) {
     auto flush_stats = [&]() {
         const unsigned row_id = (unsigned)(((seg * a.tiles_yb + tiy) * a.tiles_x + tix) * 4 + wv);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NT; ++n) {
             float cnt = (float)(st_nv * st_planes);
             float mean = cnt > 0.f ? st_k[n] + st_s1[n] / cnt : 0.f;
             float m2 = cnt > 0.f ? st_s2[n] - st_s1[n] * st_s1[n] / cnt : 0.f;
@@ -216,7 +221,7 @@ conv2d_roll_kernel(const C2RArgs a) {
     };
 
     // ---- one stage: image p, chunk CC, slab in buffer `buf`; straight-line ----
-    float4 wk[2][2][3];
+    float4 wk[2][NT][3];
     f32x4 tq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     auto stage_s = [&](auto cc_tag, int p, int buf) {
         constexpr int CC = decltype(cc_tag)::value;
@@ -231,7 +236,7 @@ conv2d_roll_kernel(const C2RArgs a) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         float4 av[2][3];
         auto load_a = [&](float4 (&aq)[3], int m, int kh, int kw) {
@@ -245,7 +250,7 @@ conv2d_roll_kernel(const C2RArgs a) {
             const int kh = j / 3, kw = j % 3;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NT; ++n)
                 load_b(wk[(j + 1) & 1][n], n, (j + 1 < 9 ? wcur + (j + 1) * TAPF4 : wnxt));
             if (j == 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -258,23 +263,24 @@ conv2d_roll_kernel(const C2RArgs a) {
                 if (m + 1 < 2) load_a(av[(t + 1) & 1], m + 1, kh, kw);
                 else if (j + 1 < 9) load_a(av[(t + 1) & 1], 0, (j + 1) / 3, (j + 1) % 3);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const int st = t * 2 + n;
+                for (int n = 0; n < NT; ++n) {
+                    const int st = t * NT + n;
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 &prev = n > 0 ? acc[m][n - 1] : (m > 0 ? acc[m - 1][1] : acc[1][1]);
+                    f32x4 &prev = n > 0 ? acc[m][n - 1] : (m > 0 ? acc[m - 1][NT - 1] : acc[1][NT - 1]);
                     r16_step(tq[st & 1], av[t & 1], wk[j & 1][n], prev, tq[(st + 1) & 1]);
-                }
-                if (m == 1 && j >= 3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    commit_piece(j - 3, sn);
+                    // the next image's six pieces, one per tap from the fourth on, behind the tap's last step
+                    if (m == 1 && n == NT - 1 && j >= 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        commit_piece(j - 3, sn);
+                    }
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        acc[1][1] += tq[1];  // 36 steps: the last one wrote tq[1]
+        acc[1][NT - 1] += tq[1];  // 18 NT steps (even): the last one wrote tq[1]
         tq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int q = 0; q < 3; ++q) wk[0][n][q] = wk[1][n][q];
         __syncthreads();
@@ -283,7 +289,7 @@ conv2d_roll_kernel(const C2RArgs a) {
     // ---- the walk over the images of the segment ----
     issue(d0, 0);
 #pragma unroll
-    for (int n = 0; n < 2; ++n) load_b(wk[0][n], n, 0);
+    for (int n = 0; n < NT; ++n) load_b(wk[0][n], n, 0);
 #pragma unroll
     for (int it = 0; it < R_NLD; ++it) commit_piece(it, slab);
     __syncthreads();
@@ -340,7 +346,7 @@ extern "C" int az_conv2d_roll_pack(float *packed, const float *w, int cin, int c
 
 // image segments per group: one round of workgroups over the chip's 512 slots if the patches allow it
 static void c2r_segments(const C2RArgs &a, int &nseg, int &seg_len) {
-    const long long patches = (long long)a.G * a.tiles_yb * a.tiles_x * (a.cout / 32);
+    const long long patches = (long long)a.G * a.tiles_yb * a.tiles_x;  // (64 output channels: one workgroup does both groups)
     long long best = -1;
     nseg = 1; seg_len = a.N;
     for (int n = 1; n <= a.N; ++n) {
@@ -370,12 +376,25 @@ extern "C" long long az_conv2d_roll_stats_rows(int groups, int B, int H, int W, 
     return a.rows;
 }
 
+// AZ_CONV2D_ROLL_NT4=0: 64 output channels as two channel groups in the grid (two workgroups per patch, each staging
+// the slab) instead of four N tiles per wave
+static bool c2r_nt4() {
+    static const int on = [] { const char *e = getenv("AZ_CONV2D_ROLL_NT4"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
 template <int EPI>
 static int c2r_launch(const C2RArgs &a, int cin, hipStream_t s) {
-    const long long blocks = (long long)a.G * a.nseg * a.tiles_yb * a.tiles_x * (a.cout / 32);
+    const bool nt4 = a.cout == 64 && c2r_nt4();
+    const long long blocks = (long long)a.G * a.nseg * a.tiles_yb * a.tiles_x * (nt4 ? 1 : a.cout / 32);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
-    if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)blocks), blk(256);
+    if (nt4) {
+        if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI, 4>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI, 4>), grid, blk, 0, s, a);
+    } else {
+        if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI, 2>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI, 2>), grid, blk, 0, s, a);
+    }
     return az_launch_status();
 }
 
