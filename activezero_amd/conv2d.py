@@ -72,10 +72,18 @@ def _roll_ok(xr, cin, cout, kh, kw, dil, res=None):
             and (res is None or res.shape[-1] == cout))
 
 
-def _pack_roll(weight, cin, cout, s_out, s_in, flip):
+def _pack_roll(weight, cin, cout, s_out, s_in, flip, cache=False):
     w = _chk(weight.detach().contiguous(), "weight")
+    key = None
+    if cache:
+        key = (_cache_key(weight), "roll", cin, cout, s_out, s_in, bool(flip))
+        hit = _cache_get(_PACK2D_CACHE, key)
+        if hit is not None:
+            return hit[0]
     packed = torch.empty(int(_lib.lib().az_conv2d_roll_packed_floats(cin, cout)), dtype=torch.float32, device=w.device)
     _call("az_conv2d_roll_pack", _p(packed), _p(w), cin, cout, s_out, s_in, int(flip), _stream())
+    if key is not None:
+        _cache_put(_PACK2D_CACHE, key, (packed, weight), 256)
     return packed
 
 
@@ -363,6 +371,11 @@ def conv_bn_eval(x, m, bn, relu=False, residual=None):
     xr = _chk(rows(x), "x")
     rr = _chk(rows(residual), "residual") if residual is not None else None
     with torch.cuda.device(x.device):
-        pk = _pack(m.weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False, cache=True)
         scale, shift = conv3d.eval_affine(bn, xr, cache=True)
+        # (NOT on the batch-walking kernel: v_mfma_f32_16x16x32_bf16 sums 32 products per instruction and its signed mean
+        #  error is -9e-9 of mean|y| against -6e-9 for the 32x32x16 form (tools/conv2d_bias_probe.py; DESIGN.md section 3
+        #  on where that floor comes from).  Train-mode BatchNorm subtracts it with the batch mean; with the
+        #  running-statistics map of inference it survives the 64x64 SPP averages, and the full-size eval output moved
+        #  from 7.0e-4 to 1.05e-3 px max error against the exact result -- over the 1e-3 bar -- for 16 % less latency.)
+        pk = _pack(m.weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False, cache=True)
         return image(_run(xr, pk, cin, cout, kh, kw, d[0] if kh > 1 else 1, scale, shift, rr, relu, tag="conv2d_eval"))
