@@ -608,10 +608,18 @@ def main():
             del opt
             if not args.no_stage_bench:
                 out["eager_stage"] = eager_stage(args, model, device)
-                out["eager_stage"]["tuned"] = _carried_tuned("eager_stage")
+                tuned = _carried_tuned("eager_stage")
+                if tuned is not None and not args.eager_tuned:
+                    # the carried record holds the tuned-eager time AND this library's time of THAT run: quote the
+                    # live-over-carried ratio next to it (same workload, same batch; the eager side is the carried one)
+                    tuned["ratio_live_over_carried_eager"] = out["eager_stage"]["this_library"]["value"] / tuned["eager"]["value"]
+                out["eager_stage"]["tuned"] = tuned
             out["eager_gpu"] = eager_gpu(args, model, il, ir, gt, device)
             out["eager_gpu"]["x"] = out["value"] / out["eager_gpu"]["value"]
-            out["eager_gpu"]["tuned_run"] = _carried_tuned("eager_gpu")
+            tuned_run = _carried_tuned("eager_gpu")
+            if tuned_run is not None and not args.eager_tuned:
+                tuned_run["x_live_over_carried_eager"] = out["value"] / tuned_run["value"]
+            out["eager_gpu"]["tuned_run"] = tuned_run
             if args.eager_tuned:  # the record a later default run quotes
                 os.makedirs(os.path.dirname(TUNED_EAGER_JSON), exist_ok=True)
                 json.dump({"eager_gpu": out["eager_gpu"], "eager_stage": out["eager_stage"],
