@@ -299,8 +299,13 @@ c1_wgrad_kernel(float *__restrict__ gw, const float *__restrict__ in,
                             //  register becomes in second place -- returns wrong values in lanes 48..63 while a wave of
                             //  another kernel issues MFMAs on the same SIMD: tools/probes/pkfma_corun.hip,
                             //  profiles/r03_pkfma_corun.md; tests/test_isa_lint_cpu.py keeps the form out of the library)
+#ifdef C1_WGRAD_OLD_OPERAND_ORDER  // (the form that fails: only to show that the tests see it -- tools/build_variant.sh)
+                            a01[t] = C1_FMA2(x01[j], g2, a01[t]);
+                            a23[t] = C1_FMA2(x23[j], g2, a23[t]);
+#else
                             a01[t] = C1_FMA2(g2, x01[j], a01[t]);
                             a23[t] = C1_FMA2(g2, x23[j], a23[t]);
+#endif
                         }
                     }
                 }

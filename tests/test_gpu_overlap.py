@@ -157,3 +157,43 @@ def test_extractor_called_twice_with_one_sink_stays_in_order():
     torch.cuda.synchronize()
     for (k, p), (_, q) in zip(fe.named_parameters(), ref.named_parameters()):
         assert torch.allclose(p.grad, q.grad, rtol=1e-3, atol=1e-3 * float(q.grad.abs().max()) + 1e-8), k
+
+
+def test_classifier_weight_gradient_beside_a_matrix_kernel():
+    """The 32 -> 1 weight-gradient kernel (VALU, v_pk_fma_f32) must give the same result whether it runs alone or on a
+    second stream while the depth-rolling convolution holds the SIMDs: with the operand form hipcc used to pick for it
+    (src1 low half from the high register of a pair) lanes 48..63 of some packed FMAs came back wrong beside MFMA
+    waves of another kernel -- 4-6e-4 relative on the gradient in the full-size step (profiles/r03_pkfma_corun.md;
+    tests/test_isa_lint_cpu.py keeps the form out of the library, this test pins the behaviour)."""
+    from activezero_amd import conv3d
+    from activezero_amd.ops import _call, _p, _stream
+
+    b, d, h, w = 1, 48, 136, 240
+    x = seeded((b, d, h, w, 32), 31).to(DEV)
+    g = (seeded((b, d, h, w), 32) * 1e-3).to(DEV)
+    sc, sh = (seeded((32,), 33) * 0.2 + 1.0).to(DEV), (seeded((32,), 34) * 0.1).to(DEV)
+    gx = seeded((b, d, h, w, 32), 35).to(DEV)
+    wt = (seeded((32, 32, 3, 3, 3), 36) * 0.05).to(DEV)
+    pk = conv3d._pack(wt, 32, 32, 27, 32 * 27, True, conv3d._layout(conv3d.DEFAULT_ARITH.conv, conv3d.CONV_S1, 32))
+
+    def c1_wgrad(out):
+        _call("az_conv3d_c1_wgrad", _p(out), _p(x), _p(g), _p(sc), _p(sh), b, d, h, w, _stream())
+
+    alone = torch.empty(1, 32, 3, 3, 3, device=DEV)
+    c1_wgrad(alone)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    worst = 0.0
+    for _ in range(3):
+        beside = torch.empty_like(alone)
+        for _ in range(3):  # keep the matrix pipe busy on the main stream for the whole side-stream kernel
+            conv3d._run_gather(gx, pk, conv3d.CONV_S1, 32, 32, conv3d.DEFAULT_ARITH.conv, tag="dgrad")
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            c1_wgrad(beside)
+        for _ in range(3):
+            conv3d._run_gather(gx, pk, conv3d.CONV_S1, 32, 32, conv3d.DEFAULT_ARITH.conv, tag="dgrad")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        worst = max(worst, float((beside.double() - alone.double()).norm() / alone.double().norm()))
+    assert worst <= 5e-6, worst  # (float-atomic order alone: ~1e-6)
