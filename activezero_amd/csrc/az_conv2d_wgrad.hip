@@ -257,6 +257,9 @@ static int dispatch_tiles(const W2Args &a, hipStream_t s) {
     return launch_w2<1, 1, KH, KW, DIL>(a, s);
 }
 
+int az_conv2d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int H, int W, int cm, int cn,
+                               int cs_c, int cs_f, hipStream_t s);
+
 extern "C" long long az_conv2d_wgrad_workspace(int cm, int cn, int kh, int kw) {
     if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32 || kh <= 0 || kw <= 0) return AZ_EINVAL;
     return (long long)kh * kw * cm * cn * (long long)sizeof(float);
@@ -282,7 +285,10 @@ extern "C" int az_conv2d_wgrad(float *grad_w, float *workspace, long long worksp
     a.coarse = grad_out; a.fine = in; a.ws = workspace;
     a.B = B; a.H = H; a.W = W; a.CM = cm; a.CN = cn; a.cs_c = go_cstride; a.cs_f = in_cstride;
     int rc = AZ_EUNSUPPORTED;
-    if (kh == 3 && kw == 3 && dilation == 1) rc = dispatch_tiles<3, 3, 1>(a, s);
+    static const int r16 = [] { const char *e = getenv("AZ_CONV2D_WGRAD_R16"); return e ? atoi(e) : 1; }();
+    if (kh == 3 && kw == 3 && dilation == 1 && r16 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64))
+        rc = az_conv2d_wgrad_r16_launch(workspace, grad_out, in, B, H, W, cm, cn, go_cstride, in_cstride, s);  // az_conv2d_wgrad16.hip
+    else if (kh == 3 && kw == 3 && dilation == 1) rc = dispatch_tiles<3, 3, 1>(a, s);
     else if (kh == 3 && kw == 3 && dilation == 2) rc = dispatch_tiles<3, 3, 2>(a, s);
     else if (kh == 1 && kw == 1) rc = dispatch_tiles<1, 1, 1>(a, s);
     else if (kh == 3 && kw == 5 && dilation == 1) {
