@@ -623,7 +623,7 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
 }
 
 // all 27 taps per wave on 16x16x32 tiles, four waves sharing one staged set (az_conv3d_wgrad16.hip)
-int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int D, int H, int W, hipStream_t s);
+int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s);
 
 extern "C" long long az_conv3d_wgrad_workspace(int cm, int cn) {
     if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32) return AZ_EINVAL;
@@ -648,10 +648,12 @@ extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long worksp
     a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;
     int rc = AZ_EUNSUPPORTED;
     {
-        static int r16 = -1;  // AZ_WGRAD_R16=0: the one-kd-per-wave kernels for the V0 layers too (A/B)
-        if (r16 < 0) { const char *e = getenv("AZ_WGRAD_R16"); r16 = e ? atoi(e) : 1; }
-        if (r16 && precision == 1 && stride == 1 && cm == 32 && cn == 32 && Dc == Df && Hc == Hf && Wc == Wf) {
-            rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, Dc, Hc, Wc, s);
+        static int r16 = -1;  // AZ_WGRAD_R16=0: the one-kd-per-wave kernels for the V0 layers too, 1: only the V0 layers on the new kernel (A/B)
+        if (r16 < 0) { const char *e = getenv("AZ_WGRAD_R16"); r16 = e ? atoi(e) : 2; }
+        // (r16 == 1: the V0 32 x 32 layers only; 2: the 64-channel stride-1 layers too, as 32 x 32 tiles in the grid)
+        if (r16 && precision == 1 && stride == 1 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64) && (r16 >= 2 || (cm == 32 && cn == 32)) &&
+            Dc == Df && Hc == Hf && Wc == Wf) {
+            rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s);
             if (rc != AZ_OK) return rc;
             const int total = cm * cn * 27;
             hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm, cn);

@@ -1,4 +1,6 @@
-// Weight gradient of the V0 32 -> 32 3x3x3 layers (bf16x6, stride 1), rebuilt the way az_conv3d_roll.hip rebuilt their
+// Weight gradient of the stride-1 3x3x3 layers (bf16x6): the V0 32 -> 32 layers and, as 2 x 2 tiles of 32 x 32 channels in
+// the grid, the 64 -> 64 layers of the hourglasses (0.94 -> 0.84 ms at 1/8 resolution, 0.44 -> 0.50 of the roofline),
+// rebuilt the way az_conv3d_roll.hip rebuilt the
 // forward / input-gradient kernel (psmnet_3.py:87-117 dres0..dres4 / classif convs; G = dW[co][ci][27]):
 //
 //   G[m][n][kd,kh,kw] = sum over positions (b, d, h, w) of  coarse[b,d,h,w][m] * fine[b, d-1+kd, h-1+kh, w-1+kw][n]
@@ -52,8 +54,9 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 struct Wg16Args {
     const float *coarse, *fine;
-    float *ws;  // [27][32][32]
+    float *ws;  // [27][CM][CN]
     int B, D, H, W;
+    int CM, CN;  // channels of coarse / fine (32 or 64 each): one workgroup owns ONE 32 x 32 (m, n) tile
     int nwchunk;
     long long ncols;  // B * D * nwchunk columns of work
     int wgs;          // persistent workgroups
@@ -67,6 +70,10 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = wv >> 1, ni = wv & 1;
+    // 64-channel operands: 2 x 2 (or 2 x 1 / 1 x 2) tiles in the grid; the workgroups of a tile are blockIdx.x / ntiles
+    const int ntn = a.CN >> 5, ntiles = (a.CM >> 5) * ntn;
+    const int tile = blockIdx.x % ntiles, wg0 = blockIdx.x / ntiles;
+    const int m0 = (tile / ntn) * 32, n0 = (tile % ntn) * 32;
 
     f32x4 acc[27];
 #pragma unroll
@@ -101,8 +108,9 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
         return __builtin_bit_cast(az_bf16x8, v);
     };
 
-    const unsigned plane_bytes = (unsigned)a.H * a.W * 32u * 4u;
-    for (long long col = blockIdx.x; col < a.ncols; col += a.wgs) {
+    const unsigned vb_c = (unsigned)a.CM * 4u, vb_f = (unsigned)a.CN * 4u;  // bytes per voxel
+    const unsigned plane_c = (unsigned)a.H * a.W * vb_c, plane_f = (unsigned)a.H * a.W * vb_f;
+    for (long long col = wg0; col < a.ncols; col += a.wgs) {
         // column -> (w chunk, coarse depth, batch); consecutive columns = consecutive depths of one chunk: the
         // workgroups resident together read neighbouring planes of the same rows (one L2 serves the three kd)
         long long r_ = col;
@@ -110,9 +118,9 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
         const int wc = (int)(r_ % a.nwchunk);
         const int b = (int)(r_ / a.nwchunk);
         const int cw0 = wc * W16_POS;
-        const unsigned vol_bytes = (unsigned)a.D * plane_bytes;
-        const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coarse) + (size_t)b * (vol_bytes / 4), 0, vol_bytes, 0x00020000);
-        const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.fine) + (size_t)b * (vol_bytes / 4), 0, vol_bytes, 0x00020000);
+        const unsigned vol_c = (unsigned)a.D * plane_c, vol_f = (unsigned)a.D * plane_f;
+        const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coarse) + (size_t)b * (vol_c / 4) + m0, 0, vol_c, 0x00020000);
+        const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.fine) + (size_t)b * (vol_f / 4) + n0, 0, vol_f, 0x00020000);
 
         // ---- staging set of step s: coarse rows 2s, 2s+1 (buffer s & 1); fine rows 2s-1+{2,3}... see below ----------
         // piece q = tid + 256 it of a set:  q < 256: coarse (row pair, 16 positions, 8 float4 per position);
@@ -126,7 +134,7 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
                 if (it == 0) {  // q < 256: coarse
                     const int k = q >> 3, row = crow0 + (k >> 4), cw = cw0 + (k & 15);
                     if (with_coarse && row < a.H && cw < a.W)
-                        off = (unsigned)cd * plane_bytes + (unsigned)(row * a.W + cw) * 128u + (unsigned)(q & 7) * 16u;
+                        off = (unsigned)cd * plane_c + (unsigned)(row * a.W + cw) * vb_c + (unsigned)(q & 7) * 16u;
                     pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 0, 0);
                 } else {
                     const int f = q - 256;
@@ -134,7 +142,7 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
                     const int j = g / 144, pp = (g - j * 144) >> 3;
                     const int fd = cd - 1 + kd, fr = frow0 + j, fw = cw0 - 1 + pp;
                     if (q < W16_NQ && (unsigned)fd < (unsigned)a.D && (unsigned)fr < (unsigned)a.H && (unsigned)fw < (unsigned)a.W)
-                        off = (unsigned)fd * plane_bytes + (unsigned)(fr * a.W + fw) * 128u + (unsigned)(q & 7) * 16u;
+                        off = (unsigned)fd * plane_f + (unsigned)(fr * a.W + fw) * vb_f + (unsigned)(q & 7) * 16u;
                     pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_f, off, 0, 0);
                 }
             }
@@ -241,33 +249,36 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
     for (int t = 0; t < 27; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = 16 * mi + 4 * (lane >> 4) + r;
-            atomicAdd(&a.ws[((size_t)t * 32 + m) * 32 + 16 * ni + (lane & 15)], acc[t][r]);
+            const int m = m0 + 16 * mi + 4 * (lane >> 4) + r;
+            atomicAdd(&a.ws[((size_t)t * a.CM + m) * a.CN + n0 + 16 * ni + (lane & 15)], acc[t][r]);
         }
 }
 
 // persistent workgroups: at most 512 resident (2 per CU); the count that balances the columns best
-int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int D, int H, int W, hipStream_t s) {
+int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s) {
+    if (!((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return AZ_EUNSUPPORTED;
     Wg16Args a{};
     a.coarse = coarse; a.fine = fine; a.ws = ws;
-    a.B = B; a.D = D; a.H = H; a.W = W;
+    a.B = B; a.D = D; a.H = H; a.W = W; a.CM = cm; a.CN = cn;
+    const int ntiles = (cm / 32) * (cn / 32);
+    const int slots = 512 / ntiles;  // resident workgroups per tile (two per CU)
     a.nwchunk = (W + W16_POS - 1) / W16_POS;
     a.ncols = (long long)B * D * a.nwchunk;
-    if ((long long)D * H * W * 128 >= 0xffffff00LL) return AZ_EUNSUPPORTED;  // one batch element through a 32-bit offset
+    if ((long long)D * H * W * (cm > cn ? cm : cn) * 4 >= 0xffffff00LL) return AZ_EUNSUPPORTED;  // one batch element through a 32-bit offset
     int best = 1;
     double best_score = -1.0;
-    for (int w = 512; w >= 128; w -= 8) {
-        if (w > a.ncols) continue;
+    for (int w = slots; w >= slots / 4; w -= 8 / (ntiles > 2 ? 4 : ntiles)) {
+        if (w > a.ncols || w < 1) continue;
         const long long per = (a.ncols + w - 1) / w;
-        const double score = (double)a.ncols / (double)(per * 512);  // useful fraction of the chip-time taken
+        const double score = (double)a.ncols / (double)(per * slots);  // useful fraction of the chip-time taken
         if (score > best_score + 1e-9) { best_score = score; best = w; }
     }
-    if (a.ncols < 128) best = (int)a.ncols;
+    if (a.ncols < slots / 4) best = (int)a.ncols;
     if (const char *e = getenv("AZ_WGRAD_R16_WGS")) {  // experiment: fewer resident workgroups leave room for the other stream
         const int cap = atoi(e);
         if (cap > 0 && cap < best) best = cap;
     }
     a.wgs = best;
-    hipLaunchKernelGGL(conv3d_wgrad_r16_kernel, dim3(a.wgs), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv3d_wgrad_r16_kernel, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
     return az_launch_status();
 }
