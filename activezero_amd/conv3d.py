@@ -25,6 +25,12 @@ from .ops import _call, _chk, _p, _stream
 CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
 FP32, BF16X6 = 0, 1
 _PREC = {"fp32": FP32, "bf16x6": BF16X6}
+# Arithmetic of the BACKWARD matrix kernels (input and weight gradients) when the forward runs on bf16x6: "f16x3" --
+# operands scaled by a power of two from the tensor's largest magnitude and split into two fp16 parts, three MFMAs per
+# product, fp32 accumulation (include/azhip.h, az_roll_common.h; per-layer error against fp64 at bf16x6's level and
+# below torch's fp32 convolution, tools/f16x3_probe.py) -- wherever an f16x3 kernel exists for the layer's shape.
+# AZ_BWD_F16=0 (read once) keeps every gradient on the forward's arithmetic, for A/B runs.
+_BWD_F16 = os.environ.get("AZ_BWD_F16", "1") != "0"
 # include/azhip.h precision 2: the bf16x6 arithmetic on the depth-rolling 16x16x32 kernel (az_conv3d_roll.hip),
 # which reads its own packed-weight layout.  Not an arithmetic a caller chooses: _layout() routes the stride-1
 # layers with 32 output channels (the V0 layers and their input gradients) there.  AZ_CONV_ROLL=0 (read once)
@@ -40,19 +46,24 @@ def _layout(precision, mode, op_cout):
     return precision
 
 
-class Arith(collections.namedtuple("Arith", "conv wgrad sink", defaults=(None,))):
+class Arith(collections.namedtuple("Arith", "conv wgrad sink bwd16", defaults=(None, False))):
     """Arithmetic of the MFMA kernels, passed with every call (no process-wide switch):
       fp32   -- v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chain (157 TFLOP/s peak)
       bf16x6 -- exact 3-way bf16 split of both operands, six bf16 MFMAs per product, fp32
                 accumulate: fp32-class accuracy (measured ~1e-7 relative) at 2.7x the rate
     `conv` covers forward / input-gradient / transposed kernels, `wgrad` the weight gradients.
     `sink` (overlap.Sink or None) is not arithmetic but travels the same way, with every call: when set, the
-    weight-gradient kernels of this forward/backward pass run on its side stream (overlap.py)."""
+    weight-gradient kernels of this forward/backward pass run on its side stream (overlap.py).
+    `bwd16`: input and weight gradients on the f16x3 kernels where one exists for the shape (default with bf16x6;
+    never with fp32, the exact mode)."""
     __slots__ = ()
 
     @classmethod
-    def of(cls, conv="bf16x6", wgrad=None):
-        return cls(_PREC[conv], _PREC[wgrad if wgrad is not None else conv])
+    def of(cls, conv="bf16x6", wgrad=None, bwd16=None):
+        w = wgrad if wgrad is not None else conv
+        if bwd16 is None:
+            bwd16 = _BWD_F16
+        return cls(_PREC[conv], _PREC[w], None, bool(bwd16) and conv == "bf16x6" and w == "bf16x6")
 
     @property
     def names(self):
@@ -230,6 +241,75 @@ def _run_gather(x, packed, mode, cin, cout, precision, scale=None, shift=None, r
     return out
 
 
+# ---- f16x3: the backward kernels' arithmetic (include/azhip.h, az_roll_common.h) ------------------------------------
+def absmax(t):
+    """device scalar max |t| (the operand scale of the f16x3 kernels); a producer kernel may have attached it"""
+    am = getattr(t, "az_amax", None)
+    if am is not None:
+        return am
+    am = t.new_empty(1)
+    with profiler.scope("absmax", bytes=4.0 * t.numel(), bound="hbm"):
+        _call("az_absmax", _p(am), _p(t), t.numel(), _stream())
+    return am
+
+
+def _pack_f16(weight, op_cin, op_cout, stride_out, stride_in, flip):
+    w = _chk(weight.detach().contiguous(), "weight")
+    w_amax = absmax(w)
+    packed = torch.empty(_lib.lib().az_conv3d_packed_floats_f16(op_cin, op_cout), dtype=torch.float32, device=w.device)
+    _call("az_conv3d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), op_cin, op_cout, stride_out, stride_in,
+          int(flip), _stream())
+    return packed, w_amax
+
+
+_PEAK_F16 = (2500.0 / 3.0, "f16x3: fp16 MFMA peak / 3")
+
+
+def _f16_dgrad_ok(mode, cin, cout):
+    """layers whose input gradient has an f16x3 kernel (operand: dy with `cout` channels -> dx with `cin`)"""
+    return mode == CONV_S1 and cin == 32
+
+
+def _input_grad_f16(dy, weight, mode, cin, cout, residual=None):
+    b, d, h, w, c = _dims(dy)
+    assert mode == CONV_S1 and c == cout
+    pk, w_amax = _pack_f16(weight, cout, cin, 27, cin * 27, True)
+    out = dy.new_empty(b, d, h, w, cin)
+    with profiler.scope(f"dgrad_m{mode}_{cout}_{cin}", flops=_conv_flops(b, d * h * w, cout, cin, mode),
+                        peak=_PEAK_F16):
+        _call("az_conv3d_bwd_f16", _p(out), _p(dy), _p(pk), _p(absmax(dy)), _p(w_amax), _p(residual), mode,
+              b, cout, cin, d, h, w, _stream())
+    return out
+
+
+def _f16_wgrad_ok(mode, cin, cout):
+    return mode == CONV_S1 and cin in (32, 64) and cout in (32, 64)
+
+
+def _wgrad_f16(coarse, fine, stride, cm, cn, tag, sink=None):
+    b, dc, hc, wc, _ = _dims(coarse)
+    _, df, hf, wf, _ = _dims(fine)
+    gw = coarse.new_empty(cm, cn, 3, 3, 3)
+    ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
+    am_c, am_f = getattr(coarse, "az_amax", None), getattr(fine, "az_amax", None)
+    with overlap.scope(sink, coarse, fine, gw, am_c, am_f):
+        ws = coarse.new_empty(ws_bytes // 4)
+        am_c, am_f = absmax(coarse), absmax(fine)  # (a pass over the tensor only when its producer attached none)
+        with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
+                            peak=_PEAK_F16):
+            _call("az_conv3d_wgrad_f16", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), _p(am_c), _p(am_f), stride,
+                  b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
+        if sink is not None and sink.live:
+            sink.keep.extend((am_c, am_f))
+    return gw
+
+
+def _weight_grad_f16(x, dy, mode, cin, cout, sink=None):
+    if mode == DECONV_S2:
+        return _wgrad_f16(x, dy, 2, cin, cout, "deconv", sink)
+    return _wgrad_f16(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", sink)
+
+
 def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
     b, dc, hc, wc, _ = _dims(coarse)
     _, df, hf, wf, _ = _dims(fine)
@@ -346,16 +426,27 @@ class _ConvBN(torch.autograd.Function):
                 coef = gy.new_empty(cout, 3)
                 ws_bytes = lib.az_bn3d_bwd_workspace(nvox, cout)
                 ws = gy.new_empty(ws_bytes // 4)
+                # f16x3 gradients: max |dx_raw| (the operand scale) is taken by the kernel that writes dx_raw
+                dx_amax = gy.new_empty(1) if arith.bwd16 else None
                 with profiler.scope(f"bn3d_bwd_{cout}", bytes=4.0 * raw.numel() * (7 if (relu and y is not None) else 5), bound="hbm"):
                     _call("az_bn3d_bwd", _p(dx_raw), _p(dz), _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes,
                           _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), _p(scale), _p(shift),
-                          int(relu), nvox, cout, _stream())
+                          int(relu), nvox, cout, _p(dx_amax), _stream())
+                if dx_amax is not None:
+                    dx_raw.az_amax = dx_amax
                 g_res = (dz if relu else gy) if has_res else None
             gx = gw = None
+            f16 = training and arith.bwd16
             if ctx.needs_input_grad[0]:
-                gx = _input_grad(dx_raw, weight, mode, cin, cout, arith.conv)
+                if f16 and _f16_dgrad_ok(mode, cin, cout):
+                    gx = _input_grad_f16(dx_raw, weight, mode, cin, cout)
+                else:
+                    gx = _input_grad(dx_raw, weight, mode, cin, cout, arith.conv)
             if ctx.needs_input_grad[1]:
-                gw = _weight_grad(x, dx_raw, mode, cin, cout, arith.wgrad, arith.sink)
+                if f16 and _f16_wgrad_ok(mode, cin, cout):
+                    gw = _weight_grad_f16(x, dx_raw, mode, cin, cout, arith.sink)
+                else:
+                    gw = _weight_grad(x, dx_raw, mode, cin, cout, arith.wgrad, arith.sink)
         return gx, gw, dgamma, dbeta, g_res, None, None, None, None, None
 
 

@@ -210,7 +210,9 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
                      const float *__restrict__ y, const float *__restrict__ x,
                      const float *__restrict__ mean, const float *__restrict__ invstd,
                      const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                     long long nvox) {
+                     long long nvox, unsigned *__restrict__ amax_zero = nullptr) {
+    // (the apply kernel that follows in the stream takes max |dx| into this word with atomicMax: start it at zero)
+    if (amax_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *amax_zero = 0u;
     // thread t owns channel quad (t % C4) and voxel lane (t / C4); C4 divides 256
     constexpr int C4 = C / 4, VPB = 256 / C4;
     // ReLU mask: from the saved output y, or -- when the forward's (scale, shift) are given and the
@@ -337,8 +339,10 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
                     const float *__restrict__ invstd, float *__restrict__ coef,
                     const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                     long long total4, const float *__restrict__ partial, int nblocks, const float *__restrict__ gamma,
-                    float *__restrict__ dgamma, float *__restrict__ dbeta, double nvox) {
+                    float *__restrict__ dgamma, float *__restrict__ dbeta, double nvox,
+                    unsigned *__restrict__ amax = nullptr) {
     constexpr int C4 = C / 4;
+    unsigned am = 0;  // max |dx| of this thread, as a bit pattern (az_absmax.hip): the f16x3 scale of dx's consumers
     __shared__ float smu[C], sis[C], k0[C], k1[C], k2[C], ssc[C], ssh[C];
     const bool remask = relu && scale != nullptr;  // see bn_bwd_reduce_kernel
     const int grp = blockIdx.y;
@@ -421,6 +425,13 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
         o.z = k0[c + 2] * (g.z - k1[c + 2] - (xx.z - smu[c + 2]) * sis[c + 2] * k2[c + 2]);
         o.w = k0[c + 3] * (g.w - k1[c + 3] - (xx.w - smu[c + 3]) * sis[c + 3] * k2[c + 3]);
         bn_st4<NT>(&dx[i], o);
+        am = max(max(am, __float_as_uint(o.x) & 0x7fffffffu), max(__float_as_uint(o.y) & 0x7fffffffu,
+                 max(__float_as_uint(o.z) & 0x7fffffffu, __float_as_uint(o.w) & 0x7fffffffu)));
+    }
+    if (amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, am);
     }
 }
 
@@ -591,7 +602,8 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
                            float *workspace, long long workspace_bytes, const float *dy,
                            const float *y, const float *x, const float *mean,
                            const float *invstd, const float *gamma, const float *scale,
-                           const float *shift, int relu, long long nvox, int C, void *stream) {
+                           const float *shift, int relu, long long nvox, int C, float *dx_amax, void *stream) {
+    unsigned *const am = reinterpret_cast<unsigned *>(dx_amax);
     AZ_REQUIRE_PTR(dx); AZ_REQUIRE_PTR(dgamma); AZ_REQUIRE_PTR(dbeta); AZ_REQUIRE_PTR(coef);
     AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(dy); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(mean);
     AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(gamma);
@@ -606,18 +618,18 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
     const bool nt = total4 * 16 >= BN_NT_BYTES;
     if (bn_bwd_fused()) {
         blocks = bn_bwd_fused_blocks(blocks, C);
-        BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox);
+        BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox, am);
         BN_LAUNCH(bn_bwd_apply_kernel, C, nt, dim3(bn_bwd_apply_grid(total4)), s, (float4 *)dx, (float4 *)dz_out, (const float4 *)dy,
                   (const float4 *)y, (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4,
-                  (const float *)workspace, blocks, gamma, dgamma, dbeta, (double)nvox);
+                  (const float *)workspace, blocks, gamma, dgamma, dbeta, (double)nvox, am);
         return az_launch_status();
     }
-    BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox);
+    BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox, am);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, dgamma, dbeta, coef,
                        workspace, gamma, invstd, blocks, C, (double)nvox, 1);
     BN_LAUNCH(bn_bwd_apply_kernel, C, nt, dim3(BN_GRID(total4)), s, (float4 *)dx, (float4 *)dz_out, (const float4 *)dy,
               (const float4 *)y, (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4,
-              (const float *)nullptr, 0, gamma, dgamma, dbeta, (double)nvox);
+              (const float *)nullptr, 0, gamma, dgamma, dbeta, (double)nvox, am);
     return az_launch_status();
 }
 

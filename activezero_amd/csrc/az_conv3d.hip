@@ -700,3 +700,27 @@ extern "C" int az_conv3d_fwd_stats(float *out, float *partials, float *counts, c
     if (a.ntiles < 0) return (int)a.ntiles;
     return dispatch_mode<1>(a, mode, precision, cin, cout, src, az_stream(stream));
 }
+
+// ---- f16x3: the input-gradient launches (az_roll_common.h) -----------------------------------------------------------
+extern "C" long long az_conv3d_packed_floats_f16(int cin, int cout) {
+    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0) return AZ_EINVAL;
+    return 27LL * cin * cout;  // two fp16 parts per weight
+}
+
+extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
+                                          long long stride_out, long long stride_in, int flip, void *stream) {
+    AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
+    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0) return AZ_EUNSUPPORTED;
+    return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream));
+}
+
+extern "C" int az_conv3d_bwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
+                                 const float *w_amax, const float *residual, int mode, int B, int cin, int cout,
+                                 int Di, int Hi, int Wi, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w); AZ_REQUIRE_PTR(in_amax); AZ_REQUIRE_PTR(w_amax);
+    ConvArgs a{};
+    if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
+    a.in = in; a.wp = packed_w; a.out = out; a.res = residual; a.in_amax = in_amax; a.w_amax = w_amax;
+    if (mode == 0 && cout == 32) return az_conv3d_roll_launch_f16(a, cin, az_stream(stream));
+    return AZ_EUNSUPPORTED;
+}

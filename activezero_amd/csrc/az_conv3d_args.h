@@ -17,7 +17,9 @@ struct ConvArgs {
     int relu;
     int map_mode;  // block->tile map: 0 linear, 1 XCD-chunked linear, 2 XCD-chunked + banded
     int nseg, seg_len;  // az_conv3d_roll.hip: depth segments per patch, output depths per segment
-    int stagger;        // az_conv3d_roll.hip: start offset between co-resident workgroups, in 4096-cycle units
+    // f16x3 launches (az_conv3d_bwd_f16): device scalars holding max |in| and max |w| (az_absmax); the kernels derive
+    // the power-of-two scales from them (az_f16_scale_exp) -- the packed weights are already scaled
+    const float *in_amax, *w_amax;
 };
 
 // bf16x6, stride-1, 32 output channels, 8x16-voxel tile per wave (az_conv3d_m128.hip)
@@ -26,6 +28,11 @@ int az_conv3d_m128_launch(const ConvArgs &a, int cin, int epi, int src, hipStrea
 // bf16x6 on the 16x16x32 MFMA, stride 1, 32 output channels, depth-rolling workgroups (az_conv3d_roll.hip);
 // weights in that kernel's own packed layout (az_conv3d_pack_r16 = az_conv3d_pack_weights precision 2)
 int az_conv3d_roll_launch(const ConvArgs &a, int cin, int epi, hipStream_t s);
+// the same kernel on the f16x3 arithmetic (az_roll_common.h): input gradients; a.in_amax / a.w_amax set, weights packed
+// by az_conv3d_pack_r16_f16
+int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, hipStream_t s);
+int az_conv3d_pack_r16_f16(float *packed, const float *w, const float *w_amax, int cin, int cout, long long stride_out,
+                           long long stride_in, int flip, hipStream_t s);
 long long az_conv3d_roll_stats_tiles(const ConvArgs &a);  // rows of the BatchNorm partial buffers of an EPI-1 launch
 int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long long stride_out, long long stride_in,
                        int flip, hipStream_t s);

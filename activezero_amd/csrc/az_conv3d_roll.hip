@@ -39,6 +39,9 @@
 
 // Diagnostic build only (-DR16_STAMP): shader cycles per wave, summed into a buffer nothing else reads
 // (tools/roll_stamp_probe.py): [0] prologue, [1] stage bodies, [2] stage-end barriers, [3] tail, [8] kernel, [9] waves.
+#ifndef R16H_ABL
+#define R16H_ABL 0  // timing-only builds of the f16x3 stage: 1 no slab staging, 2 no weight refills, 4 no output stores, 8 no fragment refills
+#endif
 #ifdef R16_STAMP
 __device__ unsigned long long r16_stamp_sum[10];
 extern "C" int az_debug_roll_stamps(unsigned long long *out10, int reset) {
@@ -52,11 +55,16 @@ extern "C" int az_debug_roll_stamps(unsigned long long *out10, int reset) {
 #endif
 
 // EPI: 0 = y = relu?(acc * scale + shift), 2 = the same + residual, 1 = raw output + BatchNorm partials
-template <int CIN, int EPI>
+// AR: 0 = bf16x6 (three bf16 parts, six MFMAs per block), 1 = f16x3 (two scaled fp16 parts, three MFMAs: input
+// gradients only, az_roll_common.h); the slab keeps its 192-byte voxels either way (the third 64-byte part is then
+// unused), so addresses and the conflict-free swizzle are shared.
+template <int CIN, int EPI, int AR = 0>
 __global__ void __launch_bounds__(256, 2)
 conv3d_roll_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32;            // 32-channel chunks per plane
-    constexpr int TAPF4 = NCH * 2 * 3 * 64;  // float4 per tap in the packed image: [tap][cc][n16][part][lane]
+    constexpr int NP = AR ? 2 : 3;           // parts per operand
+    constexpr int TAPF4 = NCH * 2 * NP * 64; // float4 per tap in the packed image: [tap][cc][n16][part][lane]
+    static_assert(AR == 0 || EPI != 1, "the forward pass (BatchNorm partials) stays on bf16x6");
     __shared__ __attribute__((aligned(16))) unsigned char slab[2 * R_SLAB_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -95,6 +103,17 @@ conv3d_roll_kernel(const ConvArgs a) {
     const auto rs_cnt = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.cnt : a.out, 0,
                                                           EPI == 1 ? (unsigned)(a.ntiles * 4) : 0u, 0x00020000);
 
+    // f16x3: power-of-two operand scales from the tensors' largest magnitudes (device scalars)
+    float in_scale = 1.f;
+    int out_exp = 0;
+    if (AR) {
+        // (wave-uniform: kept in scalar registers)
+        const int ki = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.in_amax))));
+        const int kw = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_amax))));
+        in_scale = az_pow2(ki);
+        out_exp = -(ki + kw);
+    }
+
     f32x4 acc[3][4];  // [slot: kd = 0 -> output p+1, 1 -> p, 2 -> p-1][4x4-voxel tile of this wave's 4x16 half patch]
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -104,7 +123,11 @@ conv3d_roll_kernel(const ConvArgs a) {
     // ---- staging: one plane chunk = 10 x 18 voxels x 32 channels fp32 -> bf16 triplets in LDS -------------
     // piece idx = tid + 256 it: voxel idx >> 3 (sy = voxel / 18, sx = voxel % 18), channels 4 (idx & 7) ..
     u32x4 pre[R_NLD];
-    auto issue = [&](int p, int cc) {
+    auto issue = [&](int p, int cc, int it0 = 0, int it1 = R_NLD) {  // pieces [it0, it1) (static)
+        int tid = threadIdx.x;
+        // (f16x3: at its register limit -- recompute the piece offsets from the thread index at every call instead of
+        //  keeping six hoisted offsets and their validity masks alive across the stage)
+        if (AR) asm volatile("" : "+v"(tid));
         int sy = 0, sx = tid >> 3;  // (tid >> 3 is 0..31)
         if (sx >= R_SX) { sx -= R_SX; ++sy; }
 #pragma unroll
@@ -113,7 +136,7 @@ conv3d_roll_kernel(const ConvArgs a) {
             const bool ok = (tid + 256 * it < R_NQ) && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi &&
                             (unsigned)p < (unsigned)a.Di;
             const unsigned off = (unsigned)((p * a.Hi + ih) * a.Wi + iw) * (CIN * 4) + cc * 128 + (tid & 7) * 16;
-            pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : R_OOB, 0, 0);
+            if (it >= it0 && it < it1) pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : R_OOB, 0, 0);
             sx += 14; ++sy;  // 32 voxels on = one slab row + 14
             if (sx >= R_SX) { sx -= R_SX; ++sy; }
         }
@@ -122,6 +145,8 @@ conv3d_roll_kernel(const ConvArgs a) {
         // (sy, sx) of piece `it`: static `it`, so this is a handful of integer instructions on tid.  The last
         // piece exists for 160 of the 256 threads only; the others re-write their previous piece (same bytes, same
         // place) instead of branching, so that a stage stays one basic block.
+        int tid = threadIdx.x;
+        if (AR) asm volatile("" : "+v"(tid));  // (see issue)
         const bool live = (tid + 256 * it < R_NQ);
         const int ite = (it > 0 && !live) ? it - 1 : it;
         const int vox = (tid >> 3) + 32 * ite;
@@ -132,12 +157,21 @@ conv3d_roll_kernel(const ConvArgs a) {
             raw[0] = live ? raw[0] : pre[it - 1][0]; raw[1] = live ? raw[1] : pre[it - 1][1];
             raw[2] = live ? raw[2] : pre[it - 1][2]; raw[3] = live ? raw[3] : pre[it - 1][3];
         }
-        uint2 hi, mid, lo;
-        az_split3_bf16x4(__builtin_bit_cast(float4, raw), hi, mid, lo);
         unsigned char *dst = dstbuf + (sy * R_SX + sx) * R_VB + ((((j >> 1) ^ ((sy & 1) << 1))) << 4) + (j & 1) * 8;
-        *reinterpret_cast<uint2 *>(dst) = hi;
-        *reinterpret_cast<uint2 *>(dst + 64) = mid;
-        *reinterpret_cast<uint2 *>(dst + 128) = lo;
+        if (AR) {
+            float4 v = __builtin_bit_cast(float4, raw);
+            v.x *= in_scale; v.y *= in_scale; v.z *= in_scale; v.w *= in_scale;
+            uint2 hi, lo;
+            az_split2_f16x4(v, hi, lo);
+            *reinterpret_cast<uint2 *>(dst) = hi;
+            *reinterpret_cast<uint2 *>(dst + 64) = lo;
+        } else {
+            uint2 hi, mid, lo;
+            az_split3_bf16x4(__builtin_bit_cast(float4, raw), hi, mid, lo);
+            *reinterpret_cast<uint2 *>(dst) = hi;
+            *reinterpret_cast<uint2 *>(dst + 64) = mid;
+            *reinterpret_cast<uint2 *>(dst + 128) = lo;
+        }
     };
 
     // ---- operands ------------------------------------------------------------------------------------------
@@ -150,11 +184,11 @@ conv3d_roll_kernel(const ConvArgs a) {
     // B: packed [tap][cc][n16][part][lane] float4 (conv3d_pack_r16_kernel), this wave's 16 output channels.  Read
     // through a buffer resource: one lane-offset register, the tap's byte offset travels in an SGPR / the immediate
     // (with flat addresses hipcc hoists the 27 x 64-bit tap addresses out of the walk and spills them)
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, 27u * CIN * 32u * 6u, 0x00020000);
-    const unsigned wlane = (unsigned)(wn * 3 * 64 + lane) * 16u;
-    auto load_b = [&](float4 (&bq)[3], int tap_f4) {  // tap_f4: float4 index of the tap's first fragment (static)
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, 27u * CIN * 32u * 2u * NP, 0x00020000);
+    const unsigned wlane = (unsigned)(wn * NP * 64 + lane) * 16u;
+    auto load_b = [&](float4 (&bq)[NP], int tap_f4) {  // tap_f4: float4 index of the tap's first fragment (static)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
             bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, tap_f4 * 16 + p * 1024, 0));
     };
     // per-channel epilogue constants, loaded once (four consecutive channels per lane after the quad transpose)
@@ -163,6 +197,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     if (EPI != 1) {
         if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + cq);
         if (a.shift) sf = *reinterpret_cast<const float4 *>(a.shift + cq);
+        if (AR) { sc.x = ldexpf(sc.x, out_exp); sc.y = ldexpf(sc.y, out_exp); sc.z = ldexpf(sc.z, out_exp); sc.w = ldexpf(sc.w, out_exp); }
     }
     const float floor_ = a.relu ? 0.f : -__builtin_inff();
 
@@ -267,7 +302,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     // LDS reads of a kd-outer order: 1.47 -> 1.435 ms); the three kd weights of a (kh, kw) are double-buffered in
     // registers, requested one (kh, kw) ahead (72 MFMAs).  Slot 2 is complete only at the end of the stage: its
     // epilogue (and the rotation) open the NEXT plane's first stage, and its stores have that whole stage to land.
-    float4 wk[2][3][3];
+    float4 wk[2][3][NP];
     f32x4 tq[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     auto stage_s = [&](auto cc_tag, int p, int buf) {
         constexpr int CC = decltype(cc_tag)::value;
@@ -275,17 +310,17 @@ conv3d_roll_kernel(const ConvArgs a) {
         constexpr int CCN = (CC + 1) % NCH;
         const unsigned char *sl = slab + buf * R_SLAB_BYTES;
         unsigned char *sn = slab + (buf ^ 1) * R_SLAB_BYTES;
-        constexpr int wcur = CC * (2 * 3 * 64), wnxt = CCN * (2 * 3 * 64);
+        constexpr int wcur = CC * (2 * NP * 64), wnxt = CCN * (2 * NP * 64);
         const int pn = LAST ? p + 1 : p;
         if (CC == 0) {
             finish(p - 2, p - 2 >= d0);
             rotate();
         }
-        float4 av[2][3];
-        auto load_a = [&](float4 (&aq)[3], int m, int kh, int kw) {
+        float4 av[2][NP];
+        auto load_a = [&](float4 (&aq)[NP], int m, int kh, int kw) {
             const unsigned char *ap = sl + abase[kh & 1] + (kh * R_SX + 4 * m + kw) * R_VB;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) aq[q] = *reinterpret_cast<const float4 *>(ap + 64 * q);
+            for (int q = 0; q < NP; ++q) aq[q] = *reinterpret_cast<const float4 *>(ap + 64 * q);
         };
         load_a(av[0], 0, 0, 0);
 #pragma unroll
@@ -313,7 +348,7 @@ conv3d_roll_kernel(const ConvArgs a) {
                     // the temporary carried in belongs to the step before: (m, kd-1), (m-1, 2) or the previous
                     // (kh, kw)'s (3, 2); the stage starts with a zero temporary
                     f32x4 &prev = kd > 0 ? acc[kd - 1][m] : (m > 0 ? acc[2][m - 1] : acc[2][3]);
-                    r16_step(tq[st & 1], av[t & 1], wk[j & 1][kd], prev, tq[(st + 1) & 1]);
+                    if constexpr (AR == 0) r16_step(tq[st & 1], av[t & 1], wk[j & 1][kd], prev, tq[(st + 1) & 1]);
                 }
                 if (j >= 5 && j < 8 && (m & 1)) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -328,7 +363,106 @@ conv3d_roll_kernel(const ConvArgs a) {
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) wk[0][kd][q] = wk[1][kd][q];
+            for (int q = 0; q < NP; ++q) wk[0][kd][q] = wk[1][kd][q];
+        R16_T(1);
+        __syncthreads();
+        R16_T(2);
+    };
+
+    // ---- f16x3 (AR = 1): epilogue and stage ------------------------------------------------------------------
+    // accumulator layout (r16_chain9): lane = voxel (row (lane >> 2) & 3, x lane & 3) of the 4x4 tile, registers = the
+    // four channels 16 wn + 4 (lane >> 4) + r: no transpose.  y = acc * 2^out_exp (+ residual); no affine map, no ReLU
+    // (an input gradient has neither).
+    const int cqh = wn * 16 + 4 * (lane >> 4);
+    const float osc = AR ? ldexpf(1.f, out_exp) : 1.f;  // (out_exp beyond the float range: the true result is, too)
+    auto finish_h = [&](int o, bool ok) {
+        const int oh = ty0 + 4 * wm + ((lane >> 2) & 3);
+        const bool row_ok = ok && oh < a.Ho;
+        const unsigned row_off = (unsigned)((o * a.Ho + oh) * a.Wo) * 128u + (unsigned)cqh * 4u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int ow = tx0 + 4 * m + (lane & 3);
+            const unsigned off = (row_ok && ow < a.Wo) ? row_off + (unsigned)ow * 128u : R_OOB;
+            float4 y = make_float4(acc[2][m][0] * osc, acc[2][m][1] * osc, acc[2][m][2] * osc, acc[2][m][3] * osc);
+            if (EPI == 2) {
+                const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
+                y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, (R16H_ABL & 4) ? R_OOB : off, 0, 0);
+        }
+    };
+    // A stage = 36 chains of nine MFMAs (r16_chain9: K = the three kw taps of a (kd, kh) row), ordered kh, tile pair,
+    // kd, tile: 144 accumulate-adds per stage (the K32-block form needs 432 and was VALU-issue bound at 0.94 ms: an
+    // MFMA leaves 8 of its 16 cycles to the vector issue of both waves of the SIMD).  Registers: the voxel fragments of
+    // a tile pair (2 x 3 kw x 2 parts = 48) are read from LDS once and serve the three kd; the weights of a kh row
+    // (3 kd x 3 kw x 2 parts = 72) stay for both pairs, and each kd's set is replaced by the next row's right after
+    // its last use (four chains = 36 MFMAs before its next one).
+    float4 wh[3][3][2];
+    auto load_bh = [&](float4 (&bq)[3][2], int tap0_f4) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                bq[kw][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (tap0_f4 + kw * TAPF4) * 16 + q * 1024, 0));
+    };
+    auto stage_h = [&](auto cc_tag, int p, int buf) {
+        constexpr int CC = decltype(cc_tag)::value;
+        constexpr bool LAST = (CC == NCH - 1);
+        constexpr int CCN = (CC + 1) % NCH;
+        const unsigned char *sl = slab + buf * R_SLAB_BYTES;
+        unsigned char *sn = slab + (buf ^ 1) * R_SLAB_BYTES;
+        constexpr int wcur = CC * (2 * NP * 64), wnxt = CCN * (2 * NP * 64);
+        const int pn = LAST ? p + 1 : p;
+        if (CC == 0) {
+            finish_h(p - 2, p - 2 >= d0);
+            rotate();
+        }
+        float4 ah[2][3][2];
+        auto load_ah = [&](int m, int kh) {
+            const unsigned char *ap = sl + abase[kh & 1] + (kh * R_SX + 4 * m) * R_VB;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ah[m & 1][kw][q] = *reinterpret_cast<const float4 *>(ap + kw * R_VB + 64 * q);
+        };
+        load_ah(0, 0);
+        load_ah(1, 0);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm) {
+                        const int m = 2 * pr + mm;
+                        const int q = ((kh * 2 + pr) * 3 + kd) * 2 + mm;
+                        __builtin_amdgcn_sched_barrier(0);
+                        // the temporary carried in belongs to the chain before (a zero at the stage start)
+                        f32x4 &prev = mm > 0 ? acc[kd][m - 1] : kd > 0 ? acc[kd - 1][m + 1] : pr > 0 ? acc[2][1] : acc[2][3];
+                        r16_chain9(tq[q & 1], ah[mm], wh[kd], prev, tq[(q + 1) & 1]);
+                        if (kd == 2 && !(kh == 2 && pr == 1) && !(R16H_ABL & 8)) {  // this tile's fragments: the next pair's / next row's
+                            __builtin_amdgcn_sched_barrier(0);
+                            load_ah(pr == 0 ? m + 2 : mm, pr == 0 ? kh : kh + 1);
+                        }
+                        if (pr == 1 && mm == 1 && !(R16H_ABL & 2)) {  // last use of this row's (kd) weights: the next row's, or the next stage's first
+                            __builtin_amdgcn_sched_barrier(0);
+                            load_bh(wh[kd], kh < 2 ? wcur + (kd * 9 + (kh + 1) * 3) * TAPF4 : wnxt + (kd * 9) * TAPF4);
+                        }
+                        // the next slab in two halves of three pieces (12 registers in flight instead of 24): requested at
+                        // chains 1 / 16, split and written at chains 10, 12, 14 / 26, 28, 30
+                        if ((q == 1 || q == 16) && !(R16H_ABL & 1)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(pn, CCN, q == 1 ? 0 : 3, q == 1 ? 3 : R_NLD);
+                        }
+                        if (((q >= 10 && q <= 14 && !(q & 1)) || (q >= 26 && q <= 30 && !(q & 1))) && !(R16H_ABL & 1)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            commit_piece(q < 16 ? (q - 10) / 2 : 3 + (q - 26) / 2, sn);
+                        }
+                    }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[2][3] += tq[1];  // the stage's last temporary (36 chains: the last one wrote tq[1])
+        tq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         R16_T(1);
         __syncthreads();
         R16_T(2);
@@ -338,26 +472,32 @@ conv3d_roll_kernel(const ConvArgs a) {
     // planes p_first .. p_last (those of d0-1 .. d1 inside the volume); plane p adds kd to output p + 1 - kd.
     const int p_first = max(d0 - 1, 0), p_last = min(d1, a.Di - 1);
     issue(p_first, 0);
+    if constexpr (AR) {
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd) load_b(wk[0][kd], (kd * 9) * TAPF4);
+        for (int kd = 0; kd < 3; ++kd) load_bh(wh[kd], (kd * 9) * TAPF4);
+    } else {
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) load_b(wk[0][kd], (kd * 9) * TAPF4);
+    }
 #pragma unroll
     for (int it = 0; it < R_NLD; ++it) commit_piece(it, slab);
     __syncthreads();
     R16_T(0);
     int buf = 0;
     for (int p = p_first; p <= p_last; ++p) {
-        if (NCH == 1) {
-            stage_s(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+        if constexpr (AR) {
+            stage_h(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
+            if (NCH == 2) { stage_h(std::integral_constant<int, NCH - 1>{}, p, buf); buf ^= 1; }
         } else {
             stage_s(std::integral_constant<int, 0>{}, p, buf); buf ^= 1;
-            stage_s(std::integral_constant<int, NCH - 1>{}, p, buf); buf ^= 1;
+            if (NCH == 2) { stage_s(std::integral_constant<int, NCH - 1>{}, p, buf); buf ^= 1; }
         }
     }
     // (output p-1 is finished at the top of stage p+1: the last processed plane's is still in slot 2)
-    finish(p_last - 1, p_last - 1 >= d0);
+    if constexpr (AR) finish_h(p_last - 1, p_last - 1 >= d0); else finish(p_last - 1, p_last - 1 >= d0);
     rotate();
     // the last output of a segment that ends at the volume's last plane has no plane behind it
-    if (p_last < d1) finish(p_last, p_last >= d0);
+    if (p_last < d1) { if constexpr (AR) finish_h(p_last, p_last >= d0); else finish(p_last, p_last >= d0); }
     if (EPI == 1) flush_stats();
 #ifdef R16_STAMP
     R16_T(3);
@@ -399,6 +539,34 @@ int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long lo
     return az_launch_status();
 }
 
+// f16x3 packing: [tap][cc32][n16][part(2)][lane(64)][8] fp16 of w * 2^k, k from the tensor's largest magnitude
+__global__ void __launch_bounds__(256)
+conv3d_pack_r16_f16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax,
+                           int cin, int cout, long long sn, long long sk, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float scale = az_pow2(az_f16_scale_exp(*amax));
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    int r = idx >> 9;
+    const int p = r & 1; r >>= 1;
+    const int nn = cout / 16, nch = cin / 32;
+    const int n = r % nn; r /= nn;
+    const int cc = r % nch;
+    const int tap = r / nch;
+    const int co = n * 16 + (lane & 15);
+    const int ci = cc * 32 + 8 * (lane >> 4) + j;
+    dst[idx] = az_split2_f16_part(src[co * sn + ci * sk + (flip ? 26 - tap : tap)] * scale, p);
+}
+
+int az_conv3d_pack_r16_f16(float *packed, const float *w, const float *w_amax, int cin, int cout, long long stride_out,
+                           long long stride_in, int flip, hipStream_t s) {
+    if (cin % 32 || cout % 16 || cin <= 0 || cout <= 0) return AZ_EUNSUPPORTED;
+    const int total = 27 * cin * cout * 2;
+    hipLaunchKernelGGL(conv3d_pack_r16_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, stride_out, stride_in, flip, total);
+    return az_launch_status();
+}
+
 // depth segments: one round of workgroups over the chip's 512 slots (256 CUs x 2) if the patches allow it,
 // otherwise the split that minimises rounds x (planes walked per workgroup)
 static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
@@ -428,7 +596,7 @@ long long az_conv3d_roll_stats_tiles(const ConvArgs &a) {
     return (long long)a.B * nseg * a.tiles_y * a.tiles_x;
 }
 
-template <int CIN, int EPI>
+template <int CIN, int EPI, int AR = 0>
 static int launch_roll(ConvArgs a, hipStream_t s) {
     roll_segments(a, a.nseg, a.seg_len);
     if (EPI == 1) a.ntiles = (long long)a.B * a.nseg * a.tiles_y * a.tiles_x;
@@ -436,8 +604,15 @@ static int launch_roll(ConvArgs a, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     // the kernel addresses one batch element of a tensor through a 32-bit buffer offset
     if ((long long)a.Di * a.Hi * a.Wi * CIN * 4 >= 0xffffff00LL || a.ntiles * 256 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI, AR>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return az_launch_status();
+}
+
+int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, hipStream_t s) {
+    if (!a.in_amax || !a.w_amax) return AZ_ENULL;
+    if (cin == 32) return a.res ? launch_roll<32, 2, 1>(a, s) : launch_roll<32, 0, 1>(a, s);
+    if (cin == 64) return a.res ? launch_roll<64, 2, 1>(a, s) : launch_roll<64, 0, 1>(a, s);
+    return AZ_EUNSUPPORTED;
 }
 
 int az_conv3d_roll_launch(const ConvArgs &a, int cin, int epi, hipStream_t s) {

@@ -623,7 +623,8 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
 }
 
 // all 27 taps per wave on 16x16x32 tiles, four waves sharing one staged set (az_conv3d_wgrad16.hip)
-int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s);
+int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s,
+                               const float *coarse_amax = nullptr, const float *fine_amax = nullptr);
 
 extern "C" long long az_conv3d_wgrad_workspace(int cm, int cn) {
     if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32) return AZ_EINVAL;
@@ -671,5 +672,27 @@ extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long worksp
     const int total = cm * cn * 27;
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w,
                        workspace, cm, cn);
+    return az_launch_status();
+}
+
+// f16x3 weight gradient (include/azhip.h): the stride-1 layers with 32 / 64 channels on either side
+extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *coarse,
+                                   const float *fine, const float *coarse_amax, const float *fine_amax, int stride,
+                                   int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream) {
+    AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(coarse); AZ_REQUIRE_PTR(fine);
+    AZ_REQUIRE_PTR(coarse_amax); AZ_REQUIRE_PTR(fine_amax);
+    AZ_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Df > 0 && Hf > 0 && Wf > 0);
+    AZ_REQUIRE(stride == 1 || stride == 2);
+    const long long need = az_conv3d_wgrad_workspace(cm, cn);
+    if (need < 0) return AZ_EUNSUPPORTED;
+    if (workspace_bytes < need) return AZ_EWORKSPACE;
+    if (!(stride == 1 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64) && Dc == Df && Hc == Hf && Wc == Wf))
+        return AZ_EUNSUPPORTED;
+    hipStream_t s = az_stream(stream);
+    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
+    const int rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s, coarse_amax, fine_amax);
+    if (rc != AZ_OK) return rc;
+    const int total = cm * cn * 27;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm, cn);
     return az_launch_status();
 }

@@ -29,10 +29,8 @@
 // with recomputed addresses +13 %).
 #include <stdlib.h>
 
-#include "az_common.h"
+#include "az_roll_common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
@@ -60,10 +58,15 @@ struct Wg16Args {
     int nwchunk;
     long long ncols;  // B * D * nwchunk columns of work
     int wgs;          // persistent workgroups
+    const float *coarse_amax, *fine_amax;  // f16x3 (AR = 1): device scalars max |coarse|, max |fine|
 };
 
+// AR: 0 = bf16x6 (three bf16 parts, six MFMAs per tap), 1 = f16x3 (two scaled fp16 parts, three MFMAs; az_roll_common.h).
+// The LDS images keep their three-part strides either way (the third part is unused with AR = 1).
+template <int AR>
 __global__ void __launch_bounds__(256, 2)
 conv3d_wgrad_r16_kernel(const Wg16Args a) {
+    constexpr int NP = AR ? 2 : 3;
     __shared__ __attribute__((aligned(16))) unsigned char lds[W16_LDS + 64];  // + a sink for the lanes of a partial piece
     unsigned char *const cbuf = lds;                  // [2][W16_CBUF]
     unsigned char *const fring = lds + 2 * W16_CBUF;  // [plane kd][slot][W16_FROW]
@@ -78,6 +81,13 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
     f32x4 acc[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float c_scale = 1.f, f_scale = 1.f, o_scale = 1.f;
+    if (AR) {  // wave-uniform power-of-two operand scales
+        const int kc = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.coarse_amax))));
+        const int kf = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.fine_amax))));
+        c_scale = az_pow2(kc); f_scale = az_pow2(kf);
+        o_scale = ldexpf(1.f, -(kc + kf));
+    }
 
     // transposing-read geometry (ds_read_b64_tr_b16 on a [k][32 ch] bf16 image): a 16-lane group (= one K octet) reads
     // 4 k-rows x 16 channels; lane 4q + p supplies the address of row q, channels 4p..4p+3 and receives channel (lane & 15)
@@ -150,7 +160,15 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
         auto commit_piece = [&](int it, int cbuf_idx, int frow0) {
             const int q = tid + 256 * it;
             uint2 hi, mid, lo;
-            az_split3_bf16x4(__builtin_bit_cast(float4, pre[it]), hi, mid, lo);
+            if (AR) {
+                float4 v = __builtin_bit_cast(float4, pre[it]);
+                const float sc_ = it == 0 ? c_scale : f_scale;
+                v.x *= sc_; v.y *= sc_; v.z *= sc_; v.w *= sc_;
+                az_split2_f16x4(v, hi, mid);
+                lo = mid;
+            } else {
+                az_split3_bf16x4(__builtin_bit_cast(float4, pre[it]), hi, mid, lo);
+            }
             unsigned char *dst;
             unsigned part_stride;
             if (it == 0) {
@@ -167,7 +185,7 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
             if (q >= W16_NQ) { dst = lds + W16_LDS + (tid & 7) * 8; part_stride = 0; }  // (no branch: a step stays one block)
             *reinterpret_cast<uint2 *>(dst) = hi;
             *reinterpret_cast<uint2 *>(dst + part_stride) = mid;
-            *reinterpret_cast<uint2 *>(dst + 2 * part_stride) = lo;
+            if (!AR) *reinterpret_cast<uint2 *>(dst + 2 * part_stride) = lo;
         };
 
         // ---- prologue: the window of step 0 (fine rows -1 .. 2, coarse rows 0, 1), then the request for step 1 -------
@@ -193,15 +211,15 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) fb[kh] = (unsigned)(rp ? slot[kh + 1] : slot[kh]) * W16_FROW;
 
-            az_bf16x8 af[3];
+            az_bf16x8 af[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = frag2(ca + p * 32 * W16_ROWB, ca + p * 32 * W16_ROWB + 4 * W16_ROWB);
-            az_bf16x8 bf[2][3];
-            auto load_b = [&](az_bf16x8 (&bq)[3], int t) {
+            for (int p = 0; p < NP; ++p) af[p] = frag2(ca + p * 32 * W16_ROWB, ca + p * 32 * W16_ROWB + 4 * W16_ROWB);
+            az_bf16x8 bf[2][NP];
+            auto load_b = [&](az_bf16x8 (&bq)[NP], int t) {
                 const int kd = t / 9, kh = (t % 9) / 3, kw = t % 3;
                 const unsigned char *fp = fring + kd * (W16_RING * W16_FROW) + fb[kh];
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NP; ++p)
                     bq[p] = frag2(fp + b_off[kw][0] + p * W16_FW * W16_ROWB, fp + b_off[kw][1] + p * W16_FW * W16_ROWB);
             };
             load_b(bf[0], 0);
@@ -211,7 +229,12 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
                 if (t + 1 < 27) load_b(bf[(t + 1) & 1], t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 c = acc[t];
-                const az_bf16x8(&bq)[3] = bf[t & 1];
+                const az_bf16x8(&bq)[NP] = bf[t & 1];
+                if constexpr (AR) {  // lo*hi, hi*lo, hi*hi chained into the running accumulator (smallest first, as below)
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(az_f16x8, af[1]), __builtin_bit_cast(az_f16x8, bq[0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bq[1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bq[0]), c, 0, 0, 0);
+                } else {
 #if W16_TWO_CHAINS
                 f32x4 u = {0.f, 0.f, 0.f, 0.f};
                 u = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bq[0], u, 0, 0, 0);
@@ -229,6 +252,7 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bq[1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bq[0], c, 0, 0, 0);
 #endif
+                }
                 acc[t] = c;
                 // the set of step s+1 (requested a step ago): one piece after each of the taps 1, 3, 5, 7, 9; then the
                 // request for step s+2 (17 taps + the next step's first ones to land)
@@ -250,15 +274,16 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * mi + 4 * (lane >> 4) + r;
-            atomicAdd(&a.ws[((size_t)t * a.CM + m) * a.CN + n0 + 16 * ni + (lane & 15)], acc[t][r]);
+            atomicAdd(&a.ws[((size_t)t * a.CM + m) * a.CN + n0 + 16 * ni + (lane & 15)], AR ? acc[t][r] * o_scale : acc[t][r]);
         }
 }
 
 // persistent workgroups: at most 512 resident (2 per CU); the count that balances the columns best
-int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s) {
+int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s,
+                               const float *coarse_amax, const float *fine_amax) {
     if (!((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return AZ_EUNSUPPORTED;
     Wg16Args a{};
-    a.coarse = coarse; a.fine = fine; a.ws = ws;
+    a.coarse = coarse; a.fine = fine; a.ws = ws; a.coarse_amax = coarse_amax; a.fine_amax = fine_amax;
     a.B = B; a.D = D; a.H = H; a.W = W; a.CM = cm; a.CN = cn;
     const int ntiles = (cm / 32) * (cn / 32);
     const int slots = 512 / ntiles;  // resident workgroups per tile (two per CU)
@@ -279,6 +304,7 @@ int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
         if (cap > 0 && cap < best) best = cap;
     }
     a.wgs = best;
-    hipLaunchKernelGGL(conv3d_wgrad_r16_kernel, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
+    if (coarse_amax && fine_amax) hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<1>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<0>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
     return az_launch_status();
 }

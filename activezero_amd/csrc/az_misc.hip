@@ -12,4 +12,4 @@ extern "C" const char *az_strerror(int code) {
     }
 }
 
-extern "C" int az_abi_version(void) { return 4; }
+extern "C" int az_abi_version(void) { return 5; }

@@ -53,6 +53,83 @@ __device__ __forceinline__ void r16_step(f32x4 &tnew, const float4 (&aq)[3], con
     __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
 }
 
+// ---- "f16x3": the backward kernels' arithmetic (round 4) -----------------------------------------------------------
+// Both operands are scaled by a power of two taken from the tensor's largest magnitude (so that the largest element
+// lands in [2^14, 2^15): az_f16_scale_exp) and split into TWO fp16 parts, hi = fp16(x), lo = fp16(x - hi), both
+// round-to-nearest: x = hi + lo up to 2^-22 |x| (11 + 11 significand bits; elements more than 2^17 below the
+// tensor's largest lose low bits of `lo` to the fp16 subnormal spacing: an ABSOLUTE error of 2^-39 of the largest
+// element).  Three products -- hi*hi, hi*lo, lo*hi, largest first -- are summed from zero by
+// v_mfma_f32_16x16x32_f16 and the block sum is added to the fp32 accumulator by VALU adds, as in r16_step; the
+// dropped lo*lo term is <= 2^-22 |x y|.  Half the matrix instructions of bf16x6 for a per-product error of about
+// 2^-22 instead of 2^-24: used for input and weight gradients only (tools/f16x3_probe.py has the per-layer errors
+// against fp64 next to torch's fp32 convolution); the forward pass stays on bf16x6.
+typedef _Float16 az_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 az_f16x2 __attribute__((ext_vector_type(2)));
+// k with 2^k * amax in [2^14, 2^15) (clamped so that 2^k is a normal float; amax = 0, inf or nan: any k works or
+// nothing does)
+__host__ __device__ __forceinline__ int az_f16_scale_exp(float amax) {
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;
+    const int k = 14 - e;
+    return k < -126 ? -126 : (k > 127 ? 127 : k);
+}
+__host__ __device__ __forceinline__ float az_pow2(int k) { return __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }
+
+__device__ __forceinline__ void az_split2_f16_pair(float x0, float x1, unsigned &hi, unsigned &lo) {
+    az_f16x2 h, l;
+    h[0] = (_Float16)x0; h[1] = (_Float16)x1;
+    l[0] = (_Float16)(x0 - (float)h[0]); l[1] = (_Float16)(x1 - (float)h[1]);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// four values (already scaled) -> two 8-byte pieces
+__device__ __forceinline__ void az_split2_f16x4(const float4 &v, uint2 &hi, uint2 &lo) {
+    az_split2_f16_pair(v.x, v.y, hi.x, lo.x);
+    az_split2_f16_pair(v.z, v.w, hi.y, lo.y);
+}
+__device__ __forceinline__ unsigned short az_split2_f16_part(float x, int p) {
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    return __builtin_bit_cast(unsigned short, p == 0 ? h : l);
+}
+
+// One f16x3 chain: the three kw taps of a (kd, kh) row for one 4x4-voxel tile, K = 3 x 32, NINE MFMAs summed from zero
+// (the three hi*hi products first, then the six cross terms), while the temporary of the chain before is added to its
+// accumulator (four VALU adds, placed behind the second and third MFMA: the previous chain's last result is then
+// complete and no wait states are inserted).  One accumulator rounding per 96-deep block.
+// OPERAND ROLES ARE SWAPPED against r16_step: the WEIGHT fragment is the A operand (rows = 16 output channels), the
+// voxel fragment the B operand (columns = 16 voxels), so that the result holds, per lane, FOUR CONSECUTIVE CHANNELS
+// (4 (lane >> 4) + r) of ONE voxel (lane & 15): a 16-byte store without the quad transpose (both fragments have
+// the same register layout -- index lane & 15, k = 8 (lane >> 4) + j -- so the swap costs nothing).
+#define R_MH(ACC, W, X) __builtin_amdgcn_mfma_f32_16x16x32_f16( \
+        __builtin_bit_cast(az_f16x8, W), __builtin_bit_cast(az_f16x8, X), ACC, 0, 0, 0)
+__device__ __forceinline__ void r16_chain9(f32x4 &tnew, const float4 (&x)[3][2], const float4 (&w)[3][2], f32x4 &cprev,
+                                           const f32x4 &tprev) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    float c0 = cprev[0], c1 = cprev[1], c2 = cprev[2], c3 = cprev[3];
+    t = R_MH(t, w[0][0], x[0][0]);
+    t = R_MH(t, w[1][0], x[1][0]);
+    c0 += tprev[0];
+    asm volatile("" : "+v"(c0));
+    c1 += tprev[1];
+    asm volatile("" : "+v"(c1));
+    t = R_MH(t, w[2][0], x[2][0]);
+    c2 += tprev[2];
+    asm volatile("" : "+v"(c2));
+    c3 += tprev[3];
+    asm volatile("" : "+v"(c3));
+    t = R_MH(t, w[0][0], x[0][1]);
+    t = R_MH(t, w[0][1], x[0][0]);
+    t = R_MH(t, w[1][0], x[1][1]);
+    t = R_MH(t, w[1][1], x[1][0]);
+    t = R_MH(t, w[2][0], x[2][1]);
+    t = R_MH(t, w[2][1], x[2][0]);
+    tnew = t;
+    cprev[0] = c0; cprev[1] = c1; cprev[2] = c2; cprev[3] = c3;
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 6, 0);
+}
+
 // 4x4 transpose across the four lanes of a quad: in: lane q holds M[q][0..3]; out: lane q holds M[0..3][q].
 // (C layout of the 16x16 MFMA: lane = output channel, registers = four x-adjacent voxels; after the transpose a
 //  lane holds four consecutive channels of ONE voxel: a 16-byte store, 64 contiguous bytes per quad.)

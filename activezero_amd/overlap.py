@@ -104,7 +104,9 @@ class Sink:
     def join(self):
         if self.joined:
             return
-        torch.cuda.current_stream().wait_stream(self.stream)
+        # (the model's device, not the calling thread's current one: the end-of-backward callback runs outside the
+        #  engine's per-node device guard)
+        torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
         self.keep.clear()
         self.joined = True
         profiler.joined()

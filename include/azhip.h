@@ -171,6 +171,34 @@ int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
                     const float *coarse, const float *fine, int stride, int precision, int B,
                     int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream);
 
+/* ---- "f16x3": the arithmetic of the input- and weight-gradient launches (round 4) ----
+ * The reference computes these gradients in fp32 (cuDNN backward kernels behind Conv3d / ConvTranspose3d,
+ * psmnet_3.py:15-58, psmnet_submodule_3.py:44-56).  Here both operands are scaled by a power of two taken from
+ * the tensor's largest magnitude (device scalars written by az_absmax or by the kernel that produced the tensor)
+ * and split into two fp16 parts, hi + lo = x up to 2^-22 |x|; hi*hi, hi*lo and lo*hi run on
+ * v_mfma_f32_16x16x32_f16 with fp32 accumulation (block sums from zero, one fp32 add per 32-deep block): per-product
+ * error ~2^-22 (bf16x6: 2^-24) at half the matrix instructions.  Results are fp32 and unscaled. */
+/* amax[0] = max |x[i]| (x 16-byte aligned; n > 0); NaN propagates */
+int az_absmax(float *amax, const float *x, long long n, void *stream);
+long long az_conv3d_packed_floats_f16(int cin, int cout);
+/* as az_conv3d_pack_weights, for az_conv3d_bwd_f16: w * 2^k (k from w_amax[0]) split into two fp16 parts,
+ * [tap][cin/32][cout/16][2][64][8 fp16] */
+int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
+                               long long stride_out, long long stride_in, int flip, void *stream);
+/* out = conv(in) (+ residual) with the index map of `mode` (as az_conv3d_fwd), no affine map, no ReLU:
+ * the input gradient of a layer from the gradient of its raw output.  in_amax / w_amax: device scalars
+ * holding max |in| and max |w| (of the UNPACKED weights).  Supported: mode 0 with cout = 32 (the V0 layers);
+ * everything else returns AZ_EUNSUPPORTED. */
+int az_conv3d_bwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
+                      const float *w_amax, const float *residual, int mode, int B, int cin, int cout,
+                      int Di, int Hi, int Wi, void *stream);
+
+/* as az_conv3d_wgrad on the f16x3 arithmetic; coarse_amax / fine_amax: device scalars max |coarse|, max |fine|.
+ * Supported: stride 1 with 32 or 64 channels on either side; everything else returns AZ_EUNSUPPORTED. */
+int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *coarse,
+                        const float *fine, const float *coarse_amax, const float *fine_amax, int stride,
+                        int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream);
+
 /* 32 -> 1 classifier conv (psmnet_3.py:103-117) with the fused running sum
  * cost_k = classif_k(out_k) + cost_{k-1} (psmnet_3.py:177-179): logits [B,D,H,W] =
  * conv(in [B,D,H,W,32], w [1,32,3,3,3]) + addend (may be NULL).
@@ -230,13 +258,15 @@ int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shi
  * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (may be NULL) = dz =
  * gradient of the residual branch.  coef: [C][3] scratch.  scale/shift (both or neither): the
  * forward's affine map; when given for a ReLU layer WITHOUT residual the mask is recomputed as
- * fma(x, scale, shift) > 0 and y is not read (may be NULL). */
+ * fma(x, scale, shift) > 0 and y is not read (may be NULL).
+ * dx_amax (may be NULL): device scalar that receives max |dx| -- the operand scale of the f16x3 input- and
+ * weight-gradient kernels that read dx next, taken while dx is written instead of by a pass of az_absmax. */
 long long az_bn3d_bwd_workspace(long long nvox, int C);
 int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
                 float *workspace, long long workspace_bytes, const float *dy, const float *y,
                 const float *x, const float *mean, const float *invstd, const float *gamma,
                 const float *scale, const float *shift, int relu, long long nvox, int C,
-                void *stream);
+                float *dx_amax, void *stream);
 /* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175 */
 int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, void *stream);
 /* y = a + b (+ c) (+ d), n floats (n % 4 == 0; c, d may be NULL): the gradient of a tensor with up to
