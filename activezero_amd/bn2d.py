@@ -57,7 +57,7 @@ class _BNAct(torch.autograd.Function):
                 from .conv3d import eval_affine
                 scale, shift = eval_affine(bn, xr, cache=cache)
                 _call("az_bn3d_apply", _p(yr), _p(xr), _p(scale), _p(shift), _p(rr), int(relu), nvox * groups, c,
-                      _stream())
+                      None, _stream())
                 ctx.save_for_backward(xr, yr if relu else None, gamma, scale, bn.running_mean.clone())
                 ctx.cfg = (False, relu, residual is not None, groups, (n, c, h, w))
                 return yr.permute(0, 3, 1, 2)

@@ -248,8 +248,7 @@ class _ConvS2Vol(torch.autograd.Function):
         w3 = weight.detach().new_zeros(cout, cin, 3, 3, 3)
         w3[:, :, 1] = weight.detach()
         with torch.cuda.device(x.device):
-            pk, _, _ = conv3d._pack_forward(w3, conv3d.CONV_S2, arith.conv)
-            y = conv3d._run_gather(xv, pk, conv3d.CONV_S2, cin, cout, arith.conv, tag="fe2d_s2")
+            y = conv3d._conv(xv, w3, conv3d.CONV_S2, arith.conv, tag="fe2d_s2")
         ctx.save_for_backward(xv, w3)
         ctx.arith = arith
         ctx.sink = _leaf_sink(arith.sink, weight)

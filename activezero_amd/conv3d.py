@@ -23,13 +23,14 @@ from . import _lib, overlap, profiler
 from .ops import _call, _chk, _p, _stream
 
 CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
-FP32, BF16X6 = 0, 1
-_PREC = {"fp32": FP32, "bf16x6": BF16X6}
-# Arithmetic of the BACKWARD matrix kernels (input and weight gradients) when the forward runs on bf16x6: "f16x3" --
-# operands scaled by a power of two from the tensor's largest magnitude and split into two fp16 parts, three MFMAs per
-# product, fp32 accumulation (include/azhip.h, az_roll_common.h; per-layer error against fp64 at bf16x6's level and
-# below torch's fp32 convolution, tools/f16x3_probe.py) -- wherever an f16x3 kernel exists for the layer's shape.
-# AZ_BWD_F16=0 (read once) keeps every gradient on the forward's arithmetic, for A/B runs.
+FP32, BF16X6, F16X3 = 0, 1, 3
+_PREC = {"fp32": FP32, "bf16x6": BF16X6, "f16x3": F16X3}
+# "f16x3" (precision 3): operands scaled by a power of two from the tensor's largest magnitude and split into two fp16
+# parts, three MFMAs per product, fp32 accumulation (include/azhip.h, az_roll_common.h; per-layer error against fp64 at
+# bf16x6's level and below torch's fp32 convolution, tools/f16x3_probe.py).  It is used wherever an f16x3 kernel exists
+# for the layer's shape (the _f16_*_ok predicates below); other shapes run on bf16x6.  As the arithmetic of the BACKWARD
+# matrix kernels it is on by default with a bf16x6 forward; AZ_BWD_F16=0 (read once) keeps every gradient on the
+# forward's arithmetic, for A/B runs.
 _BWD_F16 = os.environ.get("AZ_BWD_F16", "1") != "0"
 # include/azhip.h precision 2: the bf16x6 arithmetic on the depth-rolling 16x16x32 kernel (az_conv3d_roll.hip),
 # which reads its own packed-weight layout.  Not an arithmetic a caller chooses: _layout() routes the stride-1
@@ -62,17 +63,18 @@ class Arith(collections.namedtuple("Arith", "conv wgrad sink bwd16", defaults=(N
     def of(cls, conv="bf16x6", wgrad=None, bwd16=None):
         w = wgrad if wgrad is not None else conv
         if bwd16 is None:
-            bwd16 = _BWD_F16
-        return cls(_PREC[conv], _PREC[w], None, bool(bwd16) and conv == "bf16x6" and w == "bf16x6")
+            bwd16 = _BWD_F16 or conv == "f16x3"
+        # (the weight-gradient kernels know fp32 and bf16x6; f16x3 reaches them through `bwd16`)
+        return cls(_PREC[conv], BF16X6 if w == "f16x3" else _PREC[w], None, bool(bwd16) and conv != "fp32" and w != "fp32")
 
     @property
     def names(self):
         inv = {v: k for k, v in _PREC.items()}
-        return inv[self.conv], inv[self.wgrad]
+        return inv[self.conv], ("f16x3" if self.bwd16 else inv[self.wgrad])
 
 
 # the default is read ONCE from the environment and never mutated afterwards
-DEFAULT_ARITH = Arith.of(os.environ.get("AZ_CONV_PRECISION", "bf16x6"), os.environ.get("AZ_WGRAD_PRECISION"))
+DEFAULT_ARITH = Arith.of(os.environ.get("AZ_CONV_PRECISION", "f16x3"), os.environ.get("AZ_WGRAD_PRECISION"))
 
 
 def _arith(a):
@@ -183,6 +185,8 @@ def _pack_forward(weight, mode, precision, cache=False, lazy=False):
 def _peak(precision):
     """MFMA roofline of the arithmetic in use, in fp32-equivalent TFLOP/s: the fp32 MFMA dense
     peak, or the bf16 dense peak divided by the six bf16 MFMAs one fp32 product costs."""
+    if precision == F16X3:
+        return _PEAK_F16
     return (157.3, "fp32 MFMA") if precision == FP32 else (2500.0 / 6.0, "bf16x6: bf16 MFMA peak / 6")
 
 
@@ -241,45 +245,114 @@ def _run_gather(x, packed, mode, cin, cout, precision, scale=None, shift=None, r
     return out
 
 
-# ---- f16x3: the backward kernels' arithmetic (include/azhip.h, az_roll_common.h) ------------------------------------
+# ---- f16x3 (include/azhip.h, az_roll_common.h) ---------------------------------------------------------------------
+_PEAK_F16 = (2500.0 / 3.0, "f16x3: fp16 MFMA peak / 3")
+
+
+def _set_amax(t, am):
+    """attach the device scalar max |t| to the tensor object (valid while the tensor's version counter stands)"""
+    t.az_amax = (am, t._version)
+
+
+def _get_amax(t):
+    a = getattr(t, "az_amax", None)
+    return a[0] if (a is not None and a[1] == t._version) else None
+
+
 def absmax(t):
-    """device scalar max |t| (the operand scale of the f16x3 kernels); a producer kernel may have attached it"""
-    am = getattr(t, "az_amax", None)
-    if am is not None:
-        return am
-    am = t.new_empty(1)
-    with profiler.scope("absmax", bytes=4.0 * t.numel(), bound="hbm"):
-        _call("az_absmax", _p(am), _p(t), t.numel(), _stream())
+    """device scalar max |t|, the operand scale of the f16x3 kernels: taken by the kernel that produced t where that is
+    one of this library's (BatchNorm apply / backward, residual sums), by a pass of az_absmax otherwise"""
+    am = _get_amax(t)
+    if am is None:
+        am = t.new_empty(1)
+        with profiler.scope("absmax", bytes=4.0 * t.numel(), bound="hbm"):
+            _call("az_absmax", _p(am), _p(t), t.numel(), _stream())
+        _set_amax(t, am)
     return am
 
 
-def _pack_f16(weight, op_cin, op_cout, stride_out, stride_in, flip):
+def _pack_f16(weight, op_cin, op_cout, stride_out, stride_in, flip, cache=False):
     w = _chk(weight.detach().contiguous(), "weight")
+    key = None
+    if cache:
+        key = (_cache_key(weight), op_cin, op_cout, stride_out, stride_in, bool(flip), F16X3)
+        hit = _cache_get(_PACK_CACHE, key)
+        if hit is not None:
+            return hit[0]
     w_amax = absmax(w)
     packed = torch.empty(_lib.lib().az_conv3d_packed_floats_f16(op_cin, op_cout), dtype=torch.float32, device=w.device)
     _call("az_conv3d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), op_cin, op_cout, stride_out, stride_in,
           int(flip), _stream())
+    if key is not None:
+        _cache_put(_PACK_CACHE, key, ((packed, w_amax), weight), 256)
     return packed, w_amax
 
 
-_PEAK_F16 = (2500.0 / 3.0, "f16x3: fp16 MFMA peak / 3")
+def _f16_fwd_ok(mode, cin, cout):
+    """shapes with an f16x3 forward kernel (operand `cin` channels -> `cout`)"""
+    return mode == CONV_S1 and cout == 32 and cin in (32, 64)
 
 
 def _f16_dgrad_ok(mode, cin, cout):
-    """layers whose input gradient has an f16x3 kernel (operand: dy with `cout` channels -> dx with `cin`)"""
-    return mode == CONV_S1 and cin == 32
+    """layers whose input gradient has an f16x3 kernel: it is a forward launch dy [cout] -> dx [cin] of the dual map"""
+    dual = {CONV_S1: CONV_S1, CONV_S2: DECONV_S2, DECONV_S2: CONV_S2}[mode]
+    return _f16_fwd_ok(dual, cout, cin)
+
+
+def _run_f16(x, packed, w_amax, mode, cin, cout, scale=None, shift=None, residual=None, relu=False, stats=False,
+             tag="conv3d"):
+    b, d, h, w, c = _dims(x)
+    assert c == cin, (c, cin)
+    do, ho, wo = _out_dims(mode, d, h, w)
+    out = x.new_empty(b, do, ho, wo, cout)
+    name = f"{tag}_m{mode}_{cin}_{cout}"
+    flops = _conv_flops(b, do * ho * wo, cin, cout, mode)
+    x_amax = absmax(x)
+    if stats:
+        ntiles = _lib.lib().az_conv3d_stats_tiles_f16(mode, b, cin, cout, d, h, w)
+        if ntiles <= 0:
+            raise RuntimeError(f"az_conv3d_stats_tiles_f16: {ntiles}")
+        part, cnt = x.new_empty(cout, ntiles, 2), x.new_empty(ntiles)
+        with profiler.scope(name, flops=flops, peak=_PEAK_F16):
+            _call("az_conv3d_fwd_stats_f16", _p(out), _p(part), _p(cnt), _p(x), _p(packed), _p(x_amax), _p(w_amax),
+                  mode, b, cin, cout, d, h, w, _stream())
+        return out, part, cnt, ntiles
+    with profiler.scope(name, flops=flops, peak=_PEAK_F16):
+        _call("az_conv3d_fwd_f16", _p(out), _p(x), _p(packed), _p(x_amax), _p(w_amax), _p(scale), _p(shift),
+              _p(residual), int(relu), mode, b, cin, cout, d, h, w, _stream())
+    return out
+
+
+def _conv(x, weight, mode, precision, scale=None, shift=None, residual=None, relu=False, stats=False, cache=False,
+          tag="conv3d"):
+    """forward convolution of a layer from its weight in PyTorch's layout, on `precision` where a kernel for the shape
+    exists (f16x3 falls back to bf16x6 otherwise); returns what _run_gather returns"""
+    lazy = isinstance(x, LazyCostVolume)
+    if mode == DECONV_S2:
+        cin, cout = weight.shape[0], weight.shape[1]
+    else:
+        cout, cin = weight.shape[0], weight.shape[1]
+    if precision == F16X3 and not lazy and _f16_fwd_ok(mode, cin, cout):
+        if mode == DECONV_S2:
+            pk, w_amax = _pack_f16(weight, cin, cout, 27, cout * 27, False, cache)
+        else:
+            pk, w_amax = _pack_f16(weight, cin, cout, cin * 27, 27, False, cache)
+        return _run_f16(x, pk, w_amax, mode, cin, cout, scale, shift, residual, relu, stats, tag)
+    prec = BF16X6 if precision == F16X3 else precision
+    packed, cin, cout = _pack_forward(weight, mode, prec, cache=cache, lazy=lazy)
+    return _run_gather(x, packed, mode, cin, cout, prec, scale, shift, residual, relu, stats, tag)
 
 
 def _input_grad_f16(dy, weight, mode, cin, cout, residual=None):
-    b, d, h, w, c = _dims(dy)
-    assert mode == CONV_S1 and c == cout
-    pk, w_amax = _pack_f16(weight, cout, cin, 27, cin * 27, True)
-    out = dy.new_empty(b, d, h, w, cin)
-    with profiler.scope(f"dgrad_m{mode}_{cout}_{cin}", flops=_conv_flops(b, d * h * w, cout, cin, mode),
-                        peak=_PEAK_F16):
-        _call("az_conv3d_bwd_f16", _p(out), _p(dy), _p(pk), _p(absmax(dy)), _p(w_amax), _p(residual), mode,
-              b, cout, cin, d, h, w, _stream())
-    return out
+    """f16x3 form of _input_grad (shapes of _f16_dgrad_ok)"""
+    if mode == CONV_S1:    # flipped taps, channels swapped
+        pk, w_amax = _pack_f16(weight, cout, cin, 27, cin * 27, True)
+        return _run_f16(dy, pk, w_amax, CONV_S1, cout, cin, residual=residual, tag="dgrad")
+    if mode == CONV_S2:    # transposed conv of dy with W[co][ci][k]
+        pk, w_amax = _pack_f16(weight, cout, cin, 27, cin * 27, False)
+        return _run_f16(dy, pk, w_amax, DECONV_S2, cout, cin, residual=residual, tag="dgrad")
+    pk, w_amax = _pack_f16(weight, cout, cin, cout * 27, 27, False)  # stride-2 conv of dy with Wt[ci][co][k]
+    return _run_f16(dy, pk, w_amax, CONV_S2, cout, cin, residual=residual, tag="dgrad")
 
 
 def _f16_wgrad_ok(mode, cin, cout):
@@ -291,7 +364,7 @@ def _wgrad_f16(coarse, fine, stride, cm, cn, tag, sink=None):
     _, df, hf, wf, _ = _dims(fine)
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
     ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
-    am_c, am_f = getattr(coarse, "az_amax", None), getattr(fine, "az_amax", None)
+    am_c, am_f = _get_amax(coarse), _get_amax(fine)
     with overlap.scope(sink, coarse, fine, gw, am_c, am_f):
         ws = coarse.new_empty(ws_bytes // 4)
         am_c, am_f = absmax(coarse), absmax(fine)  # (a pass over the tensor only when its producer attached none)
@@ -326,6 +399,10 @@ def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
 
 def _input_grad(dy, weight, mode, cin, cout, precision):
     """gradient of the layer's input from the gradient dy of its (raw) convolution output"""
+    if precision == F16X3:
+        if _f16_dgrad_ok(mode, cin, cout):
+            return _input_grad_f16(dy, weight, mode, cin, cout)
+        precision = BF16X6
     if mode == CONV_S1:    # flipped taps, channels swapped
         pk = _pack(weight, cout, cin, 27, cin * 27, True, _layout(precision, CONV_S1, cin))
         return _run_gather(dy, pk, CONV_S1, cout, cin, precision, tag="dgrad")
@@ -337,6 +414,10 @@ def _input_grad(dy, weight, mode, cin, cout, precision):
 
 
 def _weight_grad(x, dy, mode, cin, cout, precision, sink=None):
+    if precision == F16X3:
+        if _f16_wgrad_ok(mode, cin, cout):
+            return _weight_grad_f16(x, dy, mode, cin, cout, sink)
+        precision = BF16X6
     if mode == DECONV_S2:
         return _wgrad(x, dy, 2, cin, cout, "deconv", precision, sink)
     return _wgrad(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", precision, sink)
@@ -352,21 +433,26 @@ class _ConvBN(torch.autograd.Function):
             residual = _chk(residual, "residual")
         training = bn.training or not bn.track_running_stats
         eps = float(bn.eps)
+        if mode == DECONV_S2:
+            cin, cout = weight.shape[0], weight.shape[1]
+        else:
+            cout, cin = weight.shape[0], weight.shape[1]
         with torch.cuda.device(x.device):
-            packed, cin, cout = _pack_forward(weight, mode, arith.conv)
             if not training:
                 # eval-mode BatchNorm under autograd (fine-tuning with frozen statistics): the same
                 # kernels, with the running-statistics affine map; backward below
                 scale, shift = eval_affine(bn, x)
-                raw = _run_gather(x, packed, mode, cin, cout, arith.conv)
+                raw = _conv(x, weight, mode, arith.conv)
                 y = torch.empty_like(raw)
+                y_amax = raw.new_empty(1)
                 _call("az_bn3d_apply", _p(y), _p(raw), _p(scale), _p(shift), _p(residual), int(relu),
-                      raw.numel() // cout, cout, _stream())
+                      raw.numel() // cout, cout, _p(y_amax), _stream())
+                _set_amax(y, y_amax)
                 ctx.save_for_backward(x, weight, gamma, raw, y if relu else None, bn.running_mean.clone(),
                                       scale, None, None)
                 ctx.cfg = (mode, relu, residual is not None, cin, cout, arith, False)
                 return y
-            raw, part, cnt, ntiles = _run_gather(x, packed, mode, cin, cout, arith.conv, stats=True)
+            raw, part, cnt, ntiles = _conv(x, weight, mode, arith.conv, stats=True)
             scale, shift = x.new_empty(cout), x.new_empty(cout)
             mean, invstd = x.new_empty(cout), x.new_empty(cout)
             track = bn.track_running_stats and bn.running_mean is not None
@@ -387,10 +473,12 @@ class _ConvBN(torch.autograd.Function):
                 y = raw
             else:
                 y = torch.empty_like(raw)
+                y_amax = raw.new_empty(1)
                 with profiler.scope(f"bn3d_apply_{cout}", bytes=4.0 * raw.numel() * (3 if residual is not None else 2),
                                     bound="hbm"):
                     _call("az_bn3d_apply", _p(y), _p(raw), _p(scale), _p(shift), _p(residual), int(relu),
-                          nvox, cout, _stream())
+                          nvox, cout, _p(y_amax), _stream())
+                _set_amax(y, y_amax)
         # a ReLU layer without residual recomputes its mask from raw in backward (fma(raw, scale, shift) > 0)
         remask = relu and residual is None
         ctx.save_for_backward(x, weight, gamma, raw, y if (relu and not remask) else None, mean, invstd,
@@ -398,6 +486,8 @@ class _ConvBN(torch.autograd.Function):
         if arith.sink is not None and not arith.sink.owns(weight):  # see conv2d._leaf_sink
             arith = arith._replace(sink=None)
         ctx.cfg = (mode, relu, residual is not None, cin, cout, arith, True)
+        # the f16x3 weight gradient scales its operand x by max |x|: keep what the forward pass knows of it
+        ctx.x_amax = _get_amax(x)
         return y
 
     @staticmethod
@@ -433,20 +523,15 @@ class _ConvBN(torch.autograd.Function):
                           _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), _p(scale), _p(shift),
                           int(relu), nvox, cout, _p(dx_amax), _stream())
                 if dx_amax is not None:
-                    dx_raw.az_amax = dx_amax
+                    _set_amax(dx_raw, dx_amax)
                 g_res = (dz if relu else gy) if has_res else None
             gx = gw = None
-            f16 = training and arith.bwd16
             if ctx.needs_input_grad[0]:
-                if f16 and _f16_dgrad_ok(mode, cin, cout):
-                    gx = _input_grad_f16(dx_raw, weight, mode, cin, cout)
-                else:
-                    gx = _input_grad(dx_raw, weight, mode, cin, cout, arith.conv)
+                gx = _input_grad(dx_raw, weight, mode, cin, cout, F16X3 if arith.bwd16 else arith.conv)
             if ctx.needs_input_grad[1]:
-                if f16 and _f16_wgrad_ok(mode, cin, cout):
-                    gw = _weight_grad_f16(x, dx_raw, mode, cin, cout, arith.sink)
-                else:
-                    gw = _weight_grad(x, dx_raw, mode, cin, cout, arith.wgrad, arith.sink)
+                if getattr(ctx, "x_amax", None) is not None and _get_amax(x) is None:
+                    _set_amax(x, ctx.x_amax)
+                gw = _weight_grad(x, dx_raw, mode, cin, cout, F16X3 if arith.bwd16 else arith.wgrad, arith.sink)
         return gx, gw, dgamma, dbeta, g_res, None, None, None, None, None
 
 
@@ -468,18 +553,16 @@ def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None, defer=None
         if torch.is_grad_enabled() or bn.training:
             raise RuntimeError("LazyCostVolume is an inference-only operand")
         with torch.cuda.device(x.fl.device):
-            packed, cin, cout = _pack_forward(conv.weight, mode, arith.conv, cache=True, lazy=True)
             scale, shift = eval_affine(bn, x.fl, cache=True)
-            return _run_gather(x, packed, mode, cin, cout, arith.conv, scale, shift, residual, relu)
+            return _conv(x, conv.weight, mode, arith.conv, scale, shift, residual, relu, cache=True)
     training = bn.training or not bn.track_running_stats
     if not training and not torch.is_grad_enabled():
         # inference: BatchNorm folded into the conv epilogue, packed weights / affine maps memoised
         x = _chk(x, "x")
         with torch.cuda.device(x.device):
-            packed, cin, cout = _pack_forward(conv.weight, mode, arith.conv, cache=True)
             scale, shift = eval_affine(bn, x, cache=True)
-            return _run_gather(x, packed, mode, cin, cout, arith.conv, scale, shift,
-                               _chk(residual, "residual") if residual is not None else None, relu)
+            return _conv(x, conv.weight, mode, arith.conv, scale, shift,
+                         _chk(residual, "residual") if residual is not None else None, relu, cache=True)
     w = arith.sink.weight(conv.weight) if arith.sink is not None else conv.weight
     return _ConvBN.apply(x, w, bn.weight, bn.bias, residual, bn, mode, relu, arith, defer)
 
@@ -537,8 +620,10 @@ class _AddRelu(torch.autograd.Function):
     def forward(ctx, a, b):
         a, b = _chk(a, "a"), _chk(b, "b")
         y = torch.empty_like(a)
+        y_amax = a.new_empty(1)
         with torch.cuda.device(a.device):
-            _call("az_add_relu", _p(y), _p(a), _p(b), 0, a.numel(), _stream())
+            _call("az_add_relu", _p(y), _p(a), _p(b), 0, a.numel(), _p(y_amax), _stream())
+        _set_amax(y, y_amax)
         return y
 
     @staticmethod
@@ -556,7 +641,12 @@ class _FanOut(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n):
-        return tuple(x.view_as(x) for _ in range(n))
+        views = tuple(x.view_as(x) for _ in range(n))
+        am = _get_amax(x)
+        if am is not None:
+            for v in views:
+                _set_amax(v, am)
+        return views
 
     @staticmethod
     def backward(ctx, *grads):
@@ -583,5 +673,4 @@ def fanout(x, n):
 def conv_plain(x, weight, mode, arith=None):
     """Bare convolution (no BN), forward only -- used by parity tests and tools."""
     arith = _arith(arith)
-    packed, cin, cout = _pack_forward(weight, mode, arith.conv)
-    return _run_gather(_chk(x, "x"), packed, mode, cin, cout, arith.conv)
+    return _conv(_chk(x, "x"), weight, mode, arith.conv)

@@ -169,8 +169,9 @@ template <int C, bool NT>
 __global__ void __launch_bounds__(256)
 bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
                 const float *__restrict__ scale, const float *__restrict__ shift,
-                const float4 *__restrict__ res, int relu, long long total4) {
+                const float4 *__restrict__ res, int relu, long long total4, unsigned *__restrict__ amax = nullptr) {
     constexpr int C4 = C / 4;
+    unsigned am = 0;
     __shared__ float4 ssc[C4], ssh[C4];
     {   // blockIdx.y = statistic group: its own slice of the tensors and its own (scale, shift)
         const long long go = (long long)blockIdx.y * total4;
@@ -197,7 +198,9 @@ bn_apply_kernel(float4 *__restrict__ y, const float4 *__restrict__ x,
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
         bn_st4<NT>(&y[i], o);
+        az_amax_acc(am, o);
     }
+    if (amax) az_amax_flush(amax, am);
 }
 
 __device__ __forceinline__ int c4_of(int tid, int C4) { return tid % C4; }
@@ -425,20 +428,16 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
         o.z = k0[c + 2] * (g.z - k1[c + 2] - (xx.z - smu[c + 2]) * sis[c + 2] * k2[c + 2]);
         o.w = k0[c + 3] * (g.w - k1[c + 3] - (xx.w - smu[c + 3]) * sis[c + 3] * k2[c + 3]);
         bn_st4<NT>(&dx[i], o);
-        am = max(max(am, __float_as_uint(o.x) & 0x7fffffffu), max(__float_as_uint(o.y) & 0x7fffffffu,
-                 max(__float_as_uint(o.z) & 0x7fffffffu, __float_as_uint(o.w) & 0x7fffffffu)));
+        az_amax_acc(am, o);
     }
-    if (amax) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax, am);
-    }
+    if (amax) az_amax_flush(amax, am);
 }
 
 // y = relu?(a + b) and its masked backward, for the plain residual sums of psmnet_3.py
 __global__ void __launch_bounds__(256)
 add_relu_kernel(float4 *__restrict__ y, const float4 *__restrict__ a,
-                const float4 *__restrict__ b, int relu, long long total4) {
+                const float4 *__restrict__ b, int relu, long long total4, unsigned *__restrict__ amax) {
+    unsigned am = 0;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
         const float4 p = a[i], q = b[i];
         float4 o = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
@@ -446,7 +445,9 @@ add_relu_kernel(float4 *__restrict__ y, const float4 *__restrict__ a,
             o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         }
         y[i] = o;
+        az_amax_acc(am, o);
     }
+    if (amax) az_amax_flush(amax, am);
 }
 
 
@@ -578,16 +579,17 @@ extern "C" int az_bn3d_eval_affine(float *scale, float *shift, const float *gamm
 }
 
 extern "C" int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shift,
-                             const float *residual, int relu, long long nvox, int C,
+                             const float *residual, int relu, long long nvox, int C, float *y_amax,
                              void *stream) {
     AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
     AZ_REQUIRE(nvox > 0);
+    if (y_amax && hipMemsetAsync(y_amax, 0, sizeof(float), az_stream(stream)) != hipSuccess) return AZ_ELAUNCH;
     const long long total4 = nvox * C / 4;
     const float4 *r4 = reinterpret_cast<const float4 *>(residual);
     if (C != 32 && C != 64 && C != 128) return AZ_EUNSUPPORTED;
     const bool nt = total4 * 16 >= BN_NT_BYTES;
     BN_LAUNCH(bn_apply_kernel, C, nt, dim3(BN_GRID(total4)), az_stream(stream), (float4 *)y, (const float4 *)x, scale,
-              shift, r4, relu, total4);
+              shift, r4, relu, total4, reinterpret_cast<unsigned *>(y_amax));
     return az_launch_status();
 }
 
@@ -633,12 +635,13 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
     return az_launch_status();
 }
 
-extern "C" int az_add_relu(float *y, const float *a, const float *b, int relu, long long n,
+extern "C" int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, float *y_amax,
                            void *stream) {
     AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(a); AZ_REQUIRE_PTR(b);
     AZ_REQUIRE(n > 0 && n % 4 == 0);
+    if (y_amax && hipMemsetAsync(y_amax, 0, sizeof(float), az_stream(stream)) != hipSuccess) return AZ_ELAUNCH;
     hipLaunchKernelGGL(add_relu_kernel, dim3(BN_GRID(n / 4)), dim3(256), 0, az_stream(stream),
-                       (float4 *)y, (const float4 *)a, (const float4 *)b, relu, n / 4);
+                       (float4 *)y, (const float4 *)a, (const float4 *)b, relu, n / 4, reinterpret_cast<unsigned *>(y_amax));
     return az_launch_status();
 }
 

@@ -44,6 +44,19 @@ __device__ __forceinline__ float4 az_ld16_or_zero(const float *base, size_t offs
     return r;
 }
 
+// ---- max |x| of a tensor, taken by the kernel that writes it (the operand scale of the f16x3 kernels that read it
+// next; az_absmax.hip is the stand-alone pass).  |x| is compared as a bit pattern: non-negative floats order like
+// unsigned integers and a NaN compares above everything.  The destination word must be zero before the launch.
+__device__ __forceinline__ void az_amax_acc(unsigned &am, const float4 &o) {
+    am = max(max(am, __float_as_uint(o.x) & 0x7fffffffu), max(__float_as_uint(o.y) & 0x7fffffffu,
+             max(__float_as_uint(o.z) & 0x7fffffffu, __float_as_uint(o.w) & 0x7fffffffu)));
+}
+__device__ __forceinline__ void az_amax_flush(unsigned *dst, unsigned am) {  // one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(dst, am);
+}
+
 // Exact 3-way split of fp32 values into bf16 parts, ROUND-TO-NEAREST-EVEN at every level:
 //   hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid);   x == hi + mid + lo exactly
 // (8 + 8 + 8 signed significand bits cover fp32's 24).  The three partial products the bf16x6 arithmetic

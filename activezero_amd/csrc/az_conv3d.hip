@@ -714,13 +714,36 @@ extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const f
     return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream));
 }
 
-extern "C" int az_conv3d_bwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
-                                 const float *w_amax, const float *residual, int mode, int B, int cin, int cout,
-                                 int Di, int Hi, int Wi, void *stream) {
+static int conv_f16_dispatch(ConvArgs &a, int mode, int cin, int cout, int epi, hipStream_t s) {
+    if (mode == 0 && cout == 32) return az_conv3d_roll_launch_f16(a, cin, epi, s);
+    return AZ_EUNSUPPORTED;
+}
+
+extern "C" int az_conv3d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
+                                 const float *w_amax, const float *scale, const float *shift, const float *residual,
+                                 int relu, int mode, int B, int cin, int cout, int Di, int Hi, int Wi, void *stream) {
     AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w); AZ_REQUIRE_PTR(in_amax); AZ_REQUIRE_PTR(w_amax);
     ConvArgs a{};
     if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
-    a.in = in; a.wp = packed_w; a.out = out; a.res = residual; a.in_amax = in_amax; a.w_amax = w_amax;
-    if (mode == 0 && cout == 32) return az_conv3d_roll_launch_f16(a, cin, az_stream(stream));
+    a.in = in; a.wp = packed_w; a.out = out; a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu;
+    a.in_amax = in_amax; a.w_amax = w_amax;
+    return conv_f16_dispatch(a, mode, cin, cout, 0, az_stream(stream));
+}
+
+extern "C" long long az_conv3d_stats_tiles_f16(int mode, int B, int cin, int cout, int Di, int Hi, int Wi) {
+    if (mode == 0 && cout == 32) return az_conv3d_stats_tiles(mode, 2, B, cin, cout, Di, Hi, Wi);
     return AZ_EUNSUPPORTED;
+}
+
+extern "C" int az_conv3d_fwd_stats_f16(float *out, float *partials, float *counts, const float *in, const float *packed_w,
+                                       const float *in_amax, const float *w_amax, int mode, int B, int cin, int cout,
+                                       int Di, int Hi, int Wi, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w); AZ_REQUIRE_PTR(in_amax); AZ_REQUIRE_PTR(w_amax);
+    AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts);
+    ConvArgs a{};
+    if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
+    a.in = in; a.wp = packed_w; a.out = out; a.part = partials; a.cnt = counts; a.in_amax = in_amax; a.w_amax = w_amax;
+    a.ntiles = az_conv3d_stats_tiles_f16(mode, B, cin, cout, Di, Hi, Wi);
+    if (a.ntiles < 0) return (int)a.ntiles;
+    return conv_f16_dispatch(a, mode, cin, cout, 1, az_stream(stream));
 }

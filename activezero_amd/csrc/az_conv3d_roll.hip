@@ -64,7 +64,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32;            // 32-channel chunks per plane
     constexpr int NP = AR ? 2 : 3;           // parts per operand
     constexpr int TAPF4 = NCH * 2 * NP * 64; // float4 per tap in the packed image: [tap][cc][n16][part][lane]
-    static_assert(AR == 0 || EPI != 1, "the forward pass (BatchNorm partials) stays on bf16x6");
+
     __shared__ __attribute__((aligned(16))) unsigned char slab[2 * R_SLAB_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -374,22 +374,81 @@ conv3d_roll_kernel(const ConvArgs a) {
     // four channels 16 wn + 4 (lane >> 4) + r: no transpose.  y = acc * 2^out_exp (+ residual); no affine map, no ReLU
     // (an input gradient has neither).
     const int cqh = wn * 16 + 4 * (lane >> 4);
-    const float osc = AR ? ldexpf(1.f, out_exp) : 1.f;  // (out_exp beyond the float range: the true result is, too)
+    float4 sch = make_float4(1.f, 1.f, 1.f, 1.f), sfh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AR) {
+        if (EPI != 1) {
+            if (a.scale) sch = *reinterpret_cast<const float4 *>(a.scale + cqh);
+            if (a.shift) sfh = *reinterpret_cast<const float4 *>(a.shift + cqh);
+        }
+        // the power-of-two unscaling rides on the affine map (out_exp beyond the float range: the true result is, too)
+        sch.x = ldexpf(sch.x, out_exp); sch.y = ldexpf(sch.y, out_exp); sch.z = ldexpf(sch.z, out_exp); sch.w = ldexpf(sch.w, out_exp);
+    }
+    // BatchNorm partials (EPI 1), this layout: per lane running sums of its FOUR channels over its voxel of each tile
+    // (shifted-data sums as in the bf16x6 form above); lanes of a channel quad are merged once, after the walk
+    float hk[4] = {0.f, 0.f, 0.f, 0.f}, hs1[4] = {0.f, 0.f, 0.f, 0.f}, hs2[4] = {0.f, 0.f, 0.f, 0.f};
+    int h_n = 0;
+    bool h_first = true;
     auto finish_h = [&](int o, bool ok) {
         const int oh = ty0 + 4 * wm + ((lane >> 2) & 3);
         const bool row_ok = ok && oh < a.Ho;
         const unsigned row_off = (unsigned)((o * a.Ho + oh) * a.Wo) * 128u + (unsigned)cqh * 4u;
+        if (EPI == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hk[r] = (row_ok && h_first) ? acc[2][0][r] * sch.x : hk[r];  // (sch.x = 2^out_exp here)
+            h_first = h_first && !row_ok;
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int ow = tx0 + 4 * m + (lane & 3);
-            const unsigned off = (row_ok && ow < a.Wo) ? row_off + (unsigned)ow * 128u : R_OOB;
-            float4 y = make_float4(acc[2][m][0] * osc, acc[2][m][1] * osc, acc[2][m][2] * osc, acc[2][m][3] * osc);
+            const bool vok = row_ok && ow < a.Wo;
+            const unsigned off = vok ? row_off + (unsigned)ow * 128u : R_OOB;
+            float4 y = make_float4(fmaf(acc[2][m][0], sch.x, sfh.x), fmaf(acc[2][m][1], sch.y, sfh.y),
+                                   fmaf(acc[2][m][2], sch.z, sfh.z), fmaf(acc[2][m][3], sch.w, sfh.w));
             if (EPI == 2) {
                 const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
                 y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
             }
+            if (EPI != 1) { y.x = fmaxf(y.x, floor_); y.y = fmaxf(y.y, floor_); y.z = fmaxf(y.z, floor_); y.w = fmaxf(y.w, floor_); }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, (R16H_ABL & 4) ? R_OOB : off, 0, 0);
+            if (EPI == 1) {
+                h_n += vok ? 1 : 0;
+                const float v[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dlt = vok ? v[r] - hk[r] : 0.f;
+                    hs1[r] += dlt;
+                    hs2[r] = fmaf(dlt, dlt, hs2[r]);
+                }
+            }
         }
+    };
+    auto flush_stats_h = [&]() {
+        const int tiy4 = 2 * tiy + wm;
+        const bool tile_ok = tiy4 < a.tiles_y;
+        const unsigned tile_id = (unsigned)(((b * a.nseg + seg) * a.tiles_y + tiy4) * a.tiles_x + tix);
+        float ntot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float n = (float)h_n;
+            float mean = n > 0.f ? hk[r] + hs1[r] / n : 0.f;
+            float m2 = n > 0.f ? hs2[r] - hs1[r] * hs1[r] / n : 0.f;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {  // the 16 voxel lanes of this channel quad
+                const float n_o = __shfl_xor(n, off), mean_o = __shfl_xor(mean, off), m2_o = __shfl_xor(m2, off);
+                const float nn = n + n_o;
+                const float dlt = mean_o - mean;
+                const float w_o = nn > 0.f ? n_o / nn : 0.f;
+                m2 = m2 + m2_o + dlt * dlt * n * w_o;
+                mean = mean + dlt * w_o;
+                n = nn;
+            }
+            ntot = n;
+            const unsigned ch = (unsigned)(cqh + r);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(n * mean, fmaxf(m2, 0.f))), rs_part,
+                                                  (tile_ok && (lane & 15) == 0 && !R16_NOPART) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ntot), rs_cnt,
+                                              (tile_ok && lane == 0 && wn == 0) ? tile_id * 4u : R_OOB, 0, 0);
     };
     // A stage = 36 chains of nine MFMAs (r16_chain9: K = the three kw taps of a (kd, kh) row), ordered kh, tile pair,
     // kd, tile: 144 accumulate-adds per stage (the K32-block form needs 432 and was VALU-issue bound at 0.94 ms: an
@@ -498,7 +557,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     rotate();
     // the last output of a segment that ends at the volume's last plane has no plane behind it
     if (p_last < d1) { if constexpr (AR) finish_h(p_last, p_last >= d0); else finish(p_last, p_last >= d0); }
-    if (EPI == 1) flush_stats();
+    if (EPI == 1) { if constexpr (AR) flush_stats_h(); else flush_stats(); }
 #ifdef R16_STAMP
     R16_T(3);
     if (lane == 0) {
@@ -608,10 +667,11 @@ static int launch_roll(ConvArgs a, hipStream_t s) {
     return az_launch_status();
 }
 
-int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, hipStream_t s) {
+int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, int epi, hipStream_t s) {
     if (!a.in_amax || !a.w_amax) return AZ_ENULL;
-    if (cin == 32) return a.res ? launch_roll<32, 2, 1>(a, s) : launch_roll<32, 0, 1>(a, s);
-    if (cin == 64) return a.res ? launch_roll<64, 2, 1>(a, s) : launch_roll<64, 0, 1>(a, s);
+    const int e = epi ? 1 : (a.res ? 2 : 0);
+    if (cin == 32) return e == 1 ? launch_roll<32, 1, 1>(a, s) : e == 2 ? launch_roll<32, 2, 1>(a, s) : launch_roll<32, 0, 1>(a, s);
+    if (cin == 64) return e == 1 ? launch_roll<64, 1, 1>(a, s) : e == 2 ? launch_roll<64, 2, 1>(a, s) : launch_roll<64, 0, 1>(a, s);
     return AZ_EUNSUPPORTED;
 }
 

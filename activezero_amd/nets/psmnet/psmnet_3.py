@@ -92,8 +92,9 @@ class PSMNet(nn.Module):
         self.wgrad_overlap = bool(enabled)
         return self
 
-    def set_arithmetic(self, conv="bf16x6", wgrad=None):
-        """'bf16x6' (default: exact 3-way bf16 split, six MFMAs per product) or 'fp32' (fp32 MFMA)."""
+    def set_arithmetic(self, conv="f16x3", wgrad=None):
+        """'f16x3' (default: two scaled fp16 parts, three MFMAs per product, where a kernel for the shape exists),
+        'bf16x6' (exact 3-way bf16 split, six MFMAs per product) or 'fp32' (fp32 MFMA)."""
         self.arith = conv3d.Arith.of(conv, wgrad)
         return self
 

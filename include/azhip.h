@@ -185,14 +185,17 @@ long long az_conv3d_packed_floats_f16(int cin, int cout);
  * [tap][cin/32][cout/16][2][64][8 fp16] */
 int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
                                long long stride_out, long long stride_in, int flip, void *stream);
-/* out = conv(in) (+ residual) with the index map of `mode` (as az_conv3d_fwd), no affine map, no ReLU:
- * the input gradient of a layer from the gradient of its raw output.  in_amax / w_amax: device scalars
- * holding max |in| and max |w| (of the UNPACKED weights).  Supported: mode 0 with cout = 32 (the V0 layers);
- * everything else returns AZ_EUNSUPPORTED. */
-int az_conv3d_bwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
-                      const float *w_amax, const float *residual, int mode, int B, int cin, int cout,
-                      int Di, int Hi, int Wi, void *stream);
-
+/* az_conv3d_fwd / az_conv3d_fwd_stats / az_conv3d_stats_tiles on the f16x3 arithmetic (src = 0 only).  in_amax /
+ * w_amax: device scalars holding max |in| and max |w| (of the UNPACKED weights).  The input gradient of a layer is
+ * this call on the gradient of its raw output with the flipped / swapped packing, no affine map.  Supported: mode 0
+ * with cout = 32 (the V0 layers); everything else returns AZ_EUNSUPPORTED. */
+int az_conv3d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
+                      const float *w_amax, const float *scale, const float *shift, const float *residual,
+                      int relu, int mode, int B, int cin, int cout, int Di, int Hi, int Wi, void *stream);
+long long az_conv3d_stats_tiles_f16(int mode, int B, int cin, int cout, int Di, int Hi, int Wi);
+int az_conv3d_fwd_stats_f16(float *out, float *partials, float *counts, const float *in, const float *packed_w,
+                            const float *in_amax, const float *w_amax, int mode, int B, int cin, int cout,
+                            int Di, int Hi, int Wi, void *stream);
 /* as az_conv3d_wgrad on the f16x3 arithmetic; coarse_amax / fine_amax: device scalars max |coarse|, max |fine|.
  * Supported: stride 1 with 32 or 64 channels on either side; everything else returns AZ_EUNSUPPORTED. */
 int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *coarse,
@@ -251,9 +254,10 @@ int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *wo
 int az_bn3d_eval_affine(float *scale, float *shift, const float *gamma, const float *beta,
                         const float *running_mean, const float *running_var, float eps, int C,
                         void *stream);
-/* y = relu?( x*scale[c] + shift[c] + residual ) over nvox voxels of C channels */
+/* y = relu?( x*scale[c] + shift[c] + residual ) over nvox voxels of C channels; y_amax (may be NULL): device
+ * scalar that receives max |y| (the f16x3 operand scale of the layers that read y) */
 int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shift,
-                  const float *residual, int relu, long long nvox, int C, void *stream);
+                  const float *residual, int relu, long long nvox, int C, float *y_amax, void *stream);
 /* backward of y = relu?(bn(x) + residual): dz = dy*[y>0] (or dy), dgamma, dbeta,
  * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dz_out (may be NULL) = dz =
  * gradient of the residual branch.  coef: [C][3] scratch.  scale/shift (both or neither): the
@@ -267,8 +271,8 @@ int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *co
                 const float *x, const float *mean, const float *invstd, const float *gamma,
                 const float *scale, const float *shift, int relu, long long nvox, int C,
                 float *dx_amax, void *stream);
-/* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175 */
-int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, void *stream);
+/* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175; y_amax as above */
+int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, float *y_amax, void *stream);
 /* y = a + b (+ c) (+ d), n floats (n % 4 == 0; c, d may be NULL): the gradient of a tensor with up to
  * four consumers (cost0 of psmnet_3.py:165-175 feeds the first hourglass and three residual sums)
  * in one pass instead of autograd's chain of pairwise adds */

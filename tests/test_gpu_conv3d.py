@@ -24,7 +24,7 @@ def ncdhw(x):  # channels-last (gpu) -> NCDHW cpu
     return x.detach().permute(0, 4, 1, 2, 3).contiguous().cpu()
 
 
-@pytest.fixture(params=["bf16x6", "fp32"])
+@pytest.fixture(params=["bf16x6", "fp32", "f16x3"])
 def arith(request):
     """every MFMA test of this file runs in both arithmetic modes (passed per call: no global switch)"""
     return conv3d.Arith.of(request.param)

@@ -29,7 +29,7 @@ def close(a, b, rtol, atol):
     np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("arith", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("arith", ["bf16x6", "fp32", "f16x3"])
 @pytest.mark.parametrize("variant,mod,nin", [("psmnet3", psm3, 3), ("psmnet6", psm6, 6)])
 def test_full_model_matches_reference_goldens(golden, variant, mod, nin, arith):
     g = golden("g4_" + variant)
@@ -197,7 +197,7 @@ def _err(a, b):
     return np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
 
 
-@pytest.mark.parametrize("arith", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("arith", ["bf16x6", "fp32", "f16x3"])
 def test_full_model_d192_error_split(golden, arith, capsys):
     """nets/psmnet/psmnet_3.py:144-220 at maxdisp = 192 on one 256x512 pair (eval + the three train-mode
     heads) and one 540->544x960 eval forward.  Three numbers per output and arithmetic mode:
@@ -243,7 +243,8 @@ def test_full_model_d192_error_split(golden, arith, capsys):
         #     25 % on the 99.9 % quantile; the max over ~15 000 sampled pixels is ONE pixel next to a soft-argmin
         #     ridge and moves by +-60 % with any change of summation order upstream (the round-3 2-D kernel moved
         #     it from 0.76x to 1.6x of the reference's own max on one head and down on two others, with means and
-        #     quantiles unchanged): bounded by 2x
+        #     quantiles unchanged; profiles/r04a_gpu_tests.log has 1.6x on pred2_ in the bit-exact fp32-MFMA mode:
+        #     4.09e-4 against 2.56e-4): bounded by 2x
         assert e_hr64.mean() <= 1.1 * e_rr.mean(), line
         assert np.quantile(e_hr64, 0.999) <= 1.25 * np.quantile(e_rr, 0.999), line
         assert e_hr64.max() <= 2.0 * e_rr.max(), line

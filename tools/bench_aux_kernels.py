@@ -80,7 +80,7 @@ row("K9 `az_lcn` (k=11)", timeit(lambda: ops.local_contrast_norm(im, 11)), 4.0 *
 xv = torch.randn(B, d, h, w, C, device=dev)
 yv = torch.empty_like(xv)
 sc, sh = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-row("`az_bn3d_apply` (V0, 32 ch)", timeit(lambda: ops._call("az_bn3d_apply", yv.data_ptr(), xv.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, 1, xv.numel() // C, C, ops._stream())), 8.0 * xv.numel())
+row("`az_bn3d_apply` (V0, 32 ch)", timeit(lambda: ops._call("az_bn3d_apply", yv.data_ptr(), xv.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, 1, xv.numel() // C, C, None, ops._stream())), 8.0 * xv.numel())
 # K10/K11 RAFT
 f1, f2 = torch.randn(B, 256, h, w, device=dev), torch.randn(B, 256, h, w, device=dev)
 ms = timeit(lambda: CorrBlock1D(f1, f2), reps=5)

@@ -16,7 +16,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
-ms = timeit(lambda: ops._call("az_bn3d_apply", yv.data_ptr(), xv.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, 1, xv.numel() // C, C, ops._stream()))
+ms = timeit(lambda: ops._call("az_bn3d_apply", yv.data_ptr(), xv.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, 1, xv.numel() // C, C, None, ops._stream()))
 print(f"bn_apply V0: {ms:.3f} ms  {8.0 * xv.numel() / ms / 1e9:.2f} TB/s")
 ms = timeit(lambda: yv.copy_(xv))
 print(f"torch copy : {ms:.3f} ms  {8.0 * xv.numel() / ms / 1e9:.2f} TB/s")

@@ -35,7 +35,7 @@ def main():
     torch.cuda.synchronize()
     for _ in range(REPS):
         # calibration: y = x*scale + shift  (reads x once, writes y once)
-        _call("az_bn3d_apply", _p(y), _p(x), _p(scale), _p(shift), None, 0, x.numel() // C, C, _stream())
+        _call("az_bn3d_apply", _p(y), _p(x), _p(scale), _p(shift), None, 0, x.numel() // C, C, None, _stream())
         pk, cin, cout = conv3d._pack_forward(w, conv3d.CONV_S1, conv3d.DEFAULT_ARITH.conv)
         conv3d._run_gather(x, pk, conv3d.CONV_S1, cin, cout, conv3d.DEFAULT_ARITH.conv, stats=True)        # forward + BN partials
         conv3d._input_grad(g, w, conv3d.CONV_S1, C, C, conv3d.DEFAULT_ARITH.conv)
