@@ -40,7 +40,7 @@ _SIGS = {
     "az_bn3d_stats_tiles": [_LL, _INT],
     "az_bn3d_stats": [_PTR] * 3 + [_LL, _INT, _PTR],
     "az_bn2d_workspace": [_INT, _LL, _INT],
-    "az_bn2d_fwd": [_PTR] * 12 + [_LL, _INT, _INT, _LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR, _PTR, _LL, _PTR],
+    "az_bn2d_fwd": [_PTR] * 12 + [_LL, _INT, _INT, _LL, _INT, _C.c_float, _C.c_float, _PTR, _PTR, _PTR, _LL, _PTR, _PTR],
     "az_conv2d_stats_tiles": [_INT] * 4,
     "az_conv2d_fwd_stats": [_PTR] * 5 + [_INT] * 11 + [_PTR],
     "az_conv2d_roll_packed_floats": [_INT] * 2,
@@ -48,7 +48,10 @@ _SIGS = {
     "az_conv2d_roll_fwd": [_PTR] * 6 + [_INT] * 6 + [_PTR],
     "az_conv2d_roll_stats_rows": [_INT] * 6,
     "az_conv2d_roll_fwd_stats": [_PTR] * 5 + [_INT] * 6 + [_PTR],
-    "az_bn2d_bwd": [_PTR] * 5 + [_LL] + [_PTR] * 8 + [_INT, _INT, _LL, _INT, _PTR],
+    "az_bn2d_bwd": [_PTR] * 5 + [_LL] + [_PTR] * 8 + [_INT, _INT, _LL, _INT, _PTR, _PTR],
+    "az_conv2d_pack_weights_f16": [_PTR, _PTR, _PTR] + [_INT] * 4 + [_LL, _LL] + [_INT] * 3 + [_PTR],
+    "az_conv2d_fwd_f16": [_PTR] * 8 + [_INT] * 12 + [_PTR],
+    "az_conv2d_fwd_stats_f16": [_PTR] * 7 + [_INT] * 11 + [_PTR],
     "az_disp_loss_fwd": [_PTR] * 6 + [_C.c_float, _C.c_float, _C.c_longlong, _PTR],
     "az_disp_loss_bwd": [_PTR] * 8 + [_C.c_float, _C.c_float, _PTR, _PTR] + [_C.c_float] * 3 + [_C.c_longlong, _PTR],
     "az_disp_metrics": [_PTR] * 7 + [_INT, _C.c_longlong, _PTR],
@@ -62,7 +65,7 @@ _SIGS = {
     "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 11 + [_PTR],
     "az_absmax": [_PTR, _PTR, _LL, _PTR],
     "az_conv3d_packed_floats_f16": [_INT, _INT],
-    "az_conv3d_pack_weights_f16": [_PTR, _PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _PTR],
+    "az_conv3d_pack_weights_f16": [_PTR, _PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
     "az_conv3d_fwd_f16": [_PTR] * 8 + [_INT] * 8 + [_PTR],
     "az_conv3d_stats_tiles_f16": [_INT] * 7,
     "az_conv3d_fwd_stats_f16": [_PTR] * 7 + [_INT] * 7 + [_PTR],

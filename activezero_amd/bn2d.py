@@ -69,19 +69,23 @@ class _BNAct(torch.autograd.Function):
             track = bn.track_running_stats and bn.running_mean is not None
             nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
             pre = partials is not None and partials.ready and partials.groups == groups
+            from . import conv3d as _c3
+            y_amax = _c3._ZEROS.take(xr)  # max |y|, taken by the apply kernel: the f16x3 scale of the layers that read y
             _call("az_bn2d_fwd", _p(yr), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
                   _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None, _p(xr), _p(rr),
                   _p(g_), _p(b_), _p(ws), ws_bytes, int(relu), groups, nvox, c, eps,
                   float(bn.momentum) if bn.momentum is not None else 0.1, _p(nbt),
                   _p(partials.part) if pre else None, _p(partials.cnt) if pre else None, partials.tiles if pre else 0,
-                  _stream())
+                  _p(y_amax), _stream())
             if nbt is not None:
                 from .conv3d import _touched
                 _touched(nbt, bn.running_mean, bn.running_var)
         # a ReLU layer without residual recomputes its mask from x in backward: y need not be kept
         ctx.save_for_backward(xr, yr if (relu and residual is not None) else None, gamma, stats)
         ctx.cfg = (True, relu, residual is not None, groups, (n, c, h, w))
-        return yr.permute(0, 3, 1, 2)  # [N,C,H,W] view in channels_last memory
+        y = yr.permute(0, 3, 1, 2)  # [N,C,H,W] view in channels_last memory
+        _c3._set_amax(y, y_amax)
+        return y
 
     @staticmethod
     def backward(ctx, gy):
@@ -108,14 +112,18 @@ class _BNAct(torch.autograd.Function):
             ws_bytes = lib.az_bn2d_workspace(groups, nvox, c)
             ws = gr.new_empty(ws_bytes // 4)
             remask = relu and not has_res
+            from . import conv3d as _c3
+            dx_amax = _c3._ZEROS.take(gr)
             _call("az_bn2d_bwd", _p(dxr), _p(dzr), _p(dgb[0]), _p(dgb[1]), _p(ws), ws_bytes, _p(gr),
                   _p(yr) if (relu and has_res) else None, _p(xr), _p(stats[0]), _p(stats[1]), _p(gamma.detach()),
                   _p(stats[2]) if remask else None, _p(stats[3]) if remask else None, int(relu), groups, nvox, c,
-                  _stream())
+                  _p(dx_amax), _stream())
         g_res = None
         if has_res:
             g_res = (dzr if relu else gr).permute(0, 3, 1, 2)
-        return dxr.permute(0, 3, 1, 2), dgb[0], dgb[1], g_res, None, None, None, None, None
+        dx = dxr.permute(0, 3, 1, 2)
+        _c3._set_amax(dx, dx_amax)
+        return dx, dgb[0], dgb[1], g_res, None, None, None, None, None
 
 
 def bn_act(x, bn, relu=False, residual=None, groups=1, partials=None):

@@ -59,6 +59,59 @@ def _pack(weight, cin, cout, ci_real, co_real, s_out, s_in, kh, kw, flip, cache=
     return packed
 
 
+PEAK_F16 = conv3d._PEAK_F16
+
+
+def _amax_of(t, r):
+    """device scalar max |t| for the f16x3 kernels: what t's producer attached (BatchNorm apply / backward), else a pass
+    over its rows r"""
+    am = conv3d._get_amax(t)
+    return am if am is not None else conv3d.absmax(r)
+
+
+def _pack_f16(weight, cin, cout, ci_real, co_real, s_out, s_in, kh, kw, flip, cache=False):
+    """(packed f16x3 image, device scalar max |w|) -- az_conv2d_pack_weights_f16"""
+    w = _chk(weight.detach().contiguous(), "weight")
+    key = None
+    if cache:
+        key = (_cache_key(weight), "f16", cin, cout, ci_real, co_real, s_out, s_in, kh, kw, bool(flip))
+        hit = _cache_get(_PACK2D_CACHE, key)
+        if hit is not None:
+            return hit[0]
+    wkey = (weight.data_ptr(), weight._version, weight.device.index, weight.numel())
+    hit = _cache_get(conv3d._W_AMAX, wkey)
+    if hit is not None:
+        w_amax = hit[0]
+    else:
+        w_amax = conv3d.absmax(w)
+        _cache_put(conv3d._W_AMAX, wkey, (w_amax, weight), 512)
+    packed = torch.empty(kh * kw * cin * cout, dtype=torch.float32, device=w.device)
+    _call("az_conv2d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), cin, cout, ci_real, co_real, s_out, s_in, kh, kw,
+          int(flip), _stream())
+    if key is not None:
+        _cache_put(_PACK2D_CACHE, key, ((packed, w_amax), weight), 256)
+    return packed, w_amax
+
+
+def _run_f16(xr, x_amax, packed, w_amax, cin, cout, kh, kw, dil, scale=None, shift=None, res=None, relu=False,
+             tag="conv2d", stats=None):
+    """_run / _run_stats on the f16x3 kernels"""
+    b, h, w, cx = xr.shape
+    out = xr.new_empty(b, h, w, cout)
+    with profiler.scope(f"{tag}_{kh}x{kw}d{dil}_{cin}_{cout}", flops=2.0 * kh * kw * cin * cout * b * h * w,
+                        peak=PEAK_F16):
+        if stats is not None:
+            tiles = int(_lib.lib().az_conv2d_stats_tiles(b, h, w, stats.groups))
+            part, cnt = xr.new_empty(stats.groups, cout, tiles, 2), xr.new_empty(stats.groups, tiles)
+            _call("az_conv2d_fwd_stats_f16", _p(out), _p(part), _p(cnt), _p(xr), _p(packed), _p(x_amax), _p(w_amax),
+                  stats.groups, b, h, w, cin, cout, cx, cout, kh, kw, dil, _stream())
+            stats.part, stats.cnt, stats.tiles = part, cnt, tiles
+        else:
+            _call("az_conv2d_fwd_f16", _p(out), _p(xr), _p(packed), _p(x_amax), _p(w_amax), _p(scale), _p(shift), _p(res),
+                  int(relu), b, h, w, cin, cout, cx, cout, res.shape[-1] if res is not None else 0, kh, kw, dil, _stream())
+    return out
+
+
 def _up(n, m):
     return (n + m - 1) // m * m
 
@@ -173,13 +226,17 @@ class _ConvSame(torch.autograd.Function):
     kernel of the autograd engine (one read + one write of the activation per block saved)."""
 
     @staticmethod
-    def forward(ctx, x, weight, dil, with_skip, sink=None, stats=None):
+    def forward(ctx, x, weight, dil, with_skip, sink=None, stats=None, f16=False):
         ctx.sink = _leaf_sink(sink, weight)
+        ctx.f16 = f16
         cout, cin, kh, kw = weight.shape
         xr = _chk(rows(x), "x")
         with torch.cuda.device(x.device):
             want_stats = stats is not None and (kh, kw) in ((3, 3), (1, 1)) and xr.shape[0] % stats.groups == 0
-            if _roll_ok(xr, cin, cout, kh, kw, dil):
+            if f16 and not _roll_ok(xr, cin, cout, kh, kw, dil):
+                pk, w_amax = _pack_f16(weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False)
+                y = _run_f16(xr, _amax_of(x, xr), pk, w_amax, cin, cout, kh, kw, dil, stats=stats if want_stats else None)
+            elif _roll_ok(xr, cin, cout, kh, kw, dil):
                 pk = _pack_roll(weight, cin, cout, cin * 9, 9, False)
                 y = _run_roll_stats(xr, pk, cin, cout, stats) if want_stats else _run_roll(xr, pk, cin, cout)
             else:
@@ -201,13 +258,16 @@ class _ConvSame(torch.autograd.Function):
         cout, cin, kh, kw = weight.shape
         dil = ctx.dil
         if gy is None:  # only the shortcut was used downstream
-            return gskip, None, None, None, None, None
+            return gskip, None, None, None, None, None, None
         gr = _chk(rows(gy), "grad_y")
         gx = gw = None
         with torch.cuda.device(gy.device):
             if ctx.needs_input_grad[0]:  # the same convolution, taps flipped, channel roles swapped
                 sk = _chk(rows(gskip), "grad_skip") if gskip is not None else None
-                if _roll_ok(gr, cout, cin, kh, kw, dil, sk):
+                if ctx.f16 and not _roll_ok(gr, cout, cin, kh, kw, dil, sk):
+                    pk, w_amax = _pack_f16(weight, cout, cin, cout, cin, kh * kw, cin * kh * kw, kh, kw, True)
+                    gx = image(_run_f16(gr, _amax_of(gy, gr), pk, w_amax, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
+                elif _roll_ok(gr, cout, cin, kh, kw, dil, sk):
                     pk = _pack_roll(weight, cout, cin, 9, cin * 9, True)
                     gx = image(_run_roll(gr, pk, cout, cin, res=sk, tag="dgrad2d"))
                 else:
@@ -215,7 +275,7 @@ class _ConvSame(torch.autograd.Function):
                     gx = image(_run(gr, pk, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
             if ctx.needs_input_grad[1]:
                 gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil, sink=ctx.sink)
-        return gx, gw, None, None, None, None
+        return gx, gw, None, None, None, None, None
 
 
 def _check_same(weight, dilation):
@@ -225,15 +285,16 @@ def _check_same(weight, dilation):
     return 1 if kh == 1 else dilation
 
 
-def conv_same(x, weight, dilation=1, sink=None, stats=None):
+def conv_same(x, weight, dilation=1, sink=None, stats=None, f16=False):
     """F.conv2d(x, weight, padding="same", dilation=dilation) for [B,C,H,W] x (channels_last preferred).
-    stats: a bn2d.Partials to fill with the BatchNorm partials of the output (3x3 and 1x1 layers)."""
-    return _ConvSame.apply(x, weight, _check_same(weight, dilation), False, sink, stats)
+    stats: a bn2d.Partials to fill with the BatchNorm partials of the output (3x3 and 1x1 layers).
+    f16: forward and input gradient on the f16x3 arithmetic (conv3d.F16X3) where a kernel for the shape exists."""
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), False, sink, stats, f16)
 
 
-def conv_same_skip(x, weight, dilation=1, sink=None, stats=None):
+def conv_same_skip(x, weight, dilation=1, sink=None, stats=None, f16=False):
     """(conv_same(x, weight, dilation), x): the second output is x for the block's shortcut (see _ConvSame)."""
-    return _ConvSame.apply(x, weight, _check_same(weight, dilation), True, sink, stats)
+    return _ConvSame.apply(x, weight, _check_same(weight, dilation), True, sink, stats, f16)
 
 
 class _ConvS2Vol(torch.autograd.Function):
@@ -343,7 +404,8 @@ def conv(x, m, arith=None, skip=False, stats=None):
     k, s, d, p = m.kernel_size, m.stride, m.dilation, m.padding
     cin, cout = m.in_channels, m.out_channels
     if is_same(m):
-        return (conv_same_skip if skip else conv_same)(x, _w(m, arith), d[0], arith.sink, stats)
+        return (conv_same_skip if skip else conv_same)(x, _w(m, arith), d[0], arith.sink, stats,
+                                                       arith.conv == conv3d.F16X3)
     if skip:
         raise RuntimeError(f"conv2d.conv: skip output needs a stride-1 layer, got {m}")
     if s == (2, 2) and k == (3, 3) and p == (1, 1) and d == (1, 1):
@@ -353,7 +415,8 @@ def conv(x, m, arith=None, skip=False, stats=None):
             sink = arith.sink
             return _ConvS2Patches.apply(x, _w(m, arith), sink, sink.token if sink is not None else None, stats)
     if s == (2, 2) and k == (1, 1) and p == (0, 0):
-        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), _w(m, arith), 1, arith.sink, stats)
+        return conv_same(x[:, :, ::2, ::2].contiguous(memory_format=torch.channels_last), _w(m, arith), 1, arith.sink, stats,
+                         arith.conv == conv3d.F16X3)
     raise RuntimeError(f"conv2d.conv: unsupported layer {m}")
 
 

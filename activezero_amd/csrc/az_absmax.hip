@@ -1,4 +1,4 @@
-// max |x| of a tensor into one device float -- the operand scale of the f16x3 arithmetic of the backward kernels
+// max |x| of a tensor into an amax array (az_common.h, include/azhip.h) -- the operand scale of the f16x3 arithmetic of the backward kernels
 // (az_roll_common.h): a pure stream, one atomic per workgroup.  |x| is compared as its bit pattern (non-negative floats
 // order like unsigned integers; a NaN compares above everything and so reaches the result).
 #include "az_common.h"
@@ -20,7 +20,11 @@ absmax_kernel(unsigned *__restrict__ out, const float *__restrict__ x, long long
     __shared__ unsigned wmax[4];
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+    if (threadIdx.x == 0) {  // (slots and the conditional atomic: az_common.h, az_amax_flush)
+        const unsigned bm = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+        unsigned *slot = out + (blockIdx.x & (AZ_AMAX_SLOTS - 1)) * AZ_AMAX_STRIDE;
+        if (bm > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bm);
+    }
 }
 
 extern "C" int az_absmax(float *amax, const float *x, long long n, void *stream) {
@@ -28,7 +32,7 @@ extern "C" int az_absmax(float *amax, const float *x, long long n, void *stream)
     AZ_REQUIRE(n > 0);
     if (reinterpret_cast<uintptr_t>(x) & 15) return AZ_EINVAL;
     hipStream_t s = az_stream(stream);
-    if (hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return AZ_ELAUNCH;
+    if (hipMemsetAsync(amax, 0, AZ_AMAX_FLOATS * sizeof(float), s) != hipSuccess) return AZ_ELAUNCH;
     hipLaunchKernelGGL(absmax_kernel, dim3(az_grid_for((n + 3) / 4, 256)), dim3(256), 0, s,
                        reinterpret_cast<unsigned *>(amax), x, n);
     return az_launch_status();

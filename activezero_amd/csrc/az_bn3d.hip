@@ -215,7 +215,7 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
                      const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                      long long nvox, unsigned *__restrict__ amax_zero = nullptr) {
     // (the apply kernel that follows in the stream takes max |dx| into this word with atomicMax: start it at zero)
-    if (amax_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *amax_zero = 0u;
+    if (amax_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < AZ_AMAX_SLOTS) amax_zero[threadIdx.x * AZ_AMAX_STRIDE] = 0u;
     // thread t owns channel quad (t % C4) and voxel lane (t / C4); C4 divides 256
     constexpr int C4 = C / 4, VPB = 256 / C4;
     // ReLU mask: from the saved output y, or -- when the forward's (scale, shift) are given and the
@@ -583,7 +583,6 @@ extern "C" int az_bn3d_apply(float *y, const float *x, const float *scale, const
                              void *stream) {
     AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
     AZ_REQUIRE(nvox > 0);
-    if (y_amax && hipMemsetAsync(y_amax, 0, sizeof(float), az_stream(stream)) != hipSuccess) return AZ_ELAUNCH;
     const long long total4 = nvox * C / 4;
     const float4 *r4 = reinterpret_cast<const float4 *>(residual);
     if (C != 32 && C != 64 && C != 128) return AZ_EUNSUPPORTED;
@@ -639,7 +638,6 @@ extern "C" int az_add_relu(float *y, const float *a, const float *b, int relu, l
                            void *stream) {
     AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(a); AZ_REQUIRE_PTR(b);
     AZ_REQUIRE(n > 0 && n % 4 == 0);
-    if (y_amax && hipMemsetAsync(y_amax, 0, sizeof(float), az_stream(stream)) != hipSuccess) return AZ_ELAUNCH;
     hipLaunchKernelGGL(add_relu_kernel, dim3(BN_GRID(n / 4)), dim3(256), 0, az_stream(stream),
                        (float4 *)y, (const float4 *)a, (const float4 *)b, relu, n / 4, reinterpret_cast<unsigned *>(y_amax));
     return az_launch_status();
@@ -702,7 +700,7 @@ static void bn2d_fwd_launch(float *y, float *mean, float *invstd, float *scale, 
                             float *rv, const float *x, const float *res, const float *gamma,
                             const float *beta, float *ws, int relu, int groups, long long nvox, float eps,
                             float momentum, long long *nbt, const float *pre_part, const float *pre_cnt,
-                            long long pre_tiles, hipStream_t s) {
+                            long long pre_tiles, hipStream_t s, unsigned *amax) {
     long long tiles = az_bn3d_stats_tiles(nvox, C);
     const float *part = ws, *cnt = ws + (size_t)groups * C * tiles * 2;
     if (pre_part != nullptr) {  // the producing convolution already reduced its patches (az_conv2d_fwd_stats)
@@ -715,7 +713,7 @@ static void bn2d_fwd_launch(float *y, float *mean, float *invstd, float *scale, 
                        part, cnt, gamma, beta, tiles, C, eps, momentum, groups, nbt);
     const long long total4 = nvox * C / 4;
     hipLaunchKernelGGL((bn_apply_kernel<C, false>), dim3(BN_GRID(total4), groups), dim3(256), 0, s, (float4 *)y,
-                       (const float4 *)x, scale, shift, (const float4 *)res, relu, total4);
+                       (const float4 *)x, scale, shift, (const float4 *)res, relu, total4, amax);
 }
 
 /* y = relu?(bn(x) + residual) with batch statistics per group; mean/invstd/scale/shift: [groups][C] outputs */
@@ -724,7 +722,8 @@ extern "C" int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, f
                            const float *gamma, const float *beta, float *workspace, long long workspace_bytes,
                            int relu, int groups, long long nvox, int C, float eps, float momentum,
                            long long *num_batches_tracked, const float *partials,
-                           const float *counts, long long partial_tiles, void *stream) {
+                           const float *counts, long long partial_tiles, float *y_amax, void *stream) {
+    unsigned *const am = reinterpret_cast<unsigned *>(y_amax);
     AZ_REQUIRE_PTR(y); AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(scale); AZ_REQUIRE_PTR(shift);
     AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(gamma); AZ_REQUIRE_PTR(beta); AZ_REQUIRE_PTR(workspace);
     if ((running_mean == nullptr) != (running_var == nullptr)) return AZ_EINVAL;
@@ -734,9 +733,9 @@ extern "C" int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, f
     if (workspace_bytes < need) return AZ_EWORKSPACE;
     if (groups > 65535) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
-    if (C == 32) bn2d_fwd_launch<32>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s);
-    else if (C == 64) bn2d_fwd_launch<64>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s);
-    else bn2d_fwd_launch<128>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s);
+    if (C == 32) bn2d_fwd_launch<32>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s, am);
+    else if (C == 64) bn2d_fwd_launch<64>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s, am);
+    else bn2d_fwd_launch<128>(y, mean, invstd, scale, shift, running_mean, running_var, x, residual, gamma, beta, workspace, relu, groups, nvox, eps, momentum, num_batches_tracked, partials, counts, partial_tiles, s, am);
     return az_launch_status();
 }
 
@@ -744,7 +743,7 @@ template <int C>
 static void bn2d_bwd_launch(float *dx, float *dz, float *dgamma, float *dbeta, float *ws, const float *dy,
                             const float *y, const float *x, const float *mean, const float *invstd,
                             const float *gamma, const float *scale, const float *shift, int relu, int groups,
-                            long long nvox, hipStream_t s) {
+                            long long nvox, hipStream_t s, unsigned *amax) {
     int blocks = bn2d_blocks(nvox, C);
     float *partial = ws, *coef = ws + (size_t)groups * blocks * C * 2;  // (coef behind the UNCAPPED partial area)
     const long long total4 = nvox * C / 4;
@@ -754,7 +753,7 @@ static void bn2d_bwd_launch(float *dx, float *dz, float *dgamma, float *dbeta, f
                            invstd, scale, shift, relu, nvox);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<C, false>), dim3(bn_bwd_apply_grid(total4), groups), dim3(256), 0, s, (float4 *)dx,
                            (float4 *)dz, (const float4 *)dy, (const float4 *)y, (const float4 *)x, mean, invstd,
-                           coef, scale, shift, relu, total4, (const float *)partial, blocks, gamma, dgamma, dbeta, (double)nvox);
+                           coef, scale, shift, relu, total4, (const float *)partial, blocks, gamma, dgamma, dbeta, (double)nvox, amax);
         return;
     }
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<C, false>), dim3(blocks, groups), dim3(256), 0, s, partial, dy, y, x, mean,
@@ -770,18 +769,20 @@ static void bn2d_bwd_launch(float *dx, float *dz, float *dgamma, float *dbeta, f
 extern "C" int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *workspace,
                            long long workspace_bytes, const float *dy, const float *y, const float *x,
                            const float *mean, const float *invstd, const float *gamma, const float *scale,
-                           const float *shift, int relu, int groups, long long nvox, int C, void *stream) {
+                           const float *shift, int relu, int groups, long long nvox, int C, float *dx_amax,
+                           void *stream) {
     AZ_REQUIRE_PTR(dx); AZ_REQUIRE_PTR(dgamma); AZ_REQUIRE_PTR(dbeta); AZ_REQUIRE_PTR(workspace);
     AZ_REQUIRE_PTR(dy); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(mean); AZ_REQUIRE_PTR(invstd); AZ_REQUIRE_PTR(gamma);
     if ((scale == nullptr) != (shift == nullptr)) return AZ_EINVAL;
     if (relu && !scale) AZ_REQUIRE_PTR(y);
+    unsigned *const am = reinterpret_cast<unsigned *>(dx_amax);
     const long long need = az_bn2d_workspace(groups, nvox, C);
     if (need < 0) return (int)need;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
     if (groups > 65535) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
-    if (C == 32) bn2d_bwd_launch<32>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s);
-    else if (C == 64) bn2d_bwd_launch<64>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s);
-    else bn2d_bwd_launch<128>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s);
+    if (C == 32) bn2d_bwd_launch<32>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s, am);
+    else if (C == 64) bn2d_bwd_launch<64>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s, am);
+    else bn2d_bwd_launch<128>(dx, dz_out, dgamma, dbeta, workspace, dy, y, x, mean, invstd, gamma, scale, shift, relu, groups, nvox, s, am);
     return az_launch_status();
 }

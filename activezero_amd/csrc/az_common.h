@@ -46,15 +46,38 @@ __device__ __forceinline__ float4 az_ld16_or_zero(const float *base, size_t offs
 
 // ---- max |x| of a tensor, taken by the kernel that writes it (the operand scale of the f16x3 kernels that read it
 // next; az_absmax.hip is the stand-alone pass).  |x| is compared as a bit pattern: non-negative floats order like
-// unsigned integers and a NaN compares above everything.  The destination word must be zero before the launch.
+// unsigned integers and a NaN compares above everything.
+// The maximum lives in AZ_AMAX_SLOTS words AZ_AMAX_STRIDE floats (256 B) apart -- an "amax array" is
+// AZ_AMAX_FLOATS = 1024 floats, all ZERO before the producing launch; a workgroup adds its maximum to the slot of its
+// block index with ONE atomic, readers take the largest slot.  Measured on a BatchNorm apply of a 67 MB tensor (20 us
+// alone; tools/amax_cost_probe.py): one atomic per WAVE into one word or into 64 adjacent words +73 us (16 384 atomics
+// drain through one memory channel at ~4 ns each, whatever the word), with every slot already at the maximum -- no atomic
+// issued, see below -- +0.1 us.  An atomic is issued only when the block's maximum beats what its slot holds; that read
+// bypasses L1 and may be stale (another XCD's L2), which only costs an atomic that changes nothing.
 __device__ __forceinline__ void az_amax_acc(unsigned &am, const float4 &o) {
     am = max(max(am, __float_as_uint(o.x) & 0x7fffffffu), max(__float_as_uint(o.y) & 0x7fffffffu,
              max(__float_as_uint(o.z) & 0x7fffffffu, __float_as_uint(o.w) & 0x7fffffffu)));
 }
-__device__ __forceinline__ void az_amax_flush(unsigned *dst, unsigned am) {  // one atomic per wave
+// called by EVERY thread of the workgroup (a barrier inside); blockDim.x <= 1024
+__device__ __forceinline__ void az_amax_flush(unsigned *dst, unsigned am) {
+    __shared__ unsigned az_amax_wave[16];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) am = max(am, (unsigned)__shfl_xor((int)am, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(dst, am);
+    if ((threadIdx.x & 63) == 0) az_amax_wave[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w) am = max(am, az_amax_wave[w]);
+        unsigned *slot = dst + ((blockIdx.x + blockIdx.y * 5u) & (AZ_AMAX_SLOTS - 1)) * AZ_AMAX_STRIDE;
+        if (am > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, am);
+    }
+}
+// the tensor's max |x| from its amax array; wave-uniform (call with all 64 lanes active)
+__device__ __forceinline__ float az_amax_read(const float *p) {
+    unsigned v = reinterpret_cast<const unsigned *>(p)[(threadIdx.x & (AZ_AMAX_SLOTS - 1)) * AZ_AMAX_STRIDE];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)v));
 }
 
 // Exact 3-way split of fp32 values into bf16 parts, ROUND-TO-NEAREST-EVEN at every level:

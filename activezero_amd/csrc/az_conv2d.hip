@@ -25,7 +25,7 @@
 // Epilogue: y = acc (* scale[c] + shift[c]) (+ residual) (ReLU) -- training stores the raw sums; an
 // eval-mode caller folds BatchNorm here.  Output pixel stride is a parameter, so a producer can write
 // straight into a channel slice of a wider tensor.
-#include "az_common.h"
+#include "az_roll_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -52,12 +52,14 @@ struct C2Args {
     float *spart, *scnt;
     int sgroups;       // statistic groups: consecutive B / sgroups images each
     long long stiles;  // patches per group
+    const float *in_amax, *w_amax;  // PARTS 2 (f16x3): device scalars max |in|, max |w| (az_roll_common.h)
 };
 
 // PARTS = 3: the bf16x6 arithmetic above (fp32-class).  PARTS = 1: plain bf16 operands (round-to-nearest), one
 // MFMA per 16-deep block, fp32 accumulation -- the arithmetic of the reference's autocast region around the
 // RAFT-Stereo GRU update (nets/raft/raft_stereo.py:98,142-172; nets/raft/update.py:19-41), same slab / weight
-// pipeline with the mid / lo parts left out.
+// pipeline with the mid / lo parts left out.  PARTS = 2: f16x3 (az_roll_common.h) -- two scaled fp16 parts in the
+// first two parts of the same slab image, three MFMAs per block.
 template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv2d_same_kernel(const C2Args a) {
@@ -97,6 +99,13 @@ conv2d_same_kernel(const C2Args a) {
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    float in_scale = 1.f, osc = 1.f;
+    if (PARTS == 2) {  // wave-uniform power-of-two operand scales
+        const int ki = az_f16_scale_exp(az_amax_read(a.in_amax));
+        const int kw_ = az_f16_scale_exp(az_amax_read(a.w_amax));
+        in_scale = az_pow2(ki);
+        osc = ldexpf(1.f, -(ki + kw_));
+    }
 
     const int row = lane & 31, half = lane >> 5;
     const int rty = row >> 3, rtx = row & 7;
@@ -135,6 +144,11 @@ conv2d_same_kernel(const C2Args a) {
                     *reinterpret_cast<uint2 *>(dst) = hi;
                     *reinterpret_cast<uint2 *>(dst + 8) = mid;
                     *reinterpret_cast<uint2 *>(dst + 16) = lo;
+                } else if (PARTS == 2) {
+                    uint2 hi, lo;
+                    az_split2_f16x4(make_float4(pre[it].x * in_scale, pre[it].y * in_scale, pre[it].z * in_scale, pre[it].w * in_scale), hi, lo);
+                    *reinterpret_cast<uint2 *>(dst) = hi;
+                    *reinterpret_cast<uint2 *>(dst + 8) = lo;
                 } else {
                     *reinterpret_cast<uint2 *>(dst) = make_uint2(az_pk_bf16(pre[it].x, pre[it].y), az_pk_bf16(pre[it].z, pre[it].w));
                 }
@@ -171,6 +185,8 @@ conv2d_same_kernel(const C2Args a) {
         if (PARTS == 1)
             acc[cur] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(az_bf16x8, aq[0]),
                                                                __builtin_bit_cast(az_bf16x8, bq[0]), acc[cur], 0, 0, 0);
+        else if (PARTS == 2 && PIPE) az_mfma3_step(tn, aq, bq, acc[(cur + 3) & 3], tp);
+        else if (PARTS == 2) az_mfma3_now(acc[cur], aq, bq);
         else if (PIPE) az_mfma6_step(tn, aq, bq, acc[(cur + 3) & 3], tp);
         else az_mfma6_now(acc[cur], aq, bq);
     };
@@ -259,7 +275,11 @@ conv2d_same_kernel(const C2Args a) {
         }
     }
 
-    if (PIPE && PARTS == 3) acc[3] += t1;  // the last block's temporary
+    if (PIPE && PARTS != 1) acc[3] += t1;  // the last block's temporary
+    if (PARTS == 2) {  // undo the operand scales once, on the finished sums
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] *= osc;
+    }
     // ---- epilogue: C/D map of the 32x32 MFMA -- column (out channel) = lane & 31, row (pixel of the 4x8
     // tile) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); M-tile m covers rows 4(m>>1).., cols 8(m&1)..
     const int co = ntile * 32 + row;
@@ -355,6 +375,40 @@ conv2d_pack_kernel(unsigned short *__restrict__ dst, const float *__restrict__ s
     float x = 0.f;
     if (co < co_real && ci < ci_real) x = src[co * s_co + ci * s_ci + (flip ? taps - 1 - t : t)];
     dst[idx] = az_split3_part(x, p);  // round-to-nearest split, as the activations' (az_common.h)
+}
+
+// f16x3 image: [tap][cin/16][cout/32][part 2][64 lanes][8] fp16 of w * 2^k (k from max |w|)
+__global__ void __launch_bounds__(256)
+conv2d_pack_f16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax,
+                       int cin, int cout, int ci_real, int co_real, long long s_co, long long s_ci, int taps, int flip,
+                       long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float scale = az_pow2(az_f16_scale_exp(az_amax_read(amax)));  // (before the early exit: a wave-wide read)
+    if (idx >= total) return;
+    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    long long r = idx >> 9;
+    const int p = (int)(r & 1); r >>= 1;
+    const int nt = cout / 32, nch = cin / 16;
+    const int n = (int)(r % nt); r /= nt;
+    const int cc = (int)(r % nch);
+    const int t = (int)(r / nch);
+    const int co = n * 32 + (lane & 31), ci = cc * 16 + 8 * (lane >> 5) + j;
+    float x = 0.f;
+    if (co < co_real && ci < ci_real) x = src[co * s_co + ci * s_ci + (flip ? taps - 1 - t : t)];
+    dst[idx] = az_split2_f16_part(x * scale, p);
+}
+
+extern "C" int az_conv2d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
+                                          int ci_real, int co_real, long long stride_out, long long stride_in, int kh,
+                                          int kw, int flip, void *stream) {
+    AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
+    if (cin <= 0 || cout <= 0 || cin % 16 || cout % 32 || kh <= 0 || kw <= 0) return AZ_EUNSUPPORTED;
+    AZ_REQUIRE(ci_real > 0 && ci_real <= cin && co_real > 0 && co_real <= cout);
+    const long long total = (long long)kh * kw * cin * cout * 2;
+    hipLaunchKernelGGL(conv2d_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, az_stream(stream),
+                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, ci_real, co_real, stride_out,
+                       stride_in, kh * kw, flip, total);
+    return az_launch_status();
 }
 
 extern "C" long long az_conv2d_packed_floats(int cin, int cout, int kh, int kw) {
@@ -486,4 +540,56 @@ extern "C" int az_conv2d_bf16_fwd(float *out, const float *in, const float *pack
     a.in_cs = in_cstride; a.out_cs = out_cstride; a.res_cs = res_cstride;
     a.tiles_y = (H + C2_TY - 1) / C2_TY; a.tiles_x = (W + C2_TX - 1) / C2_TX;
     return dispatch_nw<3, 3, 1, 1>(a, az_stream(stream));
+}
+
+/* az_conv2d_fwd / az_conv2d_fwd_stats on the f16x3 arithmetic (include/azhip.h): in_amax / w_amax = device scalars
+ * max |in|, max |w|; weights packed by az_conv2d_pack_weights_f16. */
+static int c2_f16_args(C2Args &a, float *out, const float *in, const float *packed_w, const float *in_amax,
+                       const float *w_amax, int B, int H, int W, int cin, int cout, int in_cstride, int out_cstride,
+                       int res_cstride) {
+    if (!out || !in || !packed_w || !in_amax || !w_amax) return AZ_ENULL;
+    if (!(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0)) return AZ_EINVAL;
+    if (cin % 16 || cout % 32) return AZ_EUNSUPPORTED;
+    if (!(in_cstride >= cin && out_cstride >= cout && in_cstride % 4 == 0)) return AZ_EINVAL;
+    long long cs = in_cstride > out_cstride ? in_cstride : out_cstride;
+    if (res_cstride > cs) cs = res_cstride;
+    if ((long long)H * W * cs > 0x7fffffffLL) return AZ_EUNSUPPORTED;
+    a.in = in; a.wp = packed_w; a.out = out; a.in_amax = in_amax; a.w_amax = w_amax;
+    a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
+    a.in_cs = in_cstride; a.out_cs = out_cstride; a.res_cs = res_cstride;
+    a.tiles_y = (H + C2_TY - 1) / C2_TY; a.tiles_x = (W + C2_TX - 1) / C2_TX;
+    return AZ_OK;
+}
+
+extern "C" int az_conv2d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
+                                 const float *w_amax, const float *scale, const float *shift, const float *residual,
+                                 int relu, int B, int H, int W, int cin, int cout, int in_cstride, int out_cstride,
+                                 int res_cstride, int kh, int kw, int dilation, void *stream) {
+    C2Args a{};
+    if (int e = c2_f16_args(a, out, in, packed_w, in_amax, w_amax, B, H, W, cin, cout, in_cstride, out_cstride,
+                            residual ? res_cstride : 0)) return e;
+    AZ_REQUIRE(residual == nullptr || res_cstride >= cout);
+    a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu ? 1 : 0;
+    hipStream_t s = az_stream(stream);
+    if (kh == 3 && kw == 3 && dilation == 1) return dispatch_nw<3, 3, 1, 2>(a, s);
+    if (kh == 3 && kw == 3 && dilation == 2) return dispatch_nw<3, 3, 2, 2>(a, s);
+    if (kh == 1 && kw == 1) return dispatch_nw<1, 1, 1, 2>(a, s);
+    if (kh == 3 && kw == 5 && dilation == 1) return dispatch_nw<3, 5, 1, 2>(a, s);
+    return AZ_EUNSUPPORTED;
+}
+
+extern "C" int az_conv2d_fwd_stats_f16(float *out, float *partials, float *counts, const float *in, const float *packed_w,
+                                       const float *in_amax, const float *w_amax, int groups, int B, int H, int W,
+                                       int cin, int cout, int in_cstride, int out_cstride, int kh, int kw, int dilation,
+                                       void *stream) {
+    AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts);
+    AZ_REQUIRE(groups > 0 && B > 0 && B % groups == 0);
+    C2Args a{};
+    if (int e = c2_f16_args(a, out, in, packed_w, in_amax, w_amax, B, H, W, cin, cout, in_cstride, out_cstride, 0)) return e;
+    a.spart = partials; a.scnt = counts; a.sgroups = groups; a.stiles = az_conv2d_stats_tiles(B, H, W, groups);
+    hipStream_t s = az_stream(stream);
+    if (kh == 3 && kw == 3 && dilation == 1) return dispatch_nw<3, 3, 1, 2, true>(a, s);
+    if (kh == 3 && kw == 3 && dilation == 2) return dispatch_nw<3, 3, 2, 2, true>(a, s);
+    if (kh == 1 && kw == 1) return dispatch_nw<1, 1, 1, 2, true>(a, s);
+    return AZ_EUNSUPPORTED;
 }

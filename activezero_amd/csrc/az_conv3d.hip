@@ -31,7 +31,7 @@
 // feature maps (reference psmnet_3.py:149-163) instead of reading a 64-channel tensor.
 #include <stdlib.h>
 
-#include "az_common.h"
+#include "az_roll_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -85,7 +85,9 @@ conv3d_gather_kernel(const ConvArgs a) {
     // of the 256-byte bank row once, and the row swizzle sends the four runs to different
     // 16-byte slots of each quad -> conflict-free (the padded layout was 3-way conflicted and
     // made the LDS, not the MFMA pipe, the bound of the 32-wide kernels).
-    constexpr bool SWZ = (PREC == 1) && (MODE != 1);
+    // PREC 3 = f16x3 (az_roll_common.h): two scaled fp16 parts in the first two 64-byte parts of the same voxel image
+    constexpr bool X16 = (PREC == 3);
+    constexpr bool SWZ = (PREC != 0) && (MODE != 1);
     constexpr int VS = (PREC == 0) ? CV_VS : SWZ ? 48 : X6_VS;
     constexpr int SXP = SX;  // LDS row pitch of the slab in voxels
     __shared__ __attribute__((aligned(16))) float slab[SY * SXP * VS];
@@ -147,6 +149,13 @@ conv3d_gather_kernel(const ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
+    float in_scale = 1.f, osc = 1.f;
+    if (X16) {  // wave-uniform power-of-two operand scales from the tensors' largest magnitudes
+        const int ki = az_f16_scale_exp(az_amax_read(a.in_amax));
+        const int kw = az_f16_scale_exp(az_amax_read(a.w_amax));
+        in_scale = az_pow2(ki);
+        osc = ldexpf(1.f, -(ki + kw));
+    }
     const int nd = (MODE == 2) ? 1 + pd : 3;
     const int nh = (MODE == 2) ? 1 + ph : 3;
     const int nw = (MODE == 2) ? 1 + pw : 3;
@@ -225,12 +234,19 @@ conv3d_gather_kernel(const ConvArgs a) {
                 if (q < NQ) *reinterpret_cast<float4 *>(&slab[vox * CV_VS + (q & 7) * 4]) = pre[it];
             } else if (q < NQ) {
                 uint2 hi, mid, lo;
-                az_split3_bf16x4(pre[it], hi, mid, lo);
+                if (X16) {
+                    float4 v = pre[it];
+                    v.x *= in_scale; v.y *= in_scale; v.z *= in_scale; v.w *= in_scale;
+                    az_split2_f16x4(v, hi, mid);
+                    lo = mid;
+                } else {
+                    az_split3_bf16x4(pre[it], hi, mid, lo);
+                }
                 unsigned *dst = reinterpret_cast<unsigned *>(slab) + vox * VS +
                                 (SWZ ? ((((q & 7) >> 1) ^ (sy & 3)) * 4 + (q & 1) * 2) : (q & 7) * 2);
                 *reinterpret_cast<uint2 *>(dst) = hi;
                 *reinterpret_cast<uint2 *>(dst + 16) = mid;
-                *reinterpret_cast<uint2 *>(dst + 32) = lo;
+                if (!X16) *reinterpret_cast<uint2 *>(dst + 32) = lo;
             }
             sx += 8;
             if (sx >= SX) { sx -= SX; ++sy; }
@@ -238,7 +254,7 @@ conv3d_gather_kernel(const ConvArgs a) {
     };
     // 16-byte operand pieces per (tile, tap, chunk): fp32 -> 4 (k = 16*half + 4j..4j+3);
     // bf16x6 -> 6 = 3 split parts x 2 K16 blocks (k = 16*kb + 8*half + 0..7), index p*2 + kb
-    constexpr int NF = (PREC == 0) ? 4 : 6;
+    constexpr int NF = (PREC == 0) ? 4 : X16 ? 4 : 6;
     auto load_b = [&](auto &bq, int tap, int cc) {
 #pragma unroll
         for (int n = 0; n < NR; ++n)
@@ -270,7 +286,7 @@ conv3d_gather_kernel(const ConvArgs a) {
             const float *ap0 = vp + (SWZ ? ((half ^ (sy & 3)) * 4) : 4 * half);
             const float *ap1 = vp + (SWZ ? (((2 + half) ^ (sy & 3)) * 4) : 4 * half + 8);
 #pragma unroll
-            for (int f = 0; f < 6; ++f)
+            for (int f = 0; f < NF; ++f)
                 aq[f] = *reinterpret_cast<const float4 *>(((f & 1) ? ap1 : ap0) + (f >> 1) * 16);
         }
     };
@@ -294,6 +310,18 @@ conv3d_gather_kernel(const ConvArgs a) {
                     c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].z, bw[n][j].z, c[n], 0, 0, 0);
                     c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j].w, bw[n][j].w, c[n], 0, 0, 0);
                 }
+            } else if constexpr (X16) {
+                // one tap x 32 channels = two K16 blocks: hi*hi twice, then the four cross terms, from zero; one VALU
+                // add of the block sum per element (the partner wave of the SIMD fills the gap behind the chain)
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define X16_MF(T, A, B) T = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, aq[A]), __builtin_bit_cast(h8, bw[n][B]), T, 0, 0, 0)
+                f32x16 t;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) t[e] = 0.f;
+                X16_MF(t, 0, 0); X16_MF(t, 1, 1); X16_MF(t, 0, 2); X16_MF(t, 2, 0); X16_MF(t, 1, 3); X16_MF(t, 3, 1);
+#undef X16_MF
+                c[n] += t;
+                asm volatile("" : "+v"(c[n]));
             } else {
                 const float4 a0q[3] = {aq[0], aq[2], aq[4]}, a1q[3] = {aq[1], aq[3], aq[5]};
                 const float4 b0q[3] = {bw[n][0], bw[n][2], bw[n][4]}, b1q[3] = {bw[n][1], bw[n][3], bw[n][5]};
@@ -361,6 +389,7 @@ conv3d_gather_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) ts[m][n][e] = 0.f;
         }
+        static_assert(!(X16 && WIDE), "f16x3 runs two waves per SIMD");
         if (BPIPE) {
             float4 bq2[NR][NF];
             for (int t = 0; t < ntaps; t += 2) {
@@ -380,6 +409,12 @@ conv3d_gather_kernel(const ConvArgs a) {
     }
 
     CV_T0();
+    if (X16) {  // undo the operand scales once, on the finished sums
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) acc[m][n] *= osc;
+    }
     // ---- epilogue ---------------------------------------------------------------------
     // C/D map of 32x32 MFMA: column (out channel) = lane & 31, row (voxel) =
     // (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
@@ -525,6 +560,26 @@ conv3d_pack_x6_kernel(unsigned short *__restrict__ dst, const float *__restrict_
     dst[idx] = az_split3_part(x, p);  // round-to-nearest split, as the activations' (az_common.h)
 }
 
+// f16x3 packing for this kernel: [tap][cc][n][part(2)][kb(2)][lane(64)][8] fp16 of w * 2^k (k from max |w|)
+__global__ void __launch_bounds__(256)
+conv3d_pack_f16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax,
+                       int cin, int cout, long long sn, long long sk, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const float scale = az_pow2(az_f16_scale_exp(az_amax_read(amax)));  // (before the early exit: a wave-wide read)
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    int r = idx >> 9;
+    const int kb = r & 1; r >>= 1;
+    const int p = r & 1; r >>= 1;
+    const int nr = cout / 32, nch = cin / 32;
+    const int n = r % nr; r /= nr;
+    const int cc = r % nch;
+    const int tap = r / nch;
+    const int co = n * 32 + (lane & 31);
+    const int ci = cc * 32 + 16 * kb + 8 * (lane >> 5) + j;
+    dst[idx] = az_split2_f16_part(src[co * sn + ci * sk + (flip ? 26 - tap : tap)] * scale, p);
+}
+
 template <int CIN, int COUT, int MODE, int EPI, int SRC, int PREC>
 static int launch_conv(const ConvArgs &a, hipStream_t s) {
     long long blocks = (long long)a.B * a.Dt * a.tiles_y * a.tiles_x *
@@ -575,6 +630,12 @@ static int dispatch_mode(const ConvArgs &a, int mode, int precision, int cin, in
         if (mode == 0) return dispatch_channels<0, EPI, 1>(a, cin, cout, src, s);
         if (mode == 1) return dispatch_channels<1, EPI, 1>(a, cin, cout, src, s);
         return dispatch_channels<2, EPI, 1>(a, cin, cout, src, s);
+    }
+    if (precision == 3) {  // f16x3 on this kernel (shapes the depth-rolling kernel does not take)
+        if (src != 0) return AZ_EUNSUPPORTED;
+        if (mode == 0) return dispatch_channels<0, EPI, 3>(a, cin, cout, src, s);
+        if (mode == 1) return dispatch_channels<1, EPI, 3>(a, cin, cout, src, s);
+        return dispatch_channels<2, EPI, 3>(a, cin, cout, src, s);
     }
     if (precision == 2) {  // bf16x6 arithmetic, weights packed for the depth-rolling 16x16x32 kernel
         if (mode != 0 || cout != 32 || src != 0) return AZ_EUNSUPPORTED;
@@ -707,16 +768,24 @@ extern "C" long long az_conv3d_packed_floats_f16(int cin, int cout) {
     return 27LL * cin * cout;  // two fp16 parts per weight
 }
 
+// which kernel serves (mode, cout) in f16x3 -- the two read different packed-weight layouts
+static bool f16_on_roll(int mode, int cout) { return mode == 0 && cout == 32; }
+
 extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
-                                          long long stride_out, long long stride_in, int flip, void *stream) {
+                                          long long stride_out, long long stride_in, int flip, int mode, void *stream) {
     AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
-    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0) return AZ_EUNSUPPORTED;
-    return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream));
+    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return AZ_EUNSUPPORTED;
+    if (f16_on_roll(mode, cout))
+        return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream));
+    const int total = 27 * cin * cout * 2;
+    hipLaunchKernelGGL(conv3d_pack_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, az_stream(stream),
+                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, stride_out, stride_in, flip, total);
+    return az_launch_status();
 }
 
 static int conv_f16_dispatch(ConvArgs &a, int mode, int cin, int cout, int epi, hipStream_t s) {
-    if (mode == 0 && cout == 32) return az_conv3d_roll_launch_f16(a, cin, epi, s);
-    return AZ_EUNSUPPORTED;
+    if (f16_on_roll(mode, cout)) return az_conv3d_roll_launch_f16(a, cin, epi, s);
+    return epi ? dispatch_mode<1>(a, mode, 3, cin, cout, 0, s) : dispatch_mode<0>(a, mode, 3, cin, cout, 0, s);
 }
 
 extern "C" int az_conv3d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
@@ -731,8 +800,9 @@ extern "C" int az_conv3d_fwd_f16(float *out, const float *in, const float *packe
 }
 
 extern "C" long long az_conv3d_stats_tiles_f16(int mode, int B, int cin, int cout, int Di, int Hi, int Wi) {
-    if (mode == 0 && cout == 32) return az_conv3d_stats_tiles(mode, 2, B, cin, cout, Di, Hi, Wi);
-    return AZ_EUNSUPPORTED;
+    if (mode < 0 || mode > 2) return AZ_EINVAL;
+    if (f16_on_roll(mode, cout)) return az_conv3d_stats_tiles(mode, 2, B, cin, cout, Di, Hi, Wi);
+    return az_conv3d_num_tiles(mode, B, Di, Hi, Wi);
 }
 
 extern "C" int az_conv3d_fwd_stats_f16(float *out, float *partials, float *counts, const float *in, const float *packed_w,

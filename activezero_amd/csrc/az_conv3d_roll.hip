@@ -108,8 +108,8 @@ conv3d_roll_kernel(const ConvArgs a) {
     int out_exp = 0;
     if (AR) {
         // (wave-uniform: kept in scalar registers)
-        const int ki = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.in_amax))));
-        const int kw = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.w_amax))));
+        const int ki = az_f16_scale_exp(az_amax_read(a.in_amax));
+        const int kw = az_f16_scale_exp(az_amax_read(a.w_amax));
         in_scale = az_pow2(ki);
         out_exp = -(ki + kw);
     }
@@ -603,8 +603,8 @@ __global__ void __launch_bounds__(256)
 conv3d_pack_r16_f16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax,
                            int cin, int cout, long long sn, long long sk, int flip, int total) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    const float scale = az_pow2(az_f16_scale_exp(az_amax_read(amax)));  // (before the early exit: a wave-wide read)
     if (idx >= total) return;
-    const float scale = az_pow2(az_f16_scale_exp(*amax));
     const int j = idx & 7, lane = (idx >> 3) & 63;
     int r = idx >> 9;
     const int p = r & 1; r >>= 1;

@@ -20,7 +20,7 @@
 // the flops.  az_conv3d_wgrad_unpack transposes [k][m][n] -> [m][n][k].
 #include <stdlib.h>
 
-#include "az_common.h"
+#include "az_roll_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -38,6 +38,7 @@ struct WgArgs {
     long long nitems;
     int waves_per_combo;
     int order;  // 0: (b, cd, hs, wc) linear; 1: XCD-chunked list with the depth index fastest
+    const float *coarse_amax, *fine_amax;  // f16x3 kernels: device scalars max |coarse|, max |fine|
 };
 
 // item -> (row-chunk, row segment, coarse depth, batch).  Waves w, w+8, ... run on one XCD (its
@@ -217,10 +218,20 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 #define WGX6_S2_OCC 1
 #endif
 #define WGX6_S2_WAVES(S) ((S) == 1 ? 2 : WGX6_S2_OCC)
-template <int CM, int CN, int S>
-__global__ void __launch_bounds__(64, WGX6_S2_WAVES(S))
+// AR: 0 = bf16x6, 1 = f16x3 (two scaled fp16 parts, three MFMAs per tap; az_roll_common.h) -- the LDS images keep their
+// three-part strides, the third part is then unused
+template <int CM, int CN, int S, int AR = 0>
+__global__ void __launch_bounds__(64, AR ? 2 : WGX6_S2_WAVES(S))
 conv3d_wgrad_x6_kernel(const WgArgs a) {
     constexpr int WCH = X6_WCH;
+    constexpr int NP = AR ? 2 : 3;
+    float c_scale = 1.f, f_scale = 1.f, o_scale = 1.f;
+    if (AR) {
+        const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax));
+        const int kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
+        c_scale = az_pow2(kc); f_scale = az_pow2(kf);
+        o_scale = ldexpf(1.f, -(kc + kf));
+    }
     constexpr int FW = S * (WCH - 1) + 3;  // fine positions per staged row
     constexpr int MT = CM / 32, NT = CN / 32, NCOMBO = 3 * MT * NT;
     constexpr int NEW = S;
@@ -251,13 +262,18 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
     const int tr_col = 16 * ((lane >> 4) & 1) + 4 * tp;
     const int tr_row = 8 * (lane >> 5) + tq;  // + 4 for the second read
 
-    auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v) {
-        // exact 3-way bf16 split; dst_part0 points at 4 channels of part 0
+    auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v, float scale_) {
+        // exact 3-way bf16 split (or the scaled two-part fp16 split); dst_part0 points at 4 channels of part 0
         uint2 hi, mid, lo;
-        az_split3_bf16x4(v, hi, mid, lo);
+        if (AR) {
+            az_split2_f16x4(make_float4(v.x * scale_, v.y * scale_, v.z * scale_, v.w * scale_), hi, mid);
+            lo = mid;
+        } else {
+            az_split3_bf16x4(v, hi, mid, lo);
+        }
         *reinterpret_cast<uint2 *>(dst_part0) = hi;
         *reinterpret_cast<uint2 *>(dst_part0 + part_stride) = mid;
-        *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = lo;
+        if (!AR) *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = lo;
     };
     // fragment of 8 consecutive K rows (positions) for this lane's column, rows given by rowfn(k)
     auto frag = [&](const unsigned short *img, int r0, int r1) -> bf16x8 {
@@ -284,6 +300,8 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
         // loads only: clamped (always valid) addresses, padding applied at commit time -- touching
         // the loaded registers here puts the whole memory latency in front of this row's MFMAs
         auto issue = [&](int ch) {
+            int lane = threadIdx.x;
+            if (AR) asm volatile("" : "+v"(lane));  // (recompute the piece offsets per call: at the register limit)
             okbits = 0;
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
@@ -304,11 +322,13 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
             }
         };
         auto commit = [&](int ch) {
+            int lane = threadIdx.x;
+            if (AR) asm volatile("" : "+v"(lane));
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int q = lane + 64 * it;
                 if (!((okbits >> it) & 1u)) pa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < NQA) split_store(&sa[(q >> 3) * 32 + (q & 7) * 4], WCH * 32, pa[it]);
+                if (q < NQA) split_store(&sa[(q >> 3) * 32 + (q & 7) * 4], WCH * 32, pa[it], c_scale);
             }
 #pragma unroll
             for (int it = 0; it < NLF; ++it) {
@@ -317,7 +337,7 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
                 const int fh = S * ch + 2 - NEW + rr;
                 const int slot = (fh + 3) % 3;
                 if (!((okbits >> (8 + it)) & 1u)) pf[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < NQF) split_store(&sf[(slot * 3 * FW + lw) * 32 + part * 4], FW * 32, pf[it]);
+                if (q < NQF) split_store(&sf[(slot * 3 * FW + lw) * 32 + part * 4], FW * 32, pf[it], f_scale);
             }
         };
 
@@ -330,7 +350,7 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (fh >= 0 && fh < a.Hf && fw >= 0 && fw < a.Wf)
                 v = *reinterpret_cast<const float4 *>(fbase + ((size_t)fh * a.Wf + fw) * CN + part * 4);
-            split_store(&sf[(((fh + 3) % 3) * 3 * FW + lw) * 32 + part * 4], FW * 32, v);
+            split_store(&sf[(((fh + 3) % 3) * 3 * FW + lw) * 32 + part * 4], FW * 32, v, f_scale);
         }
         issue(h_beg);
         for (int ch = h_beg; ch < h_end; ++ch) {
@@ -342,7 +362,7 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
             // A fragments (coarse): parts hi/mid/lo, K rows = positions 8*(lane>>5) + 0..7
             bf16x8 af[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = frag(sa + p * WCH * 32, tr_row, tr_row + 4);
+            for (int p = 0; p < NP; ++p) af[p] = frag(sa + p * WCH * 32, tr_row, tr_row + 4);
 #if WGX6_BPIPE
             // fine-row fragments one tap ahead of their MFMAs (ping-pong registers, order pinned)
             auto load_bf = [&](bf16x8 (&bfr)[3], int t) {
@@ -385,9 +405,17 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
                 for (int kw = 0; kw < 3; ++kw) {
                     bf16x8 bfr[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
+                    for (int p = 0; p < NP; ++p)
                         bfr[p] = frag(frow + p * FW * 32, S * tr_row + kw, S * (tr_row + 4) + kw);
                     f32x16 c = acc[kh * 3 + kw];
+                    if constexpr (AR) {
+                        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[1]), __builtin_bit_cast(h8, bfr[0]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[0]), __builtin_bit_cast(h8, bfr[1]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, af[0]), __builtin_bit_cast(h8, bfr[0]), c, 0, 0, 0);
+                        acc[kh * 3 + kw] = c;
+                        continue;
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], c, 0, 0, 0);
@@ -406,7 +434,7 @@ conv3d_wgrad_x6_kernel(const WgArgs a) {
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
             const int m = mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-            atomicAdd(&a.ws[((size_t)tap * CM + m) * CN + nt * 32 + row], acc[t][rg]);
+            atomicAdd(&a.ws[((size_t)tap * CM + m) * CN + nt * 32 + row], AR ? acc[t][rg] * o_scale : acc[t][rg]);
         }
     }
 }
@@ -573,7 +601,7 @@ wgrad_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int c
 
 template <int CM, int CN, int S, int PREC>
 static int launch_wgrad(WgArgs a, hipStream_t s) {
-    constexpr int WCH = (PREC == 1) ? X6_WCH : (S == 1) ? WG_WCH1 : WG_WCH2;
+    constexpr int WCH = (PREC == 1 || PREC == 3) ? X6_WCH : (S == 1) ? WG_WCH1 : WG_WCH2;
     constexpr int NCOMBO = 3 * (CM / 32) * (CN / 32);
     a.nwchunk = (a.Wc + WCH - 1) / WCH;
     // Static work lists: wave w of a combo takes items w, w + W, w + 2W, ...  The kernel ends
@@ -611,7 +639,9 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
     }
     static int fine_walk = -1;  // AZ_WGRAD_FW=0: the coarse-row walk for the stride-1 layers too (A/B)
     if (fine_walk < 0) { const char *e = getenv("AZ_WGRAD_FW"); fine_walk = e ? atoi(e) : 1; }
-    if (PREC == 1 && S == 1 && fine_walk)
+    if (PREC == 3)
+        hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CM, CN, S, 1>), dim3(a.waves_per_combo * NCOMBO), dim3(64), 0, s, a);
+    else if (PREC == 1 && S == 1 && fine_walk)
         hipLaunchKernelGGL((conv3d_wgrad_x6_fw_kernel<CM, CN>), dim3(a.waves_per_combo * NCOMBO), dim3(64), 0, s, a);
     else if (PREC == 1)
         hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CM, CN, S>), dim3(a.waves_per_combo * NCOMBO),
@@ -686,11 +716,20 @@ extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long wo
     const long long need = az_conv3d_wgrad_workspace(cm, cn);
     if (need < 0) return AZ_EUNSUPPORTED;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
-    if (!(stride == 1 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64) && Dc == Df && Hc == Hf && Wc == Wf))
-        return AZ_EUNSUPPORTED;
+    if (!((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
-    const int rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s, coarse_amax, fine_amax);
+    int rc = AZ_EUNSUPPORTED;
+    if (stride == 1 && Dc == Df && Hc == Hf && Wc == Wf) {  // all 27 taps per wave on 16x16x32 tiles (az_conv3d_wgrad16.hip)
+        rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s, coarse_amax, fine_amax);
+    } else {  // stride 2: one kd per wave
+        WgArgs a{};
+        a.coarse = coarse; a.fine = fine; a.ws = workspace; a.coarse_amax = coarse_amax; a.fine_amax = fine_amax;
+        a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;
+#define WG16_CASE(M, N) if (cm == M && cn == N) rc = (stride == 1) ? launch_wgrad<M, N, 1, 3>(a, s) : launch_wgrad<M, N, 2, 3>(a, s);
+        WG16_CASE(32, 32) WG16_CASE(32, 64) WG16_CASE(64, 32) WG16_CASE(64, 64)
+#undef WG16_CASE
+    }
     if (rc != AZ_OK) return rc;
     const int total = cm * cn * 27;
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm, cn);

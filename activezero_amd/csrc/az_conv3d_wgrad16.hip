@@ -83,8 +83,8 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
     for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float c_scale = 1.f, f_scale = 1.f, o_scale = 1.f;
     if (AR) {  // wave-uniform power-of-two operand scales
-        const int kc = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.coarse_amax))));
-        const int kf = az_f16_scale_exp(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, *a.fine_amax))));
+        const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax));
+        const int kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
         c_scale = az_pow2(kc); f_scale = az_pow2(kf);
         o_scale = ldexpf(1.f, -(kc + kf));
     }

@@ -92,6 +92,38 @@ __device__ __forceinline__ unsigned short az_split2_f16_part(float x, int p) {
     return __builtin_bit_cast(unsigned short, p == 0 ? h : l);
 }
 
+// f16x3 on the 32x32x16 shape (az_conv2d.hip, az_conv3d.hip): tnew = one K16 block (hi*hi, hi*lo, lo*hi from zero);
+// cprev += tprev with the sixteen adds spread behind the second and third MFMA (the temporary of the block before is
+// complete by then: no wait states)
+typedef float az_f32x16h __attribute__((ext_vector_type(16)));
+#define AZ_H3(ACC, A, B) __builtin_amdgcn_mfma_f32_32x32x16_f16( \
+        __builtin_bit_cast(az_f16x8, aq[A]), __builtin_bit_cast(az_f16x8, bq[B]), ACC, 0, 0, 0)
+__device__ __forceinline__ void az_mfma3_step(az_f32x16h &tnew, const float4 (&aq)[3], const float4 (&bq)[3],
+                                              az_f32x16h &cprev, const az_f32x16h &tprev) {
+    az_f32x16h t;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) t[e] = 0.f;
+    t = AZ_H3(t, 0, 0);
+    t = AZ_H3(t, 0, 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cprev[e] += tprev[e];
+    t = AZ_H3(t, 1, 0);
+#pragma unroll
+    for (int e = 8; e < 16; ++e) cprev[e] += tprev[e];
+    tnew = t;
+    asm volatile("" : "+v"(cprev));
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+}
+__device__ __forceinline__ void az_mfma3_now(az_f32x16h &c, const float4 (&aq)[3], const float4 (&bq)[3]) {
+    az_f32x16h t;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) t[e] = 0.f;
+    t = AZ_H3(t, 0, 0); t = AZ_H3(t, 0, 1); t = AZ_H3(t, 1, 0);
+    c += t;
+    asm volatile("" : "+v"(c));
+}
+
 // One f16x3 chain: the three kw taps of a (kd, kh) row for one 4x4-voxel tile, K = 3 x 32, NINE MFMAs summed from zero
 // (the three hi*hi products first, then the six cross terms), while the temporary of the chain before is added to its
 // accumulator (four VALU adds, placed behind the second and third MFMA: the previous chain's last result is then

@@ -44,6 +44,7 @@ There is no module-level state: a Sink belongs to one forward/backward pass of o
 stream itself is cached per device).  `begin()` returns None -- plain in-order weight gradients -- whenever the
 construction above does not apply (no grad mode, a frozen convolution weight, CPU tensors).
 """
+import os
 import threading
 
 import torch
@@ -52,6 +53,9 @@ from . import profiler
 
 _STREAMS = {}
 _STREAMS_LOCK = threading.Lock()
+# HIP priority of the side stream (read once): larger = lower.  The backward pass's critical chain is the MAIN stream
+# (input gradients and BatchNorm backward); the weight gradients have slack until the join at the end.
+_SIDE_PRIORITY = int(os.environ.get("AZ_SIDE_PRIORITY", "0"))
 
 
 def side_stream(device):
@@ -61,7 +65,7 @@ def side_stream(device):
     with _STREAMS_LOCK:
         s = _STREAMS.get(idx)
         if s is None:
-            s = _STREAMS[idx] = torch.cuda.Stream(device=idx)
+            s = _STREAMS[idx] = torch.cuda.Stream(device=idx, priority=_SIDE_PRIORITY)
     return s
 
 

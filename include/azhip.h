@@ -178,17 +178,25 @@ int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
  * and split into two fp16 parts, hi + lo = x up to 2^-22 |x|; hi*hi, hi*lo and lo*hi run on
  * v_mfma_f32_16x16x32_f16 with fp32 accumulation (block sums from zero, one fp32 add per 32-deep block): per-product
  * error ~2^-22 (bf16x6: 2^-24) at half the matrix instructions.  Results are fp32 and unscaled. */
-/* amax[0] = max |x[i]| (x 16-byte aligned; n > 0); NaN propagates */
+/* Every "*_amax" argument of this header is an "amax array": AZ_AMAX_FLOATS floats of which every AZ_AMAX_STRIDE-th
+ * is a slot, and the LARGEST slot is max |tensor| (the workgroups that write a tensor add their maxima to different
+ * slots, in different 256-byte lines: thousands of atomics on one memory channel serialise; readers take the largest
+ * slot).  Output amax arguments must be all ZERO before the call unless stated otherwise.
+ * az_absmax: the amax array of x (16-byte aligned; n > 0), zeroing included; NaN propagates. */
+#define AZ_AMAX_SLOTS 16
+#define AZ_AMAX_STRIDE 64
+#define AZ_AMAX_FLOATS (AZ_AMAX_SLOTS * AZ_AMAX_STRIDE)
 int az_absmax(float *amax, const float *x, long long n, void *stream);
 long long az_conv3d_packed_floats_f16(int cin, int cout);
-/* as az_conv3d_pack_weights, for az_conv3d_bwd_f16: w * 2^k (k from w_amax[0]) split into two fp16 parts,
- * [tap][cin/32][cout/16][2][64][8 fp16] */
+/* as az_conv3d_pack_weights, for the f16x3 launches below: w * 2^k (k from w_amax[0]) split into two fp16 parts.
+ * `mode` = the mode the buffer will be launched with: mode 0 with cout = 32 runs on the depth-rolling kernel
+ * ([tap][cin/32][cout/16][2][64][8 fp16]), everything else on the gather kernel ([tap][cin/32][cout/32][2][2][64][8]). */
 int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
-                               long long stride_out, long long stride_in, int flip, void *stream);
+                               long long stride_out, long long stride_in, int flip, int mode, void *stream);
 /* az_conv3d_fwd / az_conv3d_fwd_stats / az_conv3d_stats_tiles on the f16x3 arithmetic (src = 0 only).  in_amax /
  * w_amax: device scalars holding max |in| and max |w| (of the UNPACKED weights).  The input gradient of a layer is
- * this call on the gradient of its raw output with the flipped / swapped packing, no affine map.  Supported: mode 0
- * with cout = 32 (the V0 layers); everything else returns AZ_EUNSUPPORTED. */
+ * this call on the gradient of its raw output with the flipped / swapped packing, no affine map.  Every mode with
+ * 32 / 64 channels on either side. */
 int az_conv3d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
                       const float *w_amax, const float *scale, const float *shift, const float *residual,
                       int relu, int mode, int B, int cin, int cout, int Di, int Hi, int Wi, void *stream);
@@ -201,6 +209,21 @@ int az_conv3d_fwd_stats_f16(float *out, float *partials, float *counts, const fl
 int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *coarse,
                         const float *fine, const float *coarse_amax, const float *fine_amax, int stride,
                         int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream);
+
+/* az_conv2d_pack_weights / az_conv2d_fwd / az_conv2d_fwd_stats on the f16x3 arithmetic (psmnet_submodule_3.py:13-41,
+ * 92-220: every stride-1 "same" Conv2d of the extractor and its input gradient): in_amax / w_amax = device scalars
+ * max |in|, max |w| (unpacked); packed buffer = kh*kw*cin*cout floats. */
+int az_conv2d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
+                               int ci_real, int co_real, long long stride_out, long long stride_in, int kh,
+                               int kw, int flip, void *stream);
+int az_conv2d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
+                      const float *w_amax, const float *scale, const float *shift, const float *residual,
+                      int relu, int B, int H, int W, int cin, int cout, int in_cstride, int out_cstride,
+                      int res_cstride, int kh, int kw, int dilation, void *stream);
+int az_conv2d_fwd_stats_f16(float *out, float *partials, float *counts, const float *in, const float *packed_w,
+                            const float *in_amax, const float *w_amax, int groups, int B, int H, int W,
+                            int cin, int cout, int in_cstride, int out_cstride, int kh, int kw, int dilation,
+                            void *stream);
 
 /* 32 -> 1 classifier conv (psmnet_3.py:103-117) with the fused running sum
  * cost_k = classif_k(out_k) + cost_{k-1} (psmnet_3.py:177-179): logits [B,D,H,W] =
@@ -244,18 +267,19 @@ int az_bn2d_fwd(float *y, float *mean, float *invstd, float *scale, float *shift
                 long long nvox, int C, float eps, float momentum, long long *num_batches_tracked /* += groups; may be NULL */,
                 const float *partials, const float *counts, long long partial_tiles /* of az_conv2d_fwd_stats; NULL, NULL, 0:
                 the statistics pass runs here */,
-                void *stream);
+                float *y_amax /* may be NULL; ZERO before the call: receives max |y| (az_bn3d_apply) */, void *stream);
 /* backward: dx [groups][nvox][C]; dgamma/dbeta [C] summed over the groups; dz_out (may be NULL) = the
  * gradient of the residual branch when relu != 0 */
 int az_bn2d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *workspace,
                 long long workspace_bytes, const float *dy, const float *y, const float *x,
                 const float *mean, const float *invstd, const float *gamma, const float *scale,
-                const float *shift, int relu, int groups, long long nvox, int C, void *stream);
+                const float *shift, int relu, int groups, long long nvox, int C,
+                float *dx_amax /* may be NULL; ZERO before the call: receives max |dx| */, void *stream);
 int az_bn3d_eval_affine(float *scale, float *shift, const float *gamma, const float *beta,
                         const float *running_mean, const float *running_var, float eps, int C,
                         void *stream);
 /* y = relu?( x*scale[c] + shift[c] + residual ) over nvox voxels of C channels; y_amax (may be NULL): device
- * scalar that receives max |y| (the f16x3 operand scale of the layers that read y) */
+ * scalar, ZERO before the call, that receives max |y| (the f16x3 operand scale of the layers that read y) */
 int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shift,
                   const float *residual, int relu, long long nvox, int C, float *y_amax, void *stream);
 /* backward of y = relu?(bn(x) + residual): dz = dy*[y>0] (or dy), dgamma, dbeta,
@@ -263,8 +287,8 @@ int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shi
  * gradient of the residual branch.  coef: [C][3] scratch.  scale/shift (both or neither): the
  * forward's affine map; when given for a ReLU layer WITHOUT residual the mask is recomputed as
  * fma(x, scale, shift) > 0 and y is not read (may be NULL).
- * dx_amax (may be NULL): device scalar that receives max |dx| -- the operand scale of the f16x3 input- and
- * weight-gradient kernels that read dx next, taken while dx is written instead of by a pass of az_absmax. */
+ * dx_amax (may be NULL; need NOT be zero, the first kernel clears it): receives max |dx| -- the operand scale of the
+ * f16x3 input- and weight-gradient kernels that read dx next, taken while dx is written instead of by az_absmax. */
 long long az_bn3d_bwd_workspace(long long nvox, int C);
 int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
                 float *workspace, long long workspace_bytes, const float *dy, const float *y,

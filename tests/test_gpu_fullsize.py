@@ -54,14 +54,11 @@ def test_conv_adjoint_and_bilinear_identities_full_size(cin, cout, stride, dims)
     out = conv3d.conv_plain(xd, w, mode)
     assert out.shape == raw_shape
     cot = _rand(*out.shape, seed=2)
-    if stride == 1:
-        gx = conv3d._input_grad(cot, w, conv3d.CONV_S1, cin, cout, conv3d.DEFAULT_ARITH.conv)
-    else:
-        pk = conv3d._pack(w, cout, cin, 27, cin * 27, False, conv3d.DEFAULT_ARITH.conv)
-        gx = conv3d._run_gather(cot, pk, conv3d.DECONV_S2, cout, cin, conv3d.DEFAULT_ARITH.conv)
+    bwd = conv3d.F16X3 if conv3d.DEFAULT_ARITH.bwd16 else conv3d.DEFAULT_ARITH.conv
+    gx = conv3d._input_grad(cot, w, mode, cin, cout, bwd)
     lhs, rhs = _dot(out, cot), _dot(xd, gx)
     _same(lhs, rhs, out, cot)
-    gw = conv3d._wgrad(cot, xd, stride, cout, cin, "conv", conv3d.DEFAULT_ARITH.wgrad)
+    gw = conv3d._weight_grad(xd, cot, mode, cin, cout, conv3d.F16X3 if conv3d.DEFAULT_ARITH.bwd16 else conv3d.DEFAULT_ARITH.wgrad)
     _same(lhs, _dot(w, gw), out, cot)
 
 
@@ -73,11 +70,11 @@ def test_deconv_identities_full_size():
     out = conv3d.conv_plain(x, w, conv3d.DECONV_S2)
     assert out.shape == (1, 48, 136, 240, cout)
     cot = _rand(*out.shape, seed=4)
-    pk = conv3d._pack(w, cout, cin, cout * 27, 27, False, conv3d.DEFAULT_ARITH.conv)
-    gx = conv3d._run_gather(cot, pk, conv3d.CONV_S2, cout, cin, conv3d.DEFAULT_ARITH.conv)
+    bwd = conv3d.F16X3 if conv3d.DEFAULT_ARITH.bwd16 else conv3d.DEFAULT_ARITH.conv
+    gx = conv3d._input_grad(cot, w, conv3d.DECONV_S2, cin, cout, bwd)
     lhs, rhs = _dot(out, cot), _dot(x, gx)
     _same(lhs, rhs, out, cot)
-    gw = conv3d._wgrad(x, cot, 2, cin, cout, "deconv", conv3d.DEFAULT_ARITH.wgrad)
+    gw = conv3d._weight_grad(x, cot, conv3d.DECONV_S2, cin, cout, conv3d.F16X3 if conv3d.DEFAULT_ARITH.bwd16 else conv3d.DEFAULT_ARITH.wgrad)
     _same(lhs, _dot(w, gw), out, cot)
 
 

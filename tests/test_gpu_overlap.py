@@ -159,7 +159,8 @@ def test_extractor_called_twice_with_one_sink_stays_in_order():
         assert torch.allclose(p.grad, q.grad, rtol=1e-3, atol=1e-3 * float(q.grad.abs().max()) + 1e-8), k
 
 
-def test_classifier_weight_gradient_beside_a_matrix_kernel():
+@pytest.mark.parametrize("matrix_arith", ["bf16x6", "f16x3"])
+def test_classifier_weight_gradient_beside_a_matrix_kernel(matrix_arith):
     """The 32 -> 1 weight-gradient kernel (VALU, v_pk_fma_f32) must give the same result whether it runs alone or on a
     second stream while the depth-rolling convolution holds the SIMDs: with the operand form hipcc used to pick for it
     (src1 low half from the high register of a pair) lanes 48..63 of some packed FMAs came back wrong beside MFMA
@@ -174,7 +175,10 @@ def test_classifier_weight_gradient_beside_a_matrix_kernel():
     sc, sh = (seeded((32,), 33) * 0.2 + 1.0).to(DEV), (seeded((32,), 34) * 0.1).to(DEV)
     gx = seeded((b, d, h, w, 32), 35).to(DEV)
     wt = (seeded((32, 32, 3, 3, 3), 36) * 0.05).to(DEV)
-    pk = conv3d._pack(wt, 32, 32, 27, 32 * 27, True, conv3d._layout(conv3d.DEFAULT_ARITH.conv, conv3d.CONV_S1, 32))
+    prec = conv3d._PREC[matrix_arith]
+
+    def matrix():  # the depth-rolling kernel in either arithmetic
+        conv3d._input_grad(gx, wt, conv3d.CONV_S1, 32, 32, prec)
 
     def c1_wgrad(out):
         _call("az_conv3d_c1_wgrad", _p(out), _p(x), _p(g), _p(sc), _p(sh), b, d, h, w, _stream())
@@ -187,12 +191,12 @@ def test_classifier_weight_gradient_beside_a_matrix_kernel():
     for _ in range(3):
         beside = torch.empty_like(alone)
         for _ in range(3):  # keep the matrix pipe busy on the main stream for the whole side-stream kernel
-            conv3d._run_gather(gx, pk, conv3d.CONV_S1, 32, 32, conv3d.DEFAULT_ARITH.conv, tag="dgrad")
+            matrix()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             c1_wgrad(beside)
         for _ in range(3):
-            conv3d._run_gather(gx, pk, conv3d.CONV_S1, 32, 32, conv3d.DEFAULT_ARITH.conv, tag="dgrad")
+            matrix()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         worst = max(worst, float((beside.double() - alone.double()).norm() / alone.double().norm()))
