@@ -52,6 +52,10 @@ _SIGS = {
     "az_conv2d_pack_weights_f16": [_PTR, _PTR, _PTR] + [_INT] * 4 + [_LL, _LL] + [_INT] * 3 + [_PTR],
     "az_conv2d_fwd_f16": [_PTR] * 8 + [_INT] * 12 + [_PTR],
     "az_conv2d_fwd_stats_f16": [_PTR] * 7 + [_INT] * 11 + [_PTR],
+    "az_conv2d_wgrad_f16": [_PTR, _PTR, _LL] + [_PTR] * 4 + [_INT] * 12 + [_PTR],
+    "az_conv2d_roll_pack_f16": [_PTR, _PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _PTR],
+    "az_conv2d_roll_fwd_f16": [_PTR] * 8 + [_INT] * 6 + [_PTR],
+    "az_conv2d_roll_fwd_stats_f16": [_PTR] * 7 + [_INT] * 6 + [_PTR],
     "az_disp_loss_fwd": [_PTR] * 6 + [_C.c_float, _C.c_float, _C.c_longlong, _PTR],
     "az_disp_loss_bwd": [_PTR] * 8 + [_C.c_float, _C.c_float, _PTR, _PTR] + [_C.c_float] * 3 + [_C.c_longlong, _PTR],
     "az_disp_metrics": [_PTR] * 7 + [_INT, _C.c_longlong, _PTR],

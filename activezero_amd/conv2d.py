@@ -78,13 +78,7 @@ def _pack_f16(weight, cin, cout, ci_real, co_real, s_out, s_in, kh, kw, flip, ca
         hit = _cache_get(_PACK2D_CACHE, key)
         if hit is not None:
             return hit[0]
-    wkey = (weight.data_ptr(), weight._version, weight.device.index, weight.numel())
-    hit = _cache_get(conv3d._W_AMAX, wkey)
-    if hit is not None:
-        w_amax = hit[0]
-    else:
-        w_amax = conv3d.absmax(w)
-        _cache_put(conv3d._W_AMAX, wkey, (w_amax, weight), 512)
+    w_amax = _w_amax(weight, w)
     packed = torch.empty(kh * kw * cin * cout, dtype=torch.float32, device=w.device)
     _call("az_conv2d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), cin, cout, ci_real, co_real, s_out, s_in, kh, kw,
           int(flip), _stream())
@@ -140,6 +134,43 @@ def _pack_roll(weight, cin, cout, s_out, s_in, flip, cache=False):
     return packed
 
 
+def _w_amax(weight, w):
+    """amax array of a weight tensor, once per optimizer step (conv3d._W_AMAX)"""
+    wkey = (weight.data_ptr(), weight._version, weight.device.index, weight.numel())
+    hit = _cache_get(conv3d._W_AMAX, wkey)
+    if hit is not None:
+        return hit[0]
+    w_amax = conv3d.absmax(w)
+    _cache_put(conv3d._W_AMAX, wkey, (w_amax, weight), 512)
+    return w_amax
+
+
+def _pack_roll_f16(weight, cin, cout, s_out, s_in, flip):
+    w = _chk(weight.detach().contiguous(), "weight")
+    w_amax = _w_amax(weight, w)
+    packed = torch.empty(9 * cin * cout, dtype=torch.float32, device=w.device)
+    _call("az_conv2d_roll_pack_f16", _p(packed), _p(w), _p(w_amax), cin, cout, s_out, s_in, int(flip), _stream())
+    return packed, w_amax
+
+
+def _run_roll_f16(xr, x_amax, packed, w_amax, cin, cout, res=None, tag="conv2d", stats=None):
+    b, h, w, _ = xr.shape
+    out = xr.new_empty(b, h, w, cout)
+    with profiler.scope(f"{tag}_3x3d1_{cin}_{cout}", flops=2.0 * 9 * cin * cout * b * h * w, peak=PEAK_F16):
+        if stats is not None:
+            nrows = int(_lib.lib().az_conv2d_roll_stats_rows(stats.groups, b, h, w, cin, cout))
+            if nrows <= 0:
+                raise RuntimeError(f"az_conv2d_roll_stats_rows: {nrows}")
+            part, cnt = xr.new_empty(stats.groups, cout, nrows, 2), xr.new_empty(stats.groups, nrows)
+            _call("az_conv2d_roll_fwd_stats_f16", _p(out), _p(part), _p(cnt), _p(xr), _p(packed), _p(x_amax), _p(w_amax),
+                  stats.groups, b, h, w, cin, cout, _stream())
+            stats.part, stats.cnt, stats.tiles = part, cnt, nrows
+        else:
+            _call("az_conv2d_roll_fwd_f16", _p(out), _p(xr), _p(packed), _p(x_amax), _p(w_amax), None, None, _p(res), 0,
+                  b, h, w, cin, cout, _stream())
+    return out
+
+
 def _run_roll(xr, packed, cin, cout, scale=None, shift=None, res=None, relu=False, tag="conv2d"):
     b, h, w, _ = xr.shape
     out = xr.new_empty(b, h, w, cout)
@@ -188,20 +219,32 @@ def _run_stats(xr, packed, cin, cout, kh, kw, dil, stats):
     return out
 
 
-def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=None):
+def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=None, amax=None):
     """gr: [B,H,W,>=cm] grad rows, xr: [B,H,W,>=cn] input rows -> [cm_real, cn_real, kh, kw].
-    sink: overlap.Sink or None -- the kernels run on its side stream (the result is valid after its join)."""
+    sink: overlap.Sink or None -- the kernels run on its side stream (the result is valid after its join).
+    amax: None (bf16x6) or (amax array of gr or None, of xr or None): the f16x3 kernels; a missing one is taken here."""
     b, h, w, _ = xr.shape
     gw = xr.new_empty(cm_real, cn_real, kh, kw)
     ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cm, cn, kh, kw)
     if ws_bytes < 0:
         raise RuntimeError(f"conv2d wgrad: unsupported channel counts {cm} x {cn}")
-    with overlap.scope(sink, gr, xr, gw):  # (gw too: the engine may drop it before the join, overlap.py)
+    keep = [t for t in (amax or ()) if t is not None]
+    with overlap.scope(sink, gr, xr, gw, *keep):  # (gw too: the engine may drop it before the join, overlap.py)
         ws = xr.new_empty(ws_bytes // 4)
-        with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
-                            peak=PEAK_X6):
-            _call("az_conv2d_wgrad", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w, cm, cn, cm_real, cn_real,
-                  gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
+        if amax is None:
+            with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
+                                peak=PEAK_X6):
+                _call("az_conv2d_wgrad", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w, cm, cn, cm_real, cn_real,
+                      gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
+        else:
+            am_g = amax[0] if amax[0] is not None else conv3d.absmax(gr)
+            am_x = amax[1] if amax[1] is not None else conv3d.absmax(xr)
+            with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
+                                peak=PEAK_F16):
+                _call("az_conv2d_wgrad_f16", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), _p(am_g), _p(am_x), b, h, w, cm, cn,
+                      cm_real, cn_real, gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
+            if sink is not None and sink.live:
+                sink.keep.extend((am_g, am_x))
     return gw
 
 
@@ -233,7 +276,10 @@ class _ConvSame(torch.autograd.Function):
         xr = _chk(rows(x), "x")
         with torch.cuda.device(x.device):
             want_stats = stats is not None and (kh, kw) in ((3, 3), (1, 1)) and xr.shape[0] % stats.groups == 0
-            if f16 and not _roll_ok(xr, cin, cout, kh, kw, dil):
+            if f16 and _roll_ok(xr, cin, cout, kh, kw, dil):
+                pk, w_amax = _pack_roll_f16(weight, cin, cout, cin * 9, 9, False)
+                y = _run_roll_f16(xr, _amax_of(x, xr), pk, w_amax, cin, cout, stats=stats if want_stats else None)
+            elif f16:
                 pk, w_amax = _pack_f16(weight, cin, cout, cin, cout, cin * kh * kw, kh * kw, kh, kw, False)
                 y = _run_f16(xr, _amax_of(x, xr), pk, w_amax, cin, cout, kh, kw, dil, stats=stats if want_stats else None)
             elif _roll_ok(xr, cin, cout, kh, kw, dil):
@@ -247,6 +293,7 @@ class _ConvSame(torch.autograd.Function):
                     y = _run(xr, pk, cin, cout, kh, kw, dil)
         ctx.save_for_backward(xr, weight)
         ctx.dil = dil
+        ctx.x_amax = (conv3d._get_amax(x) if conv3d._get_amax(x) is not None else conv3d._get_amax(xr)) if f16 else None
         ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None, not as a zero tensor
         if with_skip:
             return image(y), x.view_as(x)
@@ -264,7 +311,10 @@ class _ConvSame(torch.autograd.Function):
         with torch.cuda.device(gy.device):
             if ctx.needs_input_grad[0]:  # the same convolution, taps flipped, channel roles swapped
                 sk = _chk(rows(gskip), "grad_skip") if gskip is not None else None
-                if ctx.f16 and not _roll_ok(gr, cout, cin, kh, kw, dil, sk):
+                if ctx.f16 and _roll_ok(gr, cout, cin, kh, kw, dil, sk):
+                    pk, w_amax = _pack_roll_f16(weight, cout, cin, 9, cin * 9, True)
+                    gx = image(_run_roll_f16(gr, _amax_of(gy, gr), pk, w_amax, cout, cin, res=sk, tag="dgrad2d"))
+                elif ctx.f16:
                     pk, w_amax = _pack_f16(weight, cout, cin, cout, cin, kh * kw, cin * kh * kw, kh, kw, True)
                     gx = image(_run_f16(gr, _amax_of(gy, gr), pk, w_amax, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
                 elif _roll_ok(gr, cout, cin, kh, kw, dil, sk):
@@ -274,7 +324,11 @@ class _ConvSame(torch.autograd.Function):
                     pk = _pack(weight, cout, cin, cout, cin, kh * kw, cin * kh * kw, kh, kw, True)
                     gx = image(_run(gr, pk, cout, cin, kh, kw, dil, res=sk, tag="dgrad2d"))
             if ctx.needs_input_grad[1]:
-                gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil, sink=ctx.sink)
+                am = None
+                if ctx.f16:
+                    g_am = conv3d._get_amax(gy)
+                    am = (g_am if g_am is not None else conv3d._get_amax(gr), ctx.x_amax)
+                gw = _wgrad(gr, xr, cout, cin, cout, cin, kh, kw, dil, sink=ctx.sink, amax=am)
         return gx, gw, None, None, None, None, None
 
 

@@ -35,14 +35,23 @@ struct C2RArgs {
     int nseg, seg_len;      // image segments per group
     int rows;               // partial rows per group = nseg * tiles_yb * tiles_x * 4
     int relu;
+    const float *in_amax, *w_amax;  // AR 1 (f16x3): amax arrays of the input and of the (unpacked) weights
 };
 
 // EPI: 0 = y = relu?(acc * scale + shift), 2 = the same + residual, 1 = raw output + BatchNorm partials
-template <int CIN, int EPI, int NT>
+// AR: 0 = bf16x6, 1 = f16x3 (az_roll_common.h; the slab keeps its 192-byte pixels, the third part unused)
+template <int CIN, int EPI, int NT, int AR = 0>
 __global__ void __launch_bounds__(256, 2)
 conv2d_roll_kernel(const C2RArgs a) {
     constexpr int NCH = CIN / 32;
-    constexpr int TAPF4 = NCH * 2 * 3 * 64;  // float4 per tap of one channel group: [tap][cc][n16][part][lane]
+    constexpr int NP = AR ? 2 : 3;
+    constexpr int TAPF4 = NCH * 2 * NP * 64;  // float4 per tap of one channel group: [tap][cc][n16][part][lane]
+    float in_scale = 1.f, osc = 1.f;
+    if (AR) {
+        const int ki = az_f16_scale_exp(az_amax_read(a.in_amax)), kw_ = az_f16_scale_exp(az_amax_read(a.w_amax));
+        in_scale = az_pow2(ki);
+        osc = ldexpf(1.f, -(ki + kw_));
+    }
     __shared__ __attribute__((aligned(16))) unsigned char slab[2 * R_SLAB_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,12 +118,21 @@ conv2d_roll_kernel(const C2RArgs a) {
             raw[0] = live ? raw[0] : pre[it - 1][0]; raw[1] = live ? raw[1] : pre[it - 1][1];
             raw[2] = live ? raw[2] : pre[it - 1][2]; raw[3] = live ? raw[3] : pre[it - 1][3];
         }
-        uint2 hi, mid, lo;
-        az_split3_bf16x4(__builtin_bit_cast(float4, raw), hi, mid, lo);
         unsigned char *dst = dstbuf + (sy * R_SX + sx) * R_VB + ((((j >> 1) ^ ((sy & 1) << 1))) << 4) + (j & 1) * 8;
-        *reinterpret_cast<uint2 *>(dst) = hi;
-        *reinterpret_cast<uint2 *>(dst + 64) = mid;
-        *reinterpret_cast<uint2 *>(dst + 128) = lo;
+        if (AR) {
+            float4 v = __builtin_bit_cast(float4, raw);
+            v.x *= in_scale; v.y *= in_scale; v.z *= in_scale; v.w *= in_scale;
+            uint2 hi, lo;
+            az_split2_f16x4(v, hi, lo);
+            *reinterpret_cast<uint2 *>(dst) = hi;
+            *reinterpret_cast<uint2 *>(dst + 64) = lo;
+        } else {
+            uint2 hi, mid, lo;
+            az_split3_bf16x4(__builtin_bit_cast(float4, raw), hi, mid, lo);
+            *reinterpret_cast<uint2 *>(dst) = hi;
+            *reinterpret_cast<uint2 *>(dst + 64) = mid;
+            *reinterpret_cast<uint2 *>(dst + 128) = lo;
+        }
     };
 
     // ---- operands ----
@@ -127,9 +145,9 @@ conv2d_roll_kernel(const C2RArgs a) {
     const unsigned wlane = (unsigned)lane * 16u;
     auto load_b = [&](float4 (&bq)[3], int n, int tap_f4) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
             bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                rs_w, wlane, (n >> 1) * (9 * TAPF4 * 16) + tap_f4 * 16 + (n & 1) * 3072 + p * 1024, 0));
+                rs_w, wlane, (n >> 1) * (9 * TAPF4 * 16) + tap_f4 * 16 + (n & 1) * (NP * 1024) + p * 1024, 0));
     };
     // per-channel epilogue constants (four consecutive channels per lane and N tile after the quad transpose)
     const int cq = lane & 12;
@@ -156,6 +174,12 @@ conv2d_roll_kernel(const C2RArgs a) {
     auto finish = [&](int o, bool ok) {
         const bool row_ok = ok && oh_l < a.H;
         const unsigned pix_row = (unsigned)((o * a.H + oh_l) * a.W);
+        if (AR) {  // undo the operand scales on the finished sums
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] *= osc;
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             float4 sc, sf;
@@ -229,7 +253,7 @@ conv2d_roll_kernel(const C2RArgs a) {
         constexpr int CCN = (CC + 1) % NCH;
         const unsigned char *sl = slab + buf * R_SLAB_BYTES;
         unsigned char *sn = slab + (buf ^ 1) * R_SLAB_BYTES;
-        constexpr int wcur = CC * (2 * 3 * 64), wnxt = CCN * (2 * 3 * 64);
+        constexpr int wcur = CC * (2 * NP * 64), wnxt = CCN * (2 * NP * 64);
         const int pn = LAST ? p + 1 : p;
         if (CC == 0) {  // the image before is complete: its epilogue opens this stage, its stores have the stage to land
             finish(p - 1, p - 1 >= d0);
@@ -242,7 +266,7 @@ conv2d_roll_kernel(const C2RArgs a) {
         auto load_a = [&](float4 (&aq)[3], int m, int kh, int kw) {
             const unsigned char *ap = sl + abase[kh & 1] + (kh * R_SX + 4 * m + kw) * R_VB;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) aq[q] = *reinterpret_cast<const float4 *>(ap + 64 * q);
+            for (int q = 0; q < NP; ++q) aq[q] = *reinterpret_cast<const float4 *>(ap + 64 * q);
         };
         load_a(av[0], 0, 0, 0);
 #pragma unroll
@@ -267,7 +291,8 @@ conv2d_roll_kernel(const C2RArgs a) {
                     const int st = t * NT + n;
                     __builtin_amdgcn_sched_barrier(0);
                     f32x4 &prev = n > 0 ? acc[m][n - 1] : (m > 0 ? acc[m - 1][NT - 1] : acc[1][NT - 1]);
-                    r16_step(tq[st & 1], av[t & 1], wk[j & 1][n], prev, tq[(st + 1) & 1]);
+                    if constexpr (AR) r16_step3(tq[st & 1], av[t & 1], wk[j & 1][n], prev, tq[(st + 1) & 1]);
+                    else r16_step(tq[st & 1], av[t & 1], wk[j & 1][n], prev, tq[(st + 1) & 1]);
                     // the next image's six pieces, one per tap from the fourth on, behind the tap's last step
                     if (m == 1 && n == NT - 1 && j >= 3) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -282,7 +307,7 @@ conv2d_roll_kernel(const C2RArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) wk[0][n][q] = wk[1][n][q];
+            for (int q = 0; q < NP; ++q) wk[0][n][q] = wk[1][n][q];
         __syncthreads();
     };
 
@@ -325,6 +350,26 @@ conv2d_pack_r16_kernel(unsigned short *__restrict__ dst, const float *__restrict
     const int ci = cc * 32 + 8 * (lane >> 4) + j;
     const float x = src[co * sn + ci * sk + (flip ? 8 - tap : tap)];
     dst[idx] = az_split3_part(x, p);
+}
+
+// f16x3 image: [cout/32][tap 9][cin/32][n16 2][part 2][lane 64][8] fp16 of w * 2^k (k from the amax array of w)
+__global__ void __launch_bounds__(256)
+conv2d_pack_r16_f16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax,
+                           int cin, int cout, long long sn, long long sk, int flip, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const float scale = az_pow2(az_f16_scale_exp(az_amax_read(amax)));  // (before the early exit: a wave-wide read)
+    if (idx >= total) return;
+    const int j = idx & 7, lane = (idx >> 3) & 63;
+    int r = idx >> 9;
+    const int p = r & 1; r >>= 1;
+    const int n = r & 1; r >>= 1;
+    const int nch = cin / 32;
+    const int cc = r % nch; r /= nch;
+    const int tap = r % 9;
+    const int cg = r / 9;
+    const int co = cg * 32 + n * 16 + (lane & 15);
+    const int ci = cc * 32 + 8 * (lane >> 4) + j;
+    dst[idx] = az_split2_f16_part(src[co * sn + ci * sk + (flip ? 8 - tap : tap)] * scale, p);
 }
 
 static bool c2r_shape_ok(int cin, int cout) { return (cin == 32 || cin == 64) && (cout == 32 || cout == 64); }
@@ -382,18 +427,18 @@ static bool c2r_nt4() {
     static const int on = [] { const char *e = getenv("AZ_CONV2D_ROLL_NT4"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
-template <int EPI>
+template <int EPI, int AR = 0>
 static int c2r_launch(const C2RArgs &a, int cin, hipStream_t s) {
     const bool nt4 = a.cout == 64 && c2r_nt4();
     const long long blocks = (long long)a.G * a.nseg * a.tiles_yb * a.tiles_x * (nt4 ? 1 : a.cout / 32);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     const dim3 grid((unsigned)blocks), blk(256);
     if (nt4) {
-        if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI, 4>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI, 4>), grid, blk, 0, s, a);
+        if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI, 4, AR>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI, 4, AR>), grid, blk, 0, s, a);
     } else {
-        if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI, 2>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI, 2>), grid, blk, 0, s, a);
+        if (cin == 32) hipLaunchKernelGGL((conv2d_roll_kernel<32, EPI, 2, AR>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((conv2d_roll_kernel<64, EPI, 2, AR>), grid, blk, 0, s, a);
     }
     return az_launch_status();
 }
@@ -418,4 +463,38 @@ extern "C" int az_conv2d_roll_fwd_stats(float *out, float *partials, float *coun
     a.in = in; a.wp = packed; a.out = out; a.part = partials; a.cnt = counts;
     a.out_cs = cout; a.res_cs = cout;
     return c2r_launch<1>(a, cin, az_stream(stream));
+}
+
+// ---- f16x3 (include/azhip.h): the same three entry points with the operands' amax arrays ---------------------------
+extern "C" int az_conv2d_roll_pack_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
+                                       long long stride_out, long long stride_in, int flip, void *stream) {
+    AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
+    if (!c2r_shape_ok(cin, cout)) return AZ_EUNSUPPORTED;
+    const int total = 9 * cin * cout * 2;
+    hipLaunchKernelGGL(conv2d_pack_r16_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, az_stream(stream),
+                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, stride_out, stride_in, flip, total);
+    return az_launch_status();
+}
+
+extern "C" int az_conv2d_roll_fwd_f16(float *out, const float *in, const float *packed, const float *in_amax,
+                                      const float *w_amax, const float *scale, const float *shift, const float *residual,
+                                      int relu, int B, int H, int W, int cin, int cout, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(in_amax); AZ_REQUIRE_PTR(w_amax);
+    C2RArgs a{};
+    if (int e = c2r_setup(a, 1, B, H, W, cin, cout)) return e;
+    a.in = in; a.wp = packed; a.out = out; a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu;
+    a.out_cs = cout; a.res_cs = cout; a.in_amax = in_amax; a.w_amax = w_amax;
+    return residual ? c2r_launch<2, 1>(a, cin, az_stream(stream)) : c2r_launch<0, 1>(a, cin, az_stream(stream));
+}
+
+extern "C" int az_conv2d_roll_fwd_stats_f16(float *out, float *partials, float *counts, const float *in,
+                                            const float *packed, const float *in_amax, const float *w_amax, int groups,
+                                            int B, int H, int W, int cin, int cout, void *stream) {
+    AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(partials); AZ_REQUIRE_PTR(counts);
+    AZ_REQUIRE_PTR(in_amax); AZ_REQUIRE_PTR(w_amax);
+    C2RArgs a{};
+    if (int e = c2r_setup(a, groups, B, H, W, cin, cout)) return e;
+    a.in = in; a.wp = packed; a.out = out; a.part = partials; a.cnt = counts;
+    a.out_cs = cout; a.res_cs = cout; a.in_amax = in_amax; a.w_amax = w_amax;
+    return c2r_launch<1, 1>(a, cin, az_stream(stream));
 }

@@ -17,7 +17,7 @@
 // list is exhausted; az_conv2d_wgrad's unpack kernel transposes [tap][co][ci] -> [co][ci][tap].
 #include <stdlib.h>
 
-#include "az_common.h"
+#include "az_roll_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -37,12 +37,21 @@ struct W2Args {
     int blocks_per_combo;
     int fine_dy;  // extra row offset of the fine rows (single-row launches of a multi-row kernel)
     int tap0;     // first workspace tap of this launch
+    const float *coarse_amax, *fine_amax;  // AR 1 (f16x3): amax arrays of dy and x
 };
 
-template <int MT, int NT, int KH, int KW, int DIL>
+// AR: 0 = bf16x6, 1 = f16x3 (az_roll_common.h; the LDS images keep their three-part strides)
+template <int MT, int NT, int KH, int KW, int DIL, int AR = 0>
 __global__ void __launch_bounds__(64 * MT * NT, 2)
 conv2d_wgrad_kernel(const W2Args a) {
     constexpr int T = KH * KW;
+    constexpr int NP = AR ? 2 : 3;
+    float c_scale = 1.f, f_scale = 1.f, o_scale = 1.f;
+    if (AR) {
+        const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax)), kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
+        c_scale = az_pow2(kc); f_scale = az_pow2(kf);
+        o_scale = ldexpf(1.f, -(kc + kf));
+    }
     constexpr int CY = (KH - 1) / 2, CX = (KW - 1) / 2;
     constexpr int WCH = W2_WCH;
     constexpr int FW = WCH + (KW - 1) * DIL;       // fine positions per staged row
@@ -79,12 +88,17 @@ conv2d_wgrad_kernel(const W2Args a) {
     const int tr_col = 16 * ((lane >> 4) & 1) + 4 * tp;
     const int tr_row = 8 * (lane >> 5) + tq;
 
-    auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v) {
+    auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v, float scale_) {
         uint2 hi, mid, lo;
-        az_split3_bf16x4(v, hi, mid, lo);
+        if (AR) {
+            az_split2_f16x4(make_float4(v.x * scale_, v.y * scale_, v.z * scale_, v.w * scale_), hi, mid);
+            lo = mid;
+        } else {
+            az_split3_bf16x4(v, hi, mid, lo);
+        }
         *reinterpret_cast<uint2 *>(dst_part0) = hi;
         *reinterpret_cast<uint2 *>(dst_part0 + part_stride) = mid;
-        *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = lo;
+        if (!AR) *reinterpret_cast<uint2 *>(dst_part0 + 2 * part_stride) = lo;
     };
     auto frag = [&](const unsigned short *img, int r0, int r1) -> bf16x8 {
         const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(img + r0 * 32 + tr_col));
@@ -135,7 +149,7 @@ conv2d_wgrad_kernel(const W2Args a) {
             for (int it = 0; it < NLA; ++it) {
                 const int q = tid + NTHR * it, pos = q / PA, part = q - pos * PA;
                 if (!((okbits >> it) & 1u)) pa[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < NQA) split_store(&sa[(part >> 3) * ATILE + pos * 32 + (part & 7) * 4], WCH * 32, pa[it]);
+                if (q < NQA) split_store(&sa[(part >> 3) * ATILE + pos * 32 + (part & 7) * 4], WCH * 32, pa[it], c_scale);
             }
             const int slot = slot_of(y + DIL * (KH - 1 - CY) + a.fine_dy);
 #pragma unroll
@@ -143,7 +157,7 @@ conv2d_wgrad_kernel(const W2Args a) {
                 const int q = tid + NTHR * it, lw = q / PF, part = q - lw * PF;
                 if (!((okbits >> (8 + it)) & 1u)) pf[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < NQF)
-                    split_store(&sf[(slot * NT + (part >> 3)) * FTILE + lw * 32 + (part & 7) * 4], FW * 32, pf[it]);
+                    split_store(&sf[(slot * NT + (part >> 3)) * FTILE + lw * 32 + (part & 7) * 4], FW * 32, pf[it], f_scale);
             }
         };
 
@@ -156,7 +170,7 @@ conv2d_wgrad_kernel(const W2Args a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (fh >= 0 && fh < a.H && fw >= 0 && fw < a.W)
                 v = *reinterpret_cast<const float4 *>(fbase + (unsigned)(fh * a.W + fw) * (unsigned)a.cs_f + part * 4);
-            split_store(&sf[(slot_of(fh) * NT + (part >> 3)) * FTILE + lw * 32 + (part & 7) * 4], FW * 32, v);
+            split_store(&sf[(slot_of(fh) * NT + (part >> 3)) * FTILE + lw * 32 + (part & 7) * 4], FW * 32, v, f_scale);
         }
         issue(h_beg);
         for (int y = h_beg; y < h_end; ++y) {
@@ -166,7 +180,7 @@ conv2d_wgrad_kernel(const W2Args a) {
             if (y + 1 < h_end) issue(y + 1);  // in flight under this row's MFMAs
             bf16x8 af[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = frag(sa + mt * ATILE + p * WCH * 32, tr_row, tr_row + 4);
+            for (int p = 0; p < NP; ++p) af[p] = frag(sa + mt * ATILE + p * WCH * 32, tr_row, tr_row + 4);
 #pragma unroll
             for (int kh = 0; kh < KH; ++kh) {
                 const unsigned short *frow =
@@ -175,9 +189,16 @@ conv2d_wgrad_kernel(const W2Args a) {
                 for (int kw = 0; kw < KW; ++kw) {
                     bf16x8 bfr[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p)
+                    for (int p = 0; p < NP; ++p)
                         bfr[p] = frag(frow + p * FW * 32, tr_row + kw * DIL, tr_row + 4 + kw * DIL);
                     f32x16 c = acc[kh * KW + kw];
+                    if constexpr (AR) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[1]), __builtin_bit_cast(az_f16x8, bfr[0]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bfr[1]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bfr[0]), c, 0, 0, 0);
+                        acc[kh * KW + kw] = c;
+                        continue;
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], c, 0, 0, 0);
@@ -195,7 +216,7 @@ conv2d_wgrad_kernel(const W2Args a) {
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
             const int m = co0 + mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-            atomicAdd(&a.ws[((size_t)(a.tap0 + t) * a.CM + m) * a.CN + ci0 + nt * 32 + row], acc[t][rg]);
+            atomicAdd(&a.ws[((size_t)(a.tap0 + t) * a.CM + m) * a.CN + ci0 + nt * 32 + row], AR ? acc[t][rg] * o_scale : acc[t][rg]);
         }
     }
 }
@@ -214,6 +235,7 @@ wgrad2d_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int
 
 template <int MT, int NT, int KH, int KW, int DIL>
 static int launch_w2(W2Args a, hipStream_t s) {
+    const bool f16 = a.coarse_amax != nullptr && a.fine_amax != nullptr;
     const int ncombo = (a.CM / (32 * MT)) * (a.CN / (32 * NT));
     a.nwchunk = (a.W + W2_WCH - 1) / W2_WCH;
     // Static work lists (as az_conv3d_wgrad.hip): block w of a combo takes items w, w + Wb, ...; the kernel
@@ -243,8 +265,12 @@ static int launch_w2(W2Args a, hipStream_t s) {
     a.nhseg = (a.H + a.hseg_rows - 1) / a.hseg_rows;
     a.nitems = base_items * a.nhseg;
     if (a.nitems < a.blocks_per_combo) a.blocks_per_combo = (int)((a.nitems + 7) & ~7LL);
-    hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL>), dim3(a.blocks_per_combo * ncombo),
-                       dim3(64 * MT * NT), 0, s, a);
+    if (f16)
+        hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 1>), dim3(a.blocks_per_combo * ncombo),
+                           dim3(64 * MT * NT), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 0>), dim3(a.blocks_per_combo * ncombo),
+                           dim3(64 * MT * NT), 0, s, a);
     return az_launch_status();
 }
 
@@ -258,7 +284,7 @@ static int dispatch_tiles(const W2Args &a, hipStream_t s) {
 }
 
 int az_conv2d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int H, int W, int cm, int cn,
-                               int cs_c, int cs_f, hipStream_t s);
+                               int cs_c, int cs_f, hipStream_t s, const float *coarse_amax, const float *fine_amax);
 
 extern "C" long long az_conv2d_wgrad_workspace(int cm, int cn, int kh, int kw) {
     if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32 || kh <= 0 || kw <= 0) return AZ_EINVAL;
@@ -268,9 +294,10 @@ extern "C" long long az_conv2d_wgrad_workspace(int cm, int cn, int kh, int kw) {
 /* grad_w[cm_real][cn_real][kh][kw] = sum over pixels of grad_out[.., co] * in[.. + tap offset, ci]  (the
  * torch layout of a Conv2d weight).  cm / cn: channel counts of the OPERATION (multiples of 32; tensors whose
  * pixel stride exceeds their real channel count are read as zero-padded by the caller's layout). */
-extern "C" int az_conv2d_wgrad(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
-                               const float *in, int B, int H, int W, int cm, int cn, int cm_real, int cn_real,
-                               int go_cstride, int in_cstride, int kh, int kw, int dilation, void *stream) {
+static int conv2d_wgrad_impl(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                             const float *in, const float *go_amax, const float *in_amax, int B, int H, int W, int cm,
+                             int cn, int cm_real, int cn_real, int go_cstride, int in_cstride, int kh, int kw,
+                             int dilation, void *stream) {
     AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(grad_out); AZ_REQUIRE_PTR(in);
     AZ_REQUIRE(B > 0 && H > 0 && W > 0);
     const long long need = az_conv2d_wgrad_workspace(cm, cn, kh, kw);
@@ -282,12 +309,12 @@ extern "C" int az_conv2d_wgrad(float *grad_w, float *workspace, long long worksp
     hipStream_t s = az_stream(stream);
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
     W2Args a{};
-    a.coarse = grad_out; a.fine = in; a.ws = workspace;
+    a.coarse = grad_out; a.fine = in; a.ws = workspace; a.coarse_amax = go_amax; a.fine_amax = in_amax;
     a.B = B; a.H = H; a.W = W; a.CM = cm; a.CN = cn; a.cs_c = go_cstride; a.cs_f = in_cstride;
     int rc = AZ_EUNSUPPORTED;
     static const int r16 = [] { const char *e = getenv("AZ_CONV2D_WGRAD_R16"); return e ? atoi(e) : 1; }();
     if (kh == 3 && kw == 3 && dilation == 1 && r16 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64))
-        rc = az_conv2d_wgrad_r16_launch(workspace, grad_out, in, B, H, W, cm, cn, go_cstride, in_cstride, s);  // az_conv2d_wgrad16.hip
+        rc = az_conv2d_wgrad_r16_launch(workspace, grad_out, in, B, H, W, cm, cn, go_cstride, in_cstride, s, go_amax, in_amax);  // az_conv2d_wgrad16.hip
     else if (kh == 3 && kw == 3 && dilation == 1) rc = dispatch_tiles<3, 3, 1>(a, s);
     else if (kh == 3 && kw == 3 && dilation == 2) rc = dispatch_tiles<3, 3, 2>(a, s);
     else if (kh == 1 && kw == 1) rc = dispatch_tiles<1, 1, 1>(a, s);
@@ -304,4 +331,21 @@ extern "C" int az_conv2d_wgrad(float *grad_w, float *workspace, long long worksp
     hipLaunchKernelGGL(wgrad2d_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm,
                        cn, cm_real, cn_real, kh * kw);
     return az_launch_status();
+}
+
+extern "C" int az_conv2d_wgrad(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                               const float *in, int B, int H, int W, int cm, int cn, int cm_real, int cn_real,
+                               int go_cstride, int in_cstride, int kh, int kw, int dilation, void *stream) {
+    return conv2d_wgrad_impl(grad_w, workspace, workspace_bytes, grad_out, in, nullptr, nullptr, B, H, W, cm, cn, cm_real,
+                             cn_real, go_cstride, in_cstride, kh, kw, dilation, stream);
+}
+
+/* az_conv2d_wgrad on the f16x3 arithmetic: go_amax / in_amax = amax arrays of grad_out and in */
+extern "C" int az_conv2d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                                   const float *in, const float *go_amax, const float *in_amax, int B, int H, int W,
+                                   int cm, int cn, int cm_real, int cn_real, int go_cstride, int in_cstride, int kh,
+                                   int kw, int dilation, void *stream) {
+    AZ_REQUIRE_PTR(go_amax); AZ_REQUIRE_PTR(in_amax);
+    return conv2d_wgrad_impl(grad_w, workspace, workspace_bytes, grad_out, in, go_amax, in_amax, B, H, W, cm, cn, cm_real,
+                             cn_real, go_cstride, in_cstride, kh, kw, dilation, stream);
 }

@@ -18,7 +18,7 @@
 // accumulate).  LDS 33 KB, so three to four workgroups share a CU (the 3-D kernel: 77 KB, two).
 #include <stdlib.h>
 
-#include "az_common.h"
+#include "az_roll_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -44,10 +44,20 @@ struct Wg2dArgs {
     int nwchunk, nrseg, seg_rows;  // 16-position chunks per row, row segments, rows per segment (even)
     long long ncols;               // B * nwchunk * nrseg columns of work per (co, ci) tile
     int wgs;                       // workgroups per tile
+    const float *coarse_amax, *fine_amax;  // AR 1 (f16x3): amax arrays of dy and x
 };
 
+// AR: 0 = bf16x6, 1 = f16x3 (az_roll_common.h; the LDS images keep their three-part strides)
+template <int AR>
 __global__ void __launch_bounds__(256, 3)
 conv2d_wgrad_r16_kernel(const Wg2dArgs a) {
+    constexpr int NP = AR ? 2 : 3;
+    float c_scale = 1.f, f_scale = 1.f, o_scale = 1.f;
+    if (AR) {
+        const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax)), kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
+        c_scale = az_pow2(kc); f_scale = az_pow2(kf);
+        o_scale = ldexpf(1.f, -(kc + kf));
+    }
     __shared__ __attribute__((aligned(16))) unsigned char lds[V16_LDS + 64];  // + a sink for the lanes of a partial piece
     unsigned char *const cbuf = lds;                  // [2][V16_CBUF]
     unsigned char *const fring = lds + 2 * V16_CBUF;  // [slot][V16_FROW]
@@ -121,7 +131,15 @@ conv2d_wgrad_r16_kernel(const Wg2dArgs a) {
         auto commit_piece = [&](int it, int cbuf_idx, int frow0) {
             const int q = tid + 256 * it;
             uint2 hi, mid, lo;
-            az_split3_bf16x4(__builtin_bit_cast(float4, pre[it]), hi, mid, lo);
+            if (AR) {
+                float4 v = __builtin_bit_cast(float4, pre[it]);
+                const float sc_ = it == 0 ? c_scale : f_scale;
+                v.x *= sc_; v.y *= sc_; v.z *= sc_; v.w *= sc_;
+                az_split2_f16x4(v, hi, mid);
+                lo = mid;
+            } else {
+                az_split3_bf16x4(__builtin_bit_cast(float4, pre[it]), hi, mid, lo);
+            }
             unsigned char *dst;
             unsigned part_stride;
             if (it == 0) {
@@ -137,7 +155,7 @@ conv2d_wgrad_r16_kernel(const Wg2dArgs a) {
             if (q >= V16_NQ) { dst = lds + V16_LDS + (tid & 7) * 8; part_stride = 0; }  // (no branch: a step stays one block)
             *reinterpret_cast<uint2 *>(dst) = hi;
             *reinterpret_cast<uint2 *>(dst + part_stride) = mid;
-            *reinterpret_cast<uint2 *>(dst + 2 * part_stride) = lo;
+            if (!AR) *reinterpret_cast<uint2 *>(dst + 2 * part_stride) = lo;
         };
 
         // ---- prologue: the window of the first step (x rows h0-1 .. h0+2, dy rows h0, h0+1), then the request for the next ----
@@ -164,13 +182,13 @@ conv2d_wgrad_r16_kernel(const Wg2dArgs a) {
 
             az_bf16x8 af[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = frag2(ca + p * 32 * V16_ROWB, ca + p * 32 * V16_ROWB + 4 * V16_ROWB);
+            for (int p = 0; p < NP; ++p) af[p] = frag2(ca + p * 32 * V16_ROWB, ca + p * 32 * V16_ROWB + 4 * V16_ROWB);
             az_bf16x8 bf[2][3];
             auto load_b = [&](az_bf16x8 (&bq)[3], int t) {
                 const int kh = t / 3, kw = t % 3;
                 const unsigned char *fp = fring + fb[kh];
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NP; ++p)
                     bq[p] = frag2(fp + b_off[kw][0] + p * V16_FW * V16_ROWB, fp + b_off[kw][1] + p * V16_FW * V16_ROWB);
             };
             load_b(bf[0], 0);
@@ -181,12 +199,18 @@ conv2d_wgrad_r16_kernel(const Wg2dArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 c = acc[t];
                 const az_bf16x8(&bq)[3] = bf[t & 1];
+                if constexpr (AR) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(az_f16x8, af[1]), __builtin_bit_cast(az_f16x8, bq[0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bq[1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bq[0]), c, 0, 0, 0);
+                } else {
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bq[0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bq[2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bq[1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bq[0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bq[1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bq[0], c, 0, 0, 0);
+                }
                 acc[t] = c;
                 // the set of the next step (requested a step ago): one piece after each of the taps 0, 2, 4; then the
                 // request for the step after that
@@ -208,17 +232,17 @@ conv2d_wgrad_r16_kernel(const Wg2dArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = co0 + 16 * mi + 4 * (lane >> 4) + r;
-            atomicAdd(&a.ws[((size_t)t * a.CM + m) * a.CN + ci0 + 16 * ni + (lane & 15)], acc[t][r]);
+            atomicAdd(&a.ws[((size_t)t * a.CM + m) * a.CN + ci0 + 16 * ni + (lane & 15)], AR ? acc[t][r] * o_scale : acc[t][r]);
         }
 }
 
 // 3x3, dilation 1, CM and CN in {32, 64}; workspace [9][CM][CN] already zeroed by the caller (az_conv2d_wgrad)
 int az_conv2d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int H, int W, int cm, int cn,
-                               int cs_c, int cs_f, hipStream_t s) {
+                               int cs_c, int cs_f, hipStream_t s, const float *coarse_amax, const float *fine_amax) {
     if (!((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return AZ_EUNSUPPORTED;
     if ((long long)H * W * (cs_c > cs_f ? cs_c : cs_f) * 4 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
     Wg2dArgs a{};
-    a.coarse = coarse; a.fine = fine; a.ws = ws;
+    a.coarse = coarse; a.fine = fine; a.ws = ws; a.coarse_amax = coarse_amax; a.fine_amax = fine_amax;
     a.B = B; a.H = H; a.W = W; a.CM = cm; a.CN = cn; a.cs_c = cs_c; a.cs_f = cs_f;
     a.nwchunk = (W + V16_POS - 1) / V16_POS;
     const int ntiles = (cm / 32) * (cn / 32);
@@ -242,6 +266,7 @@ int az_conv2d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
     a.nrseg = best_seg;
     a.ncols = (long long)B * a.nwchunk * a.nrseg;
     a.wgs = best_w;
-    hipLaunchKernelGGL(conv2d_wgrad_r16_kernel, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
+    if (coarse_amax && fine_amax) hipLaunchKernelGGL(conv2d_wgrad_r16_kernel<1>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv2d_wgrad_r16_kernel<0>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
     return az_launch_status();
 }

@@ -124,6 +124,31 @@ __device__ __forceinline__ void az_mfma3_now(az_f32x16h &c, const float4 (&aq)[3
     asm volatile("" : "+v"(c));
 }
 
+// f16x3 form of r16_step (one K32 block: hi*hi, hi*lo, lo*hi from zero; unswapped operand roles, C layout as
+// r16_step): the four adds of the temporary before sit behind the second and third MFMA
+#define R_MH3(ACC, A, B) __builtin_amdgcn_mfma_f32_16x16x32_f16( \
+        __builtin_bit_cast(az_f16x8, aq[A]), __builtin_bit_cast(az_f16x8, bq[B]), ACC, 0, 0, 0)
+__device__ __forceinline__ void r16_step3(f32x4 &tnew, const float4 (&aq)[3], const float4 (&bq)[3], f32x4 &cprev,
+                                          const f32x4 &tprev) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    float c0 = cprev[0], c1 = cprev[1], c2 = cprev[2], c3 = cprev[3];
+    t = R_MH3(t, 0, 0);
+    t = R_MH3(t, 0, 1);
+    c0 += tprev[0];
+    asm volatile("" : "+v"(c0));
+    c1 += tprev[1];
+    asm volatile("" : "+v"(c1));
+    t = R_MH3(t, 1, 0);
+    c2 += tprev[2];
+    asm volatile("" : "+v"(c2));
+    c3 += tprev[3];
+    asm volatile("" : "+v"(c3));
+    tnew = t;
+    cprev[0] = c0; cprev[1] = c1; cprev[2] = c2; cprev[3] = c3;
+    __builtin_amdgcn_sched_group_barrier(0x8, 2, 0); __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+}
+
 // One f16x3 chain: the three kw taps of a (kd, kh) row for one 4x4-voxel tile, K = 3 x 32, NINE MFMAs summed from zero
 // (the three hi*hi products first, then the six cross terms), while the temporary of the chain before is added to its
 // accumulator (four VALU adds, placed behind the second and third MFMA: the previous chain's last result is then

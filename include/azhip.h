@@ -224,6 +224,21 @@ int az_conv2d_fwd_stats_f16(float *out, float *partials, float *counts, const fl
                             const float *in_amax, const float *w_amax, int groups, int B, int H, int W,
                             int cin, int cout, int in_cstride, int out_cstride, int kh, int kw, int dilation,
                             void *stream);
+/* az_conv2d_wgrad on f16x3: go_amax / in_amax = amax arrays of grad_out and in */
+int az_conv2d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                        const float *in, const float *go_amax, const float *in_amax, int B, int H, int W,
+                        int cm, int cn, int cm_real, int cn_real, int go_cstride, int in_cstride, int kh,
+                        int kw, int dilation, void *stream);
+/* az_conv2d_roll_pack / _fwd / _fwd_stats (the batch-walking kernel of the 3x3 layers with 32 / 64 channels) on f16x3;
+ * packed buffer = 9*cin*cout floats; partial rows = az_conv2d_roll_stats_rows */
+int az_conv2d_roll_pack_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
+                            long long stride_out, long long stride_in, int flip, void *stream);
+int az_conv2d_roll_fwd_f16(float *out, const float *in, const float *packed, const float *in_amax,
+                           const float *w_amax, const float *scale, const float *shift, const float *residual,
+                           int relu, int B, int H, int W, int cin, int cout, void *stream);
+int az_conv2d_roll_fwd_stats_f16(float *out, float *partials, float *counts, const float *in, const float *packed,
+                                 const float *in_amax, const float *w_amax, int groups, int B, int H, int W,
+                                 int cin, int cout, void *stream);
 
 /* 32 -> 1 classifier conv (psmnet_3.py:103-117) with the fused running sum
  * cost_k = classif_k(out_k) + cost_{k-1} (psmnet_3.py:177-179): logits [B,D,H,W] =
