@@ -299,6 +299,28 @@ def absmax(t):
     return am
 
 
+def prime_weight_amax(weights):
+    """The amax arrays of all given weight tensors in THREE launches (one multi-tensor max-norm, one stack, one scatter
+    into zeroed arrays) instead of a memset + reduction per weight and step: fills the per-version cache that the f16x3
+    packers read.  Weights whose current version is already cached are skipped; called at the start of a forward pass."""
+    todo = []
+    for w in weights:
+        if w is None or not w.is_cuda or w.dtype != torch.float32:
+            continue
+        key = (w.data_ptr(), w._version, w.device.index, w.numel())
+        if _cache_get(_W_AMAX, key) is None:
+            todo.append((key, w))
+    if not todo:
+        return
+    with torch.no_grad():
+        dets = [w.detach() for _, w in todo]
+        maxes = torch.stack(torch._foreach_norm(dets, float("inf")))
+        arr = torch.zeros(len(todo), AMAX_SLOTS, dtype=torch.float32, device=dets[0].device)
+        arr[:, 0] = maxes
+    for i, (key, w) in enumerate(todo):
+        _cache_put(_W_AMAX, key, (arr[i], w), 512)
+
+
 def _pack_f16(weight, op_cin, op_cout, stride_out, stride_in, flip, mode, cache=False):
     """`mode`: the index map the packed buffer will be launched with (it selects the kernel, hence the layout)"""
     w = _chk(weight.detach().contiguous(), "weight")
@@ -325,8 +347,6 @@ def _pack_f16(weight, op_cin, op_cout, stride_out, stride_in, flip, mode, cache=
 
 def _f16_fwd_ok(mode, cin, cout):
     """shapes with an f16x3 forward kernel (operand `cin` channels -> `cout`)"""
-    if mode == DECONV_S2 and cout == 32:
-        return False  # (bf16x6 has the all-phases kernel az_conv3d_t2.hip for this shape; f16x3 not yet)
     return cin in (32, 64) and cout in (32, 64)
 
 

@@ -604,8 +604,8 @@ template <int MODE, int EPI, int PREC>
 static int dispatch_channels(const ConvArgs &a, int cin, int cout, int src, hipStream_t s) {
     if (PREC == 1 && MODE == 0 && cout == 32 && conv_m128_enabled())
         return az_conv3d_m128_launch(a, cin, EPI, src, s);
-    if (PREC == 1 && MODE == 2 && cout == 32 && src == 0 && (cin == 32 || cin == 64))
-        return az_conv3d_t2_launch(a, cin, EPI, s);
+    if ((PREC == 1 || PREC == 3) && MODE == 2 && cout == 32 && src == 0 && (cin == 32 || cin == 64))
+        return az_conv3d_t2_launch(a, cin, EPI, s);  // (f16x3 when a.in_amax / a.w_amax are set)
     if (src == 1) {
         if (MODE != 0 || cin != 64) return AZ_EUNSUPPORTED;
         if (cout == 32) return launch_conv<64, 32, 0, EPI, 1, PREC>(a, s);

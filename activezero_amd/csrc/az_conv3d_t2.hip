@@ -20,8 +20,9 @@
 #include <type_traits>
 
 #include "az_conv3d_args.h"
+#include "az_roll_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));  // (= az_f32x16h)
 
 #define T2_PITCH 20  // LDS row pitch in voxels (== 4 mod 8)
 #define T2_VS 24     // dwords per slab voxel
@@ -57,9 +58,18 @@ __host__ __device__ constexpr int t2_count(int w, int od) {
     return n;
 }
 
-template <int CIN, int EPI, int WV>
+// AR: 0 = bf16x6, 1 = f16x3 (az_roll_common.h: two scaled fp16 parts in the first two parts of the same slab image,
+// three MFMAs per block; weights in the gather kernel's f16x3 packing)
+template <int CIN, int EPI, int WV, int AR>
 __device__ __forceinline__ void t2_wave(const ConvArgs &a, float *slab, int b, int td, int tiy, int tix) {
     constexpr int NCH = CIN / 16, NCH32 = CIN / 32;
+    constexpr int NP = AR ? 2 : 3, NF = AR ? 4 : 6;
+    float in_scale = 1.f, osc = 1.f;
+    if (AR) {
+        const int ki = az_f16_scale_exp(az_amax_read(a.in_amax)), kw_ = az_f16_scale_exp(az_amax_read(a.w_amax));
+        in_scale = az_pow2(ki);
+        osc = ldexpf(1.f, -(ki + kw_));
+    }
     constexpr int SLAB = T2_SY * T2_PITCH * T2_VS;
     constexpr int NQ = T2_SY * T2_SX * 4, NLD = (NQ + 255) / 256;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -104,19 +114,24 @@ __device__ __forceinline__ void t2_wave(const ConvArgs &a, float *slab, int b, i
             if (!((okbits >> it) & 1u)) pre[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < NQ) {
                 uint2 hi, mid, lo;
-                az_split3_bf16x4(pre[it], hi, mid, lo);
+                if (AR) {
+                    az_split2_f16x4(make_float4(pre[it].x * in_scale, pre[it].y * in_scale, pre[it].z * in_scale, pre[it].w * in_scale), hi, mid);
+                    lo = mid;
+                } else {
+                    az_split3_bf16x4(pre[it], hi, mid, lo);
+                }
                 unsigned *dst = sb + (sy * T2_PITCH + sx) * T2_VS + (((j >> 1) ^ (sy & 1)) * 4) + (j & 1) * 2;
                 *reinterpret_cast<uint2 *>(dst) = hi;
                 *reinterpret_cast<uint2 *>(dst + 8) = mid;
-                *reinterpret_cast<uint2 *>(dst + 16) = lo;
+                if (!AR) *reinterpret_cast<uint2 *>(dst + 16) = lo;
             }
         }
     };
     // packed weights [tap][cin/32][n = 0][part*2 + kb][lane] float4 (az_conv3d.hip), kb = odd 16-channel chunk
     auto load_b = [&](float4 (&bq)[3], int tap, int cc) {
-        const float4 *p = wp4 + ((size_t)(tap * NCH32 + (cc >> 1)) * 6 + (cc & 1)) * 64 + lane;
+        const float4 *p = wp4 + ((size_t)(tap * NCH32 + (cc >> 1)) * NF + (cc & 1)) * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) bq[k] = p[k * 2 * 64];
+        for (int k = 0; k < NP; ++k) bq[k] = p[k * 2 * 64];
     };
     const float *abase[2];
     abase[0] = &slab[(rty * T2_PITCH + rtx) * T2_VS + ((half ^ (rty & 1)) * 4)];
@@ -124,7 +139,7 @@ __device__ __forceinline__ void t2_wave(const ConvArgs &a, float *slab, int b, i
     auto load_a = [&](float4 (&aq)[3], int buf, int m, int oh, int ow) {
         const float *ap = abase[oh & 1] + buf * SLAB + (oh * T2_PITCH + 8 * m + ow) * T2_VS;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) aq[p] = *reinterpret_cast<const float4 *>(ap + 8 * p);
+        for (int p = 0; p < NP; ++p) aq[p] = *reinterpret_cast<const float4 *>(ap + 8 * p);
     };
 
     issue(0);
@@ -158,9 +173,9 @@ __device__ __forceinline__ void t2_wave(const ConvArgs &a, float *slab, int b, i
                 load_a(a1, buf, 1, oh, ow);
             }
             __builtin_amdgcn_sched_barrier(0);
-            az_mfma6_step(t0, a0, bq[i & 1], acc[qprev][1], t1);
+            if constexpr (AR) az_mfma3_step(t0, a0, bq[i & 1], acc[qprev][1], t1); else az_mfma6_step(t0, a0, bq[i & 1], acc[qprev][1], t1);
             __builtin_amdgcn_sched_barrier(0);
-            az_mfma6_step(t1, a1, bq[i & 1], acc[q][0], t0);
+            if constexpr (AR) az_mfma3_step(t1, a1, bq[i & 1], acc[q][0], t0); else az_mfma6_step(t1, a1, bq[i & 1], acc[q][0], t0);
             __builtin_amdgcn_sched_barrier(0);
         }
         commit(buf ^ 1);
@@ -177,6 +192,12 @@ __device__ __forceinline__ void t2_wave(const ConvArgs &a, float *slab, int b, i
         acc[t2_block(WV, 0, t2_count(WV, 0) - 1) & 15][1] += t1;
     }
 
+    if (AR) {  // undo the operand scales on the finished sums
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[q][m] *= osc;
+    }
     // ---- epilogue: one 4x16 coarse patch per phase -> fine voxels (2t + p) ---------------------------------
     const float sc = (EPI == 0 && a.scale) ? a.scale[row] : 1.f, sf = (EPI == 0 && a.shift) ? a.shift[row] : 0.f;
 #pragma unroll
@@ -234,7 +255,7 @@ __device__ __forceinline__ void t2_wave(const ConvArgs &a, float *slab, int b, i
     }
 }
 
-template <int CIN, int EPI>
+template <int CIN, int EPI, int AR>
 __global__ void __launch_bounds__(256, 2)
 conv3d_t2_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float slab[2 * T2_SY * T2_PITCH * T2_VS];
@@ -261,17 +282,19 @@ conv3d_t2_kernel(const ConvArgs a) {
         b = lin / a.Dt;
     }
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wv == 0) t2_wave<CIN, EPI, 0>(a, slab, b, td, tiy, tix);
-    else if (wv == 1) t2_wave<CIN, EPI, 1>(a, slab, b, td, tiy, tix);
-    else if (wv == 2) t2_wave<CIN, EPI, 2>(a, slab, b, td, tiy, tix);
-    else t2_wave<CIN, EPI, 3>(a, slab, b, td, tiy, tix);
+    if (wv == 0) t2_wave<CIN, EPI, 0, AR>(a, slab, b, td, tiy, tix);
+    else if (wv == 1) t2_wave<CIN, EPI, 1, AR>(a, slab, b, td, tiy, tix);
+    else if (wv == 2) t2_wave<CIN, EPI, 2, AR>(a, slab, b, td, tiy, tix);
+    else t2_wave<CIN, EPI, 3, AR>(a, slab, b, td, tiy, tix);
 }
 
 int az_conv3d_t2_launch(const ConvArgs &a, int cin, int epi, hipStream_t s) {
     const long long blocks = (long long)a.B * a.Dt * a.tiles_y * a.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     if ((long long)a.Ho * a.Wo * 32 > 0x7fffffffLL) return AZ_EUNSUPPORTED;
-#define T2_LAUNCH(CIN, EPI) hipLaunchKernelGGL((conv3d_t2_kernel<CIN, EPI>), dim3((unsigned)blocks), dim3(256), 0, s, a)
+    const bool f16 = a.in_amax != nullptr && a.w_amax != nullptr;
+#define T2_LAUNCH(CIN, EPI) do { if (f16) hipLaunchKernelGGL((conv3d_t2_kernel<CIN, EPI, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a); \
+                                 else hipLaunchKernelGGL((conv3d_t2_kernel<CIN, EPI, 0>), dim3((unsigned)blocks), dim3(256), 0, s, a); } while (0)
     if (cin == 64) { if (epi) T2_LAUNCH(64, 1); else T2_LAUNCH(64, 0); }
     else if (cin == 32) { if (epi) T2_LAUNCH(32, 1); else T2_LAUNCH(32, 0); }
     else return AZ_EUNSUPPORTED;

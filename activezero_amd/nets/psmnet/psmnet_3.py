@@ -142,6 +142,10 @@ class PSMNet(nn.Module):
         overlap.Sink (weight-gradient kernels on a side stream; overlap.py explains why autograd and DDP are
         unaffected).  Nothing is stored on the module."""
         sink = overlap.begin(self, like) if self.wgrad_overlap else None
+        if self.arith.conv == conv3d.F16X3 or self.arith.bwd16:
+            # the f16x3 kernels scale their weights by max |w|: all of them in one multi-tensor pass per optimizer step.
+            # (the gated aliases of a training pass share storage and version counter with the parameters)
+            conv3d.prime_weight_amax(overlap.conv_weights(self))
         return self.arith._replace(sink=sink)
 
     def _from_features(self, feat_l, feat_r, arith=None):

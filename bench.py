@@ -549,14 +549,21 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"model ready, {args.warmup} warm-up steps")
-    for _ in range(args.warmup):
-        step()
+    import contextlib
+    # AZ_BENCH_HP=1 (scheduling experiment, tools/sched_ab.sh): the whole step on a HIGH-priority stream, so that the
+    # main stream's short kernels are dispatched ahead of the side stream's pending weight-gradient workgroups
+    hp_stream = torch.cuda.Stream(device=device, priority=-1) if os.environ.get("AZ_BENCH_HP") == "1" else None
+    on_stream = (lambda: torch.cuda.stream(hp_stream)) if hp_stream is not None else contextlib.nullcontext
+    with on_stream():
+        for _ in range(args.warmup):
+            step()
     fence()
     note(f"timing {args.steps} steps")
     profiler.start()  # HIP events around the dominant kernel, on the launch stream
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    with on_stream():
+        for _ in range(args.steps):
+            loss = step()
     fence()
     dt = time.perf_counter() - t0
     prof = profiler.stop()
