@@ -18,6 +18,8 @@ _PTR, _INT, _SIZE, _LL = _C.c_void_p, _C.c_int, _C.c_size_t, _C.c_longlong
 # name -> argtypes (return type is int unless listed in _RESTYPE)
 _SIGS = {
     "az_abi_version": [],
+    "az_hbm_copy_probe": [_PTR, _PTR, _LL, _PTR],
+    "az_option": [_C.c_char_p],
     "az_strerror": [_INT],
     "az_warp_scatter": [_PTR, _PTR, _PTR, _INT, _INT, _INT, _INT, _INT, _PTR],
     "az_cost_volume_fwd": [_PTR] * 3 + [_INT] * 5 + [_PTR],
@@ -52,6 +54,8 @@ _SIGS = {
     "az_conv2d_pack_weights_f16": [_PTR, _PTR, _PTR] + [_INT] * 4 + [_LL, _LL] + [_INT] * 3 + [_PTR],
     "az_conv2d_fwd_f16": [_PTR] * 8 + [_INT] * 12 + [_PTR],
     "az_conv2d_fwd_stats_f16": [_PTR] * 7 + [_INT] * 11 + [_PTR],
+    "az_conv2d_pack_weights_bf16_flipped": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
+    "az_conv2d_wgrad_bf16": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 9 + [_PTR],
     "az_conv2d_wgrad_f16": [_PTR, _PTR, _LL] + [_PTR] * 4 + [_INT] * 12 + [_PTR],
     "az_conv2d_roll_pack_f16": [_PTR, _PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _PTR],
     "az_conv2d_roll_fwd_f16": [_PTR] * 8 + [_INT] * 6 + [_PTR],

@@ -116,7 +116,9 @@ _ROLL2D = os.environ.get("AZ_CONV2D_ROLL", "1") != "0"
 def _roll_ok(xr, cin, cout, kh, kw, dil, res=None):
     """the layer is one az_conv2d_roll.hip takes: 3x3, dilation 1, 32 / 64 channels on both sides, dense tensors"""
     return (_ROLL2D and kh == 3 and kw == 3 and dil == 1 and cin in (32, 64) and cout in (32, 64) and xr.shape[-1] == cin
-            and (res is None or res.shape[-1] == cout))
+            and (res is None or res.shape[-1] == cout)
+            # one statistic group of a tensor goes through a 32-bit buffer offset there (conservatively: the whole batch)
+            and xr.shape[0] * xr.shape[1] * xr.shape[2] * 256 < 0xffffff00)
 
 
 def _pack_roll(weight, cin, cout, s_out, s_in, flip, cache=False):

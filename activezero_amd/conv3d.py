@@ -40,9 +40,20 @@ BF16X6_R16 = 2
 _ROLL = os.environ.get("AZ_CONV_ROLL", "1") != "0"
 
 
-def _layout(precision, mode, op_cout):
+_OFF32 = 0xffffff00  # the depth-rolling kernels address ONE batch element through a 32-bit buffer offset
+
+
+def _fits32(x, cin, cout):
+    """the volume x ([B,D,H,W,C] tensor or LazyCostVolume) fits the 32-bit offsets of the depth-rolling kernels"""
+    if isinstance(x, LazyCostVolume):
+        return True
+    _, d, h, w, _ = x.shape
+    return d * h * w * max(cin, cout) * 4 < _OFF32
+
+
+def _layout(precision, mode, op_cout, fits32=True):
     """precision code the C ABI is called with (packing and launch must agree)"""
-    if precision == BF16X6 and mode == CONV_S1 and op_cout == 32 and _ROLL:
+    if precision == BF16X6 and mode == CONV_S1 and op_cout == 32 and _ROLL and fits32:
         return BF16X6_R16
     return precision
 
@@ -172,13 +183,13 @@ def eval_affine(bn, like, cache=False):
     return scale, shift
 
 
-def _pack_forward(weight, mode, precision, cache=False, lazy=False):
+def _pack_forward(weight, mode, precision, cache=False, lazy=False, fits32=True):
     if mode == DECONV_S2:  # [Cin, Cout, 27]
         cin, cout = weight.shape[0], weight.shape[1]
         return _pack(weight, cin, cout, 27, cout * 27, False, precision, cache), cin, cout
     cout, cin = weight.shape[0], weight.shape[1]
     if not lazy:  # (the fused cost-volume operand, src = 1, stays on the 32x32x16 kernels)
-        precision = _layout(precision, mode, cout)
+        precision = _layout(precision, mode, cout, fits32)
     return _pack(weight, cin, cout, cin * 27, 27, False, precision, cache), cin, cout
 
 
@@ -389,6 +400,9 @@ def _conv(x, weight, mode, precision, scale=None, shift=None, residual=None, rel
         cin, cout = weight.shape[0], weight.shape[1]
     else:
         cout, cin = weight.shape[0], weight.shape[1]
+    fits = _fits32(x, cin, cout)
+    if precision == F16X3 and not fits and mode == CONV_S1 and cout == 32:
+        precision = BF16X6  # (a batch element >= 4 GiB: the flat-address bf16x6 kernels)
     if precision == F16X3 and not lazy and _f16_fwd_ok(mode, cin, cout):
         if mode == DECONV_S2:
             pk, w_amax = _pack_f16(weight, cin, cout, 27, cout * 27, False, mode, cache)
@@ -396,7 +410,7 @@ def _conv(x, weight, mode, precision, scale=None, shift=None, residual=None, rel
             pk, w_amax = _pack_f16(weight, cin, cout, cin * 27, 27, False, mode, cache)
         return _run_f16(x, pk, w_amax, mode, cin, cout, scale, shift, residual, relu, stats, tag)
     prec = BF16X6 if precision == F16X3 else precision
-    packed, cin, cout = _pack_forward(weight, mode, prec, cache=cache, lazy=lazy)
+    packed, cin, cout = _pack_forward(weight, mode, prec, cache=cache, lazy=lazy, fits32=fits)
     return _run_gather(x, packed, mode, cin, cout, prec, scale, shift, residual, relu, stats, tag)
 
 
@@ -456,12 +470,13 @@ def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
 
 def _input_grad(dy, weight, mode, cin, cout, precision):
     """gradient of the layer's input from the gradient dy of its (raw) convolution output"""
+    fits = _fits32(dy, cin, cout)
     if precision == F16X3:
-        if _f16_dgrad_ok(mode, cin, cout):
+        if _f16_dgrad_ok(mode, cin, cout) and (fits or not (mode == CONV_S1 and cin == 32)):
             return _input_grad_f16(dy, weight, mode, cin, cout)
         precision = BF16X6
     if mode == CONV_S1:    # flipped taps, channels swapped
-        pk = _pack(weight, cout, cin, 27, cin * 27, True, _layout(precision, CONV_S1, cin))
+        pk = _pack(weight, cout, cin, 27, cin * 27, True, _layout(precision, CONV_S1, cin, fits))
         return _run_gather(dy, pk, CONV_S1, cout, cin, precision, tag="dgrad")
     if mode == CONV_S2:    # transposed conv of dy with W[co][ci][k]
         pk = _pack(weight, cout, cin, 27, cin * 27, False, precision)

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "az_common.h"
+#include "az_options.h"
 
 // Block-wide fp64 sum in two barriers: DPP/shuffle inside each wave, one LDS slot per wave, then every thread
 // adds the (at most 16) wave sums.  The finalize kernels below are latency bound -- one block per channel, a
@@ -517,7 +518,7 @@ sum4_kernel(float4 *__restrict__ y, const float4 *__restrict__ a, const float4 *
 #define BN_GRID(total) az_grid_for((total), 256)
 // finalize folded into the apply kernel's prologue (AZ_BN_BWD_FUSED=0: the three-kernel sequence, for A/B runs)
 static bool bn_bwd_fused() {
-    static const int on = [] { const char *e = getenv("AZ_BN_BWD_FUSED"); return e ? atoi(e) : 1; }();
+    const int on = az_options().bn_bwd_fused;
     return on != 0;
 }
 static int bn_bwd_fused_blocks(int blocks, int C) {

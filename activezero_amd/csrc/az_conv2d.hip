@@ -430,15 +430,25 @@ extern "C" int az_conv2d_pack_weights(float *packed, const float *w, int cin, in
 }
 
 // plain bf16 image (one part): [tap][cin/16][cout/32][64 lanes][8] bf16 = kh*kw*cin*cout/2 floats
-extern "C" int az_conv2d_pack_weights_bf16(float *packed, const float *w, int cin, int cout, long long stride_out,
-                                           long long stride_in, int kh, int kw, void *stream) {
+static int pack_bf16(float *packed, const float *w, int cin, int cout, long long stride_out, long long stride_in, int kh,
+                     int kw, int flip, void *stream) {
     AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w);
     if (az_conv2d_packed_floats(cin, cout, kh, kw) < 0) return AZ_EUNSUPPORTED;
     const long long total = (long long)kh * kw * cin * cout;
     hipLaunchKernelGGL(conv2d_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, az_stream(stream),
                        reinterpret_cast<unsigned short *>(packed), w, cin, cout, cin, cout, stride_out, stride_in,
-                       kh * kw, 0, 1, total);
+                       kh * kw, flip, 1, total);
     return az_launch_status();
+}
+extern "C" int az_conv2d_pack_weights_bf16(float *packed, const float *w, int cin, int cout, long long stride_out,
+                                           long long stride_in, int kh, int kw, void *stream) {
+    return pack_bf16(packed, w, cin, cout, stride_out, stride_in, kh, kw, 0, stream);
+}
+/* the same with the taps flipped: with (cin, cout, stride_out, stride_in) swapped this is the packing of the layer's
+ * input gradient (az_conv2d_bf16_fwd on the output gradient) */
+extern "C" int az_conv2d_pack_weights_bf16_flipped(float *packed, const float *w, int cin, int cout, long long stride_out,
+                                                   long long stride_in, int kh, int kw, void *stream) {
+    return pack_bf16(packed, w, cin, cout, stride_out, stride_in, kh, kw, 1, stream);
 }
 
 template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>

@@ -22,6 +22,8 @@
 #include <type_traits>
 
 #include "az_roll_common.h"
+#include "az_options.h"
+#include "az_launch_math.h"
 
 struct C2RArgs {
     const float *in;    // [G*N, H, W, CIN] dense channels-last
@@ -58,11 +60,7 @@ conv2d_roll_kernel(const C2RArgs a) {
     const int wr = wv >> 1, wc = wv & 1;  // this wave's quarter: rows 4 wr .., columns 8 wc ..
 
     // ---- block -> (channel group, statistic group, segment, patch): contiguous chunk of the linear order per XCD ----
-    int lin = blockIdx.x;
-    {
-        const int nblk = gridDim.x, xcd = blockIdx.x & 7, q8 = nblk >> 3, r8 = nblk & 7;
-        lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    }
+    int lin = az_xcd_map(blockIdx.x, gridDim.x);
     const int ngrp = a.cout / (16 * NT);  // channel groups in the grid (NT = 4: one workgroup does all 64 channels)
     const int cg = lin % ngrp; lin /= ngrp;
     const int tix = lin % a.tiles_x; lin /= a.tiles_x;
@@ -391,16 +389,8 @@ extern "C" int az_conv2d_roll_pack(float *packed, const float *w, int cin, int c
 
 // image segments per group: one round of workgroups over the chip's 512 slots if the patches allow it
 static void c2r_segments(const C2RArgs &a, int &nseg, int &seg_len) {
-    const long long patches = (long long)a.G * a.tiles_yb * a.tiles_x;  // (64 output channels: one workgroup does both groups)
-    long long best = -1;
-    nseg = 1; seg_len = a.N;
-    for (int n = 1; n <= a.N; ++n) {
-        const int len = (a.N + n - 1) / n;
-        if ((a.N + len - 1) / len != n) continue;
-        const long long rounds = (patches * n + 511) / 512;
-        const long long cost = rounds * (len * 3 + 2);  // stages per workgroup + its fixed cost
-        if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
-    }
+    // (64 output channels: one workgroup does both channel groups)
+    az_c2r_segments((long long)a.G * a.tiles_yb * a.tiles_x, a.N, nseg, seg_len);
 }
 
 static int c2r_setup(C2RArgs &a, int groups, int B, int H, int W, int cin, int cout) {
@@ -424,7 +414,7 @@ extern "C" long long az_conv2d_roll_stats_rows(int groups, int B, int H, int W, 
 // AZ_CONV2D_ROLL_NT4=0: 64 output channels as two channel groups in the grid (two workgroups per patch, each staging
 // the slab) instead of four N tiles per wave
 static bool c2r_nt4() {
-    static const int on = [] { const char *e = getenv("AZ_CONV2D_ROLL_NT4"); return e ? atoi(e) : 1; }();
+    const int on = az_options().conv2d_roll_nt4;
     return on != 0;
 }
 template <int EPI, int AR = 0>

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "az_roll_common.h"
+#include "az_options.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -38,16 +39,19 @@ struct W2Args {
     int fine_dy;  // extra row offset of the fine rows (single-row launches of a multi-row kernel)
     int tap0;     // first workspace tap of this launch
     const float *coarse_amax, *fine_amax;  // AR 1 (f16x3): amax arrays of dy and x
+    int plain_bf16;                        // AR 2
 };
 
-// AR: 0 = bf16x6, 1 = f16x3 (az_roll_common.h; the LDS images keep their three-part strides)
+// AR: 0 = bf16x6, 1 = f16x3 (az_roll_common.h; the LDS images keep their three-part strides), 2 = plain bf16 operands
+// (round-to-nearest, ONE MFMA per tap, fp32 accumulation): the arithmetic of the reference's autocast region around the
+// RAFT-Stereo GRU update (nets/raft/raft_stereo.py:142-172, train.py:303-309), for that block's weight gradients
 template <int MT, int NT, int KH, int KW, int DIL, int AR = 0>
 __global__ void __launch_bounds__(64 * MT * NT, 2)
 conv2d_wgrad_kernel(const W2Args a) {
     constexpr int T = KH * KW;
-    constexpr int NP = AR ? 2 : 3;
+    constexpr int NP = AR == 2 ? 1 : AR ? 2 : 3;
     float c_scale = 1.f, f_scale = 1.f, o_scale = 1.f;
-    if (AR) {
+    if (AR == 1) {
         const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax)), kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
         c_scale = az_pow2(kc); f_scale = az_pow2(kf);
         o_scale = ldexpf(1.f, -(kc + kf));
@@ -90,6 +94,10 @@ conv2d_wgrad_kernel(const W2Args a) {
 
     auto split_store = [&](unsigned short *dst_part0, int part_stride, const float4 &v, float scale_) {
         uint2 hi, mid, lo;
+        if (AR == 2) {
+            *reinterpret_cast<uint2 *>(dst_part0) = make_uint2(az_pk_bf16(v.x, v.y), az_pk_bf16(v.z, v.w));
+            return;
+        }
         if (AR) {
             az_split2_f16x4(make_float4(v.x * scale_, v.y * scale_, v.z * scale_, v.w * scale_), hi, mid);
             lo = mid;
@@ -192,7 +200,11 @@ conv2d_wgrad_kernel(const W2Args a) {
                     for (int p = 0; p < NP; ++p)
                         bfr[p] = frag(frow + p * FW * 32, tr_row + kw * DIL, tr_row + 4 + kw * DIL);
                     f32x16 c = acc[kh * KW + kw];
-                    if constexpr (AR) {
+                    if constexpr (AR == 2) {
+                        acc[kh * KW + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+                        continue;
+                    }
+                    if constexpr (AR == 1) {
                         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[1]), __builtin_bit_cast(az_f16x8, bfr[0]), c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bfr[1]), c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bfr[0]), c, 0, 0, 0);
@@ -216,7 +228,7 @@ conv2d_wgrad_kernel(const W2Args a) {
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
             const int m = co0 + mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-            atomicAdd(&a.ws[((size_t)(a.tap0 + t) * a.CM + m) * a.CN + ci0 + nt * 32 + row], AR ? acc[t][rg] * o_scale : acc[t][rg]);
+            atomicAdd(&a.ws[((size_t)(a.tap0 + t) * a.CM + m) * a.CN + ci0 + nt * 32 + row], AR == 1 ? acc[t][rg] * o_scale : acc[t][rg]);
         }
     }
 }
@@ -236,6 +248,7 @@ wgrad2d_unpack_kernel(float *__restrict__ dst, const float *__restrict__ ws, int
 template <int MT, int NT, int KH, int KW, int DIL>
 static int launch_w2(W2Args a, hipStream_t s) {
     const bool f16 = a.coarse_amax != nullptr && a.fine_amax != nullptr;
+    const bool plain = a.plain_bf16 != 0;
     const int ncombo = (a.CM / (32 * MT)) * (a.CN / (32 * NT));
     a.nwchunk = (a.W + W2_WCH - 1) / W2_WCH;
     // Static work lists (as az_conv3d_wgrad.hip): block w of a combo takes items w, w + Wb, ...; the kernel
@@ -265,7 +278,13 @@ static int launch_w2(W2Args a, hipStream_t s) {
     a.nhseg = (a.H + a.hseg_rows - 1) / a.hseg_rows;
     a.nitems = base_items * a.nhseg;
     if (a.nitems < a.blocks_per_combo) a.blocks_per_combo = (int)((a.nitems + 7) & ~7LL);
-    if (f16)
+    if (plain) {
+        if constexpr (KH == 3 && KW == 3 && DIL == 1)  // (the GRU's convolutions: the only users)
+            hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 2>), dim3(a.blocks_per_combo * ncombo),
+                               dim3(64 * MT * NT), 0, s, a);
+        else
+            return AZ_EUNSUPPORTED;
+    } else if (f16)
         hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 1>), dim3(a.blocks_per_combo * ncombo),
                            dim3(64 * MT * NT), 0, s, a);
     else
@@ -297,7 +316,7 @@ extern "C" long long az_conv2d_wgrad_workspace(int cm, int cn, int kh, int kw) {
 static int conv2d_wgrad_impl(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
                              const float *in, const float *go_amax, const float *in_amax, int B, int H, int W, int cm,
                              int cn, int cm_real, int cn_real, int go_cstride, int in_cstride, int kh, int kw,
-                             int dilation, void *stream) {
+                             int dilation, void *stream, int plain_bf16 = 0) {
     AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(grad_out); AZ_REQUIRE_PTR(in);
     AZ_REQUIRE(B > 0 && H > 0 && W > 0);
     const long long need = az_conv2d_wgrad_workspace(cm, cn, kh, kw);
@@ -310,10 +329,11 @@ static int conv2d_wgrad_impl(float *grad_w, float *workspace, long long workspac
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
     W2Args a{};
     a.coarse = grad_out; a.fine = in; a.ws = workspace; a.coarse_amax = go_amax; a.fine_amax = in_amax;
+    a.plain_bf16 = plain_bf16;
     a.B = B; a.H = H; a.W = W; a.CM = cm; a.CN = cn; a.cs_c = go_cstride; a.cs_f = in_cstride;
     int rc = AZ_EUNSUPPORTED;
-    static const int r16 = [] { const char *e = getenv("AZ_CONV2D_WGRAD_R16"); return e ? atoi(e) : 1; }();
-    if (kh == 3 && kw == 3 && dilation == 1 && r16 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64))
+    const int r16 = az_options().conv2d_wgrad_r16;
+    if (kh == 3 && kw == 3 && dilation == 1 && r16 && !plain_bf16 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64))
         rc = az_conv2d_wgrad_r16_launch(workspace, grad_out, in, B, H, W, cm, cn, go_cstride, in_cstride, s, go_amax, in_amax);  // az_conv2d_wgrad16.hip
     else if (kh == 3 && kw == 3 && dilation == 1) rc = dispatch_tiles<3, 3, 1>(a, s);
     else if (kh == 3 && kw == 3 && dilation == 2) rc = dispatch_tiles<3, 3, 2>(a, s);
@@ -348,4 +368,13 @@ extern "C" int az_conv2d_wgrad_f16(float *grad_w, float *workspace, long long wo
     AZ_REQUIRE_PTR(go_amax); AZ_REQUIRE_PTR(in_amax);
     return conv2d_wgrad_impl(grad_w, workspace, workspace_bytes, grad_out, in, go_amax, in_amax, B, H, W, cm, cn, cm_real,
                              cn_real, go_cstride, in_cstride, kh, kw, dilation, stream);
+}
+
+/* az_conv2d_wgrad with plain bf16 operands (round-to-nearest, one MFMA per 16-deep block, fp32 accumulation, fp32 in / out):
+ * the weight gradient of the RAFT-Stereo GRU's convolutions in the reference's autocast arithmetic; 3x3, dilation 1 */
+extern "C" int az_conv2d_wgrad_bf16(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                                    const float *in, int B, int H, int W, int cm, int cn, int cm_real, int cn_real,
+                                    int go_cstride, int in_cstride, void *stream) {
+    return conv2d_wgrad_impl(grad_w, workspace, workspace_bytes, grad_out, in, nullptr, nullptr, B, H, W, cm, cn, cm_real,
+                             cn_real, go_cstride, in_cstride, 3, 3, 1, stream, 1);
 }

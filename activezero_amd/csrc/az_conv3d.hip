@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "az_roll_common.h"
+#include "az_options.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -591,14 +592,7 @@ static int launch_conv(const ConvArgs &a, hipStream_t s) {
 }
 
 // AZ_CONV_M128=0 keeps the 4x16-patch kernel for the bf16x6 stride-1 32-output-channel layers
-static bool conv_m128_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("AZ_CONV_M128");
-        on = e ? (atoi(e) != 0) : 1;
-    }
-    return on != 0;
-}
+static bool conv_m128_enabled() { return az_options().conv_m128 != 0; }
 
 template <int MODE, int EPI, int PREC>
 static int dispatch_channels(const ConvArgs &a, int cin, int cout, int src, hipStream_t s) {
@@ -702,15 +696,7 @@ extern "C" int az_conv3d_pack_weights(float *packed, const float *w, int cin, in
     return az_launch_status();
 }
 
-static int conv_map_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("AZ_CONV_MAP");
-        mode = e ? atoi(e) : 2;
-        if (mode < 0 || mode > 3) mode = 2;
-    }
-    return mode;
-}
+static int conv_map_mode() { return az_options().conv_map; }
 
 static int conv_common(ConvArgs &a, int mode, int B, int cin, int Di, int Hi, int Wi, int src) {
     if (mode < 0 || mode > 2 || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return AZ_EINVAL;

@@ -36,6 +36,8 @@
 #include "az_conv3d_args.h"
 
 #include "az_roll_common.h"
+#include "az_options.h"
+#include "az_launch_math.h"
 
 // Diagnostic build only (-DR16_STAMP): shader cycles per wave, summed into a buffer nothing else reads
 // (tools/roll_stamp_probe.py): [0] prologue, [1] stage bodies, [2] stage-end barriers, [3] tail, [8] kernel, [9] waves.
@@ -77,16 +79,10 @@ conv3d_roll_kernel(const ConvArgs a) {
 
     // ---- block -> (batch, depth segment, patch): contiguous chunk of the linear order per XCD, x fastest,
     //      so that the workgroups resident on an XCD are a compact (y, x) region walking the same depths ----
-    int lin = blockIdx.x;
-    if (a.map_mode >= 1) {
-        const int nblk = gridDim.x, xcd = blockIdx.x & 7, q8 = nblk >> 3, r8 = nblk & 7;
-        lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    }
+    const int lin = a.map_mode >= 1 ? az_xcd_map(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int tyb = (a.tiles_y + 1) >> 1;  // 8-row patch rows (a.tiles_y counts 4-row tiles)
-    const int tix = lin % a.tiles_x; lin /= a.tiles_x;
-    const int tiy = lin % tyb; lin /= tyb;
-    const int seg = lin % a.nseg;
-    const int b = lin / a.nseg;
+    int tix, tiy, seg, b;
+    az_roll_decode(lin, a.tiles_x, tyb, a.nseg, tix, tiy, seg, b);
     const int d0 = seg * a.seg_len, d1 = min(d0 + a.seg_len, a.Do);  // outputs [d0, d1)
     const int ty0 = tiy * R_TY, tx0 = tix * R_TX;
     const int ih0 = ty0 - 1, iw0 = tx0 - 1;
@@ -629,23 +625,7 @@ int az_conv3d_pack_r16_f16(float *packed, const float *w, const float *w_amax, i
 // depth segments: one round of workgroups over the chip's 512 slots (256 CUs x 2) if the patches allow it,
 // otherwise the split that minimises rounds x (planes walked per workgroup)
 static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
-    const long long patches = (long long)a.B * ((a.tiles_y + 1) / 2) * a.tiles_x;
-    const char *e = getenv("AZ_ROLL_SEGLEN");
-    if (e && atoi(e) > 0) {
-        seg_len = min(atoi(e), a.Do);
-        nseg = (a.Do + seg_len - 1) / seg_len;
-        return;
-    }
-    long long best = -1;
-    nseg = 1; seg_len = a.Do;
-    for (int n = 1; n <= a.Do; ++n) {
-        const int len = (a.Do + n - 1) / n;
-        const int nn = (a.Do + len - 1) / len;
-        if (nn != n) continue;
-        const long long rounds = (patches * n + 511) / 512;
-        const long long cost = rounds * (len + 2) * 3 + 2;  // +: fixed cost per workgroup
-        if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
-    }
+    az_roll_segments((long long)a.B * ((a.tiles_y + 1) / 2) * a.tiles_x, a.Do, az_options().roll_seglen, nseg, seg_len);
 }
 
 // rows of the BatchNorm partial buffers of a roll launch: one per (batch, depth segment, 4x16 tile)
@@ -662,7 +642,7 @@ static int launch_roll(ConvArgs a, hipStream_t s) {
     const long long blocks = (long long)a.B * a.nseg * ((a.tiles_y + 1) / 2) * a.tiles_x;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     // the kernel addresses one batch element of a tensor through a 32-bit buffer offset
-    if ((long long)a.Di * a.Hi * a.Wi * CIN * 4 >= 0xffffff00LL || a.ntiles * 256 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
+    if (!az_fits_buffer_offset((long long)a.Di * a.Hi * a.Wi * CIN * 4) || a.ntiles * 256 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
     hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI, AR>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return az_launch_status();
 }

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "az_roll_common.h"
+#include "az_options.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -608,8 +609,7 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
     // with its most loaded wave, so pick (row segments, waves per combo W) such that the item
     // count is (nearly) a multiple of W while W * NCOMBO stays close to the ~2048 resident
     // waves: score = balance * occupancy, >= 4 items per wave to amortise the per-item prologue.
-    static int slots = -1;  // resident waves the launch may take (AZ_WGRAD_SLOTS: experiments with room left for the other stream)
-    if (slots < 0) { const char *e = getenv("AZ_WGRAD_SLOTS"); slots = e ? atoi(e) : 256 * 8; }
+    const int slots = az_options().wgrad_slots;  // resident waves the launch may take (AZ_WGRAD_SLOTS: room left for the other stream)
     const int wmax = max(8, (slots / NCOMBO) & ~7);
     const long long base_items = (long long)a.B * a.Dc * a.nwchunk;
     double best = -1.0;
@@ -632,13 +632,8 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
     a.nhseg = (a.Hc + a.hseg_rows - 1) / a.hseg_rows;
     a.nitems = base_items * a.nhseg;
     if (a.nitems < a.waves_per_combo) a.waves_per_combo = (int)((a.nitems + 7) & ~7LL);
-    {
-        static int order = -1;
-        if (order < 0) { const char *e = getenv("AZ_WGRAD_ORDER"); order = e ? atoi(e) : 1; }
-        a.order = order;
-    }
-    static int fine_walk = -1;  // AZ_WGRAD_FW=0: the coarse-row walk for the stride-1 layers too (A/B)
-    if (fine_walk < 0) { const char *e = getenv("AZ_WGRAD_FW"); fine_walk = e ? atoi(e) : 1; }
+    a.order = az_options().wgrad_order;
+    const int fine_walk = az_options().wgrad_fw;  // AZ_WGRAD_FW=0: the coarse-row walk for the stride-1 layers too (A/B)
     if (PREC == 3)
         hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CM, CN, S, 1>), dim3(a.waves_per_combo * NCOMBO), dim3(64), 0, s, a);
     else if (PREC == 1 && S == 1 && fine_walk)
@@ -679,16 +674,19 @@ extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long worksp
     a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;
     int rc = AZ_EUNSUPPORTED;
     {
-        static int r16 = -1;  // AZ_WGRAD_R16=0: the one-kd-per-wave kernels for the V0 layers too, 1: only the V0 layers on the new kernel (A/B)
-        if (r16 < 0) { const char *e = getenv("AZ_WGRAD_R16"); r16 = e ? atoi(e) : 2; }
+        const int r16 = az_options().wgrad_r16;  // 0: the one-kd-per-wave kernels for the V0 layers too, 1: only the V0 layers on the new kernel (A/B)
         // (r16 == 1: the V0 32 x 32 layers only; 2: the 64-channel stride-1 layers too, as 32 x 32 tiles in the grid)
         if (r16 && precision == 1 && stride == 1 && (cm == 32 || cm == 64) && (cn == 32 || cn == 64) && (r16 >= 2 || (cm == 32 && cn == 32)) &&
             Dc == Df && Hc == Hf && Wc == Wf) {
             rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s);
-            if (rc != AZ_OK) return rc;
-            const int total = cm * cn * 27;
-            hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm, cn);
-            return az_launch_status();
+            if (rc == AZ_OK) {
+                const int total = cm * cn * 27;
+                hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm, cn);
+                return az_launch_status();
+            }
+            // AZ_EUNSUPPORTED: a batch element beyond the kernel's 32-bit buffer offsets (>= 4 GiB) -- the flat-address
+            // kernels below take it
+            if (rc != AZ_EUNSUPPORTED) return rc;
         }
     }
 #define WG_CASE(M, N)                                                                        \
@@ -720,9 +718,9 @@ extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long wo
     hipStream_t s = az_stream(stream);
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
     int rc = AZ_EUNSUPPORTED;
-    if (stride == 1 && Dc == Df && Hc == Hf && Wc == Wf) {  // all 27 taps per wave on 16x16x32 tiles (az_conv3d_wgrad16.hip)
+    if (stride == 1 && Dc == Df && Hc == Hf && Wc == Wf)  // all 27 taps per wave on 16x16x32 tiles (az_conv3d_wgrad16.hip)
         rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s, coarse_amax, fine_amax);
-    } else {  // stride 2: one kd per wave
+    if (rc == AZ_EUNSUPPORTED) {  // stride 2, or a batch element beyond that kernel's 32-bit offsets: one kd per wave
         WgArgs a{};
         a.coarse = coarse; a.fine = fine; a.ws = workspace; a.coarse_amax = coarse_amax; a.fine_amax = fine_amax;
         a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;

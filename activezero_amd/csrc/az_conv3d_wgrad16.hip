@@ -30,6 +30,8 @@
 #include <stdlib.h>
 
 #include "az_roll_common.h"
+#include "az_options.h"
+#include "az_launch_math.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -289,20 +291,8 @@ int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
     const int slots = 512 / ntiles;  // resident workgroups per tile (two per CU)
     a.nwchunk = (W + W16_POS - 1) / W16_POS;
     a.ncols = (long long)B * D * a.nwchunk;
-    if ((long long)D * H * W * (cm > cn ? cm : cn) * 4 >= 0xffffff00LL) return AZ_EUNSUPPORTED;  // one batch element through a 32-bit offset
-    int best = 1;
-    double best_score = -1.0;
-    for (int w = slots; w >= slots / 4; w -= 8 / (ntiles > 2 ? 4 : ntiles)) {
-        if (w > a.ncols || w < 1) continue;
-        const long long per = (a.ncols + w - 1) / w;
-        const double score = (double)a.ncols / (double)(per * slots);  // useful fraction of the chip-time taken
-        if (score > best_score + 1e-9) { best_score = score; best = w; }
-    }
-    if (a.ncols < slots / 4) best = (int)a.ncols;
-    if (const char *e = getenv("AZ_WGRAD_R16_WGS")) {  // experiment: fewer resident workgroups leave room for the other stream
-        const int cap = atoi(e);
-        if (cap > 0 && cap < best) best = cap;
-    }
+    if (!az_fits_buffer_offset((long long)D * H * W * (cm > cn ? cm : cn) * 4)) return AZ_EUNSUPPORTED;  // one batch element through a 32-bit offset
+    const int best = az_wgrad16_workgroups(a.ncols, slots, ntiles, az_options().wgrad_r16_wgs);
     a.wgs = best;
     if (coarse_amax && fine_amax) hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<1>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<0>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "az_common.h"
+#include "az_options.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -206,7 +207,7 @@ bgemm_x6_kernel(const GemmArgs g) {
 static int launch_gemm(const GemmArgs &g, int batches, hipStream_t s) {
     if (batches <= 0 || batches > 65535) return AZ_EUNSUPPORTED;
     dim3 grid((g.N + G_TN - 1) / G_TN, (g.M + G_TM - 1) / G_TM, batches);
-    static const int fp32 = [] { const char *e = getenv("AZ_CORR_FP32"); return e ? atoi(e) : 0; }();
+    const int fp32 = az_options().corr_fp32;
     if (fp32) {
         hipLaunchKernelGGL(bgemm_tn_kernel, grid, dim3(256), 0, s, g);
         return az_launch_status();

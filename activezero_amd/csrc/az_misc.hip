@@ -1,4 +1,7 @@
+#include <stdlib.h>
+
 #include "az_common.h"
+#include "az_options.h"
 
 extern "C" const char *az_strerror(int code) {
     switch (code) {
@@ -13,3 +16,72 @@ extern "C" const char *az_strerror(int code) {
 }
 
 extern "C" int az_abi_version(void) { return 5; }
+
+// Measurement only (bench.py roofline.measured_hbm; SURVEY.md 8d's second denominator beside the 8 TB/s spec figure): a
+// float4 grid-stride copy, 16 bytes per lane per access -- the stream MI355X_MICROARCH.md quotes 6.29 TB/s for.
+typedef float az_v4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256)
+hbm_copy_kernel(az_v4 *__restrict__ dst, const az_v4 *__restrict__ src, long long n4) {
+    // four 16-byte loads in flight per lane, streaming (nontemporal) in both directions
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const az_v4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const az_v4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+extern "C" int az_hbm_copy_probe(float *dst, const float *src, long long n, void *stream) {
+    AZ_REQUIRE_PTR(dst); AZ_REQUIRE_PTR(src);
+    AZ_REQUIRE(n > 0 && n % 4 == 0);
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) return AZ_EINVAL;
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3(256 * 8), dim3(256), 0, az_stream(stream), reinterpret_cast<az_v4 *>(dst),
+                       reinterpret_cast<const az_v4 *>(src), n / 4);
+    return az_launch_status();
+}
+
+static int az_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+const AzOptions &az_options() {
+    static const AzOptions o = [] {
+        AzOptions v;
+        v.bn_bwd_fused = az_env_int("AZ_BN_BWD_FUSED", 1);
+        v.conv2d_roll_nt4 = az_env_int("AZ_CONV2D_ROLL_NT4", 1);
+        v.conv2d_wgrad_r16 = az_env_int("AZ_CONV2D_WGRAD_R16", 1);
+        v.conv_m128 = az_env_int("AZ_CONV_M128", 1);
+        v.conv_map = az_env_int("AZ_CONV_MAP", 2);
+        if (v.conv_map < 0 || v.conv_map > 3) v.conv_map = 2;
+        v.roll_seglen = az_env_int("AZ_ROLL_SEGLEN", 0);
+        v.wgrad_slots = az_env_int("AZ_WGRAD_SLOTS", 256 * 8);
+        v.wgrad_order = az_env_int("AZ_WGRAD_ORDER", 1);
+        v.wgrad_fw = az_env_int("AZ_WGRAD_FW", 1);
+        v.wgrad_r16 = az_env_int("AZ_WGRAD_R16", 2);
+        v.wgrad_r16_wgs = az_env_int("AZ_WGRAD_R16_WGS", 0);
+        v.corr_fp32 = az_env_int("AZ_CORR_FP32", 0);
+        v.patch_tiled = az_env_int("AZ_PATCH_TILED", 1);
+        v.patch_k = az_env_int("AZ_PATCH_K", 4);
+        return v;
+    }();
+    return o;
+}
+// the value of one switch as the library reads it (tests; name = the environment variable); AZ_EINVAL: no such switch
+extern "C" int az_option(const char *name) {
+    AZ_REQUIRE_PTR(name);
+    const AzOptions &o = az_options();
+    struct { const char *n; int v; } t[] = {
+        {"AZ_BN_BWD_FUSED", o.bn_bwd_fused}, {"AZ_CONV2D_ROLL_NT4", o.conv2d_roll_nt4}, {"AZ_CONV2D_WGRAD_R16", o.conv2d_wgrad_r16},
+        {"AZ_CONV_M128", o.conv_m128}, {"AZ_CONV_MAP", o.conv_map}, {"AZ_ROLL_SEGLEN", o.roll_seglen},
+        {"AZ_WGRAD_SLOTS", o.wgrad_slots}, {"AZ_WGRAD_ORDER", o.wgrad_order}, {"AZ_WGRAD_FW", o.wgrad_fw},
+        {"AZ_WGRAD_R16", o.wgrad_r16}, {"AZ_WGRAD_R16_WGS", o.wgrad_r16_wgs}, {"AZ_CORR_FP32", o.corr_fp32},
+        {"AZ_PATCH_TILED", o.patch_tiled}, {"AZ_PATCH_K", o.patch_k}};
+    for (const auto &e : t) {
+        const char *a = e.n, *b = name;
+        while (*a && *a == *b) { ++a; ++b; }
+        if (!*a && !*b) return e.v;
+    }
+    return AZ_EINVAL;
+}

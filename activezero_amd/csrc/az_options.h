@@ -1,0 +1,23 @@
+// The library's A/B switches (DESIGN.md section 4, table "A/B switches"): environment variables read ONCE, when the first
+// call needs one, into one immutable struct -- no getenv in a launch path, no unsynchronised first-write caches
+// (C++11 guarantees the initialisation of the function-local static in az_options() happens exactly once, under a lock).
+#pragma once
+
+struct AzOptions {
+    int bn_bwd_fused;      // AZ_BN_BWD_FUSED      1: BatchNorm backward in two launches (reduce, apply + merge); 0: three
+    int conv2d_roll_nt4;   // AZ_CONV2D_ROLL_NT4   1: 64 output channels as four N tiles per wave in az_conv2d_roll.hip
+    int conv2d_wgrad_r16;  // AZ_CONV2D_WGRAD_R16  1: 3x3 32/64-channel 2-D weight gradients on az_conv2d_wgrad16.hip
+    int conv_m128;         // AZ_CONV_M128         1: bf16x6 (precision 1) stride-1 32-output layers on az_conv3d_m128.hip
+    int conv_map;          // AZ_CONV_MAP          block -> tile map of the 3-D kernels: 0 linear, 1 XCD-chunked, 2 + banded
+    int roll_seglen;       // AZ_ROLL_SEGLEN       > 0: depth-segment length of az_conv3d_roll.hip (0: chosen per launch)
+    int wgrad_slots;       // AZ_WGRAD_SLOTS       resident waves a 3-D one-kd-per-wave weight gradient may take
+    int wgrad_order;       // AZ_WGRAD_ORDER       work-list order of those kernels (1: XCD-chunked, depth fastest)
+    int wgrad_fw;          // AZ_WGRAD_FW          1: stride-1 bf16x6 fallback kernel walks fine rows
+    int wgrad_r16;         // AZ_WGRAD_R16         0 / 1 / 2: stride-1 3-D weight gradients on az_conv3d_wgrad16.hip (none / 32x32 / all)
+    int wgrad_r16_wgs;     // AZ_WGRAD_R16_WGS     > 0: cap on that kernel's persistent workgroups
+    int corr_fp32;         // AZ_CORR_FP32         1: RAFT correlation GEMMs on the fp32-MFMA kernel
+    int patch_tiled;       // AZ_PATCH_TILED       1: band-tiled patch-reprojection kernel
+    int patch_k;           // AZ_PATCH_K           pixels per thread of that kernel
+};
+
+const AzOptions &az_options();

@@ -16,6 +16,7 @@
 // Backward (w.r.t. the disparity only -- the patterns are data):
 //   d loss / d disp = gloss * 2/count * sign * sum_taps diff * d warped / d ix.
 #include "az_common.h"
+#include "az_options.h"
 
 #define PR_MAX_PS 15
 
@@ -309,11 +310,7 @@ static int pr_band_rows(int B, int H, int W, int ps, int pr_k, size_t *lds_bytes
     }
     return best;
 }
-static bool pr_tiled_enabled() {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("AZ_PATCH_TILED"); on = e ? atoi(e) : 1; }
-    return on != 0;
-}
+static bool pr_tiled_enabled() { return az_options().patch_tiled != 0; }
 template <int MODE, int PSM, int K>
 static bool pr_launch_tiled_k(double *acc, float *gdisp, const float *gloss, const float *L, const float *R,
                               const float *disp, const uint8_t *mask, int B, int C, int H, int W, int ps, float sign,
@@ -322,8 +319,7 @@ template <int MODE, int PSM>
 static bool pr_launch_tiled_ps(double *acc, float *gdisp, const float *gloss, const float *L, const float *R,
                                const float *disp, const uint8_t *mask, int B, int C, int H, int W, int ps, float sign,
                                hipStream_t s) {
-    static int kk = -1;
-    if (kk < 0) { const char *e = getenv("AZ_PATCH_K"); kk = e ? atoi(e) : 4; }  // 1: one pixel per thread (A/B: same forward time, slower backward)
+    const int kk = az_options().patch_k;  // 1: one pixel per thread (A/B: same forward time, slower backward)
     if (kk == 1) return pr_launch_tiled_k<MODE, PSM, 1>(acc, gdisp, gloss, L, R, disp, mask, B, C, H, W, ps, sign, s);
     return pr_launch_tiled_k<MODE, PSM, (MODE == 0 ? 4 : 2)>(acc, gdisp, gloss, L, R, disp, mask, B, C, H, W, ps, sign, s);
 }

@@ -11,8 +11,11 @@ bf16 MFMA path (include/azhip.h `az_conv2d_bf16_fwd`) in TWO launches per update
 
 The gates, context terms and the state itself stay fp32 (the reference keeps them in 16 bits between the
 convolutions, so this path is the more accurate of the two; tests/test_gpu_raft_gru.py measures both against an
-fp64 evaluation).  With autograd enabled (training) the three convolutions run on the differentiable bf16x6
-kernels of activezero_amd.conv2d (fp32-class arithmetic) and the gates in torch.
+fp64 evaluation).  With autograd enabled (training) the convolutions keep that arithmetic in BOTH directions, as the
+reference's autocast + GradScaler training does (train.py:303-309, configs/config.py:24 MIXED_PRECISION = True):
+forward, input gradient (the same kernel on the flipped weight image) and weight gradient (az_conv2d_wgrad_bf16) round
+their operands to bf16 once, one MFMA per block, fp32 accumulation; the gates are fp32 torch operators.
+`ConvGRU.train_arithmetic = "bf16x6"` restores round 3's fp32-class convolutions (six MFMAs per product).
 
 The file is deliberately not called update.py: the rest of that reference module (motion encoder, flow head,
 multi-level block) is ordinary torch code outside this path and keeps resolving from the reference tree; the
@@ -65,7 +68,51 @@ def _rows(t):
     return _chk(t.float().permute(0, 2, 3, 1).contiguous(), "ConvGRU input")
 
 
+class _Conv3x3Bf16(torch.autograd.Function):
+    """conv3x3(x, w) + bias on [B,C,H,W] tensors in channels_last memory, every operand rounded to bf16 once (forward,
+    input gradient, weight gradient), fp32 accumulation and fp32 results"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xr = _chk(conv2d.rows(x), "x")
+        cout, cin = weight.shape[0], weight.shape[1]
+        w = weight.detach().float().contiguous()
+        packed = torch.empty(9 * cin * cout // 2, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(x.device):
+            _call("az_conv2d_pack_weights_bf16", _p(packed), _p(w), cin, cout, cin * 9, 9, 3, 3, _stream())
+            y = conv3x3_bf16(xr, packed, cin, cout, bias.detach().float().contiguous() if bias is not None else None)
+        ctx.save_for_backward(xr, weight)
+        ctx.has_bias = bias is not None
+        return conv2d.image(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        gr = _chk(conv2d.rows(gy), "grad_y")
+        b, h, w_, _ = xr.shape
+        gx = gw = gb = None
+        with torch.cuda.device(gy.device):
+            wt = weight.detach().float().contiguous()
+            if ctx.needs_input_grad[0]:  # the same convolution on gy with flipped taps and swapped channel roles
+                packed = torch.empty(9 * cin * cout // 2, dtype=torch.float32, device=wt.device)
+                _call("az_conv2d_pack_weights_bf16_flipped", _p(packed), _p(wt), cout, cin, 9, cin * 9, 3, 3, _stream())
+                gx = conv2d.image(conv3x3_bf16(gr, packed, cout, cin))
+            if ctx.needs_input_grad[1]:
+                gw = xr.new_empty(cout, cin, 3, 3)
+                ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cout, cin, 3, 3)
+                ws = xr.new_empty(ws_bytes // 4)
+                with profiler.scope(f"gru_wgrad_bf16_{cout}_{cin}", flops=18.0 * cin * cout * b * h * w_, peak=PEAK_BF16):
+                    _call("az_conv2d_wgrad_bf16", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w_, cout, cin, cout, cin,
+                          gr.shape[-1], xr.shape[-1], _stream())
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = gr.sum(dim=(0, 1, 2))
+        return gx, gw, gb
+
+
 class ConvGRU(nn.Module):
+    train_arithmetic = "bf16"  # "bf16": the reference's autocast arithmetic; "bf16x6": fp32-class convolutions (round 3)
+
     def __init__(self, hidden_dim, input_dim, kernel_size=3):
         super().__init__()
         if kernel_size != 3:
@@ -109,11 +156,20 @@ class ConvGRU(nn.Module):
             x = torch.cat([t.float() for t in x_list], 1)
             hx = torch.cat([h, x], 1).contiguous(memory_format=torch.channels_last)
 
-            def conv(m, t):
-                return conv2d.conv_same(t, m.weight) + m.bias.view(1, -1, 1, 1)
+            if self.train_arithmetic == "bf16":
+                def conv(m, t):
+                    return _Conv3x3Bf16.apply(t, m.weight, m.bias)
+            else:
+                def conv(m, t):
+                    return conv2d.conv_same(t, m.weight) + m.bias.view(1, -1, 1, 1)
 
-            z = torch.sigmoid(conv(self.convz, hx) + cz)
-            r = torch.sigmoid(conv(self.convr, hx) + cr)
+            if self.train_arithmetic == "bf16":  # z and r read the same operand: one convolution with 2 x hidden outputs
+                zr = _Conv3x3Bf16.apply(hx, torch.cat([self.convz.weight, self.convr.weight], 0),
+                                        torch.cat([self.convz.bias, self.convr.bias], 0))
+                z, r = torch.sigmoid(zr[:, :self.hidden_dim] + cz), torch.sigmoid(zr[:, self.hidden_dim:] + cr)
+            else:
+                z = torch.sigmoid(conv(self.convz, hx) + cz)
+                r = torch.sigmoid(conv(self.convr, hx) + cr)
             rhx = torch.cat([r * h, x], 1).contiguous(memory_format=torch.channels_last)
             q = torch.tanh(conv(self.convq, rhx) + cq)
             return (1 - z) * h + z * q

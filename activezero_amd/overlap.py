@@ -23,11 +23,12 @@ convention:
     layer's node and the gate nothing reads the tensor: the gate's input buffer holds a single defined gradient,
     so the engine has nothing to add up early -- also when several forward passes of the same module are
     back-propagated together (each pass has its own gates, tail and join).
-  * Operands AND outputs of side-stream kernels are kept referenced by the sink until the join, so the caching
-    allocator cannot hand their memory to later main-stream work while the side stream still reads or writes it
-    (the outputs matter when the engine drops a weight gradient at once, `backward(inputs=[...])` on a subset:
-    tests/test_gpu_overlap.py::test_partial_backward_still_joins_the_side_stream failed with 1e34-sized BatchNorm
-    gradients before they were kept).
+  * Operands AND outputs of side-stream kernels are recorded on the side stream (`Tensor.record_stream`), so the
+    caching allocator cannot hand their memory to later main-stream work while the side stream still reads or
+    writes it (the outputs matter when the engine drops a weight gradient at once, `backward(inputs=[...])` on a
+    subset: tests/test_gpu_overlap.py::test_partial_backward_still_joins_the_side_stream failed with 1e34-sized
+    BatchNorm gradients before they were protected).  Until round 4 they were kept referenced until the join, which
+    held every layer's operands to the end of the backward pass.
 Backstops, so that the scheme cannot silently corrupt memory outside the case it was designed around:
   * the first kernel a pass sends to the side stream registers `sink.join` as an end-of-backward callback of the
     autograd engine: the join also happens when the engine never reaches `_Tail` (`backward(inputs=[...])` or
@@ -185,7 +186,14 @@ class scope:
         sink = self.sink
         if sink is not None and sink.live:
             sink.ensure_callback()
-            sink.keep.extend(t for t in self.operands if t is not None)
+            # Operands and outputs live in the MAIN stream's allocator pool and are read / written here on the side
+            # stream: tell the caching allocator (record_stream), which then holds a freed block back until the side
+            # stream has passed the point of the free.  Round 3 kept Python references until the join instead, so the
+            # operands of every layer (x, dy: 0.2-0.8 GB each at V0) stayed allocated until the end of backward and the
+            # peak grew with depth; now each is released as soon as autograd drops it and its kernel has run.
+            for t in self.operands:
+                if t is not None:
+                    t.record_stream(sink.stream)
             sink.stream.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(sink.stream)
             self.ctx.__enter__()

@@ -71,12 +71,13 @@ def stop():
     return out
 
 
-# profiler scope name -> kernel symbol in the rocprofv3 PMC summary
-_PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_roll_kernel<32, 1>", "conv3d_m128_kernel<32, 1, 0>",
-                                  "conv3d_gather_kernel<32, 32, 0, 1, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 1, 0, 0>"),
-              "dgrad_m0_32_32": ("conv3d_roll_kernel<32, 0>", "conv3d_roll_kernel<32, 2>", "conv3d_m128_kernel<32, 0, 0>",
-                                 "conv3d_gather_kernel<32, 32, 0, 0, 0, 1>", "conv3d_gather_kernel<32, 32, 0, 0, 0, 0>"),
-              "conv_wgrad_s1_32_32": ("conv3d_wgrad_x6_kernel<32, 32, 1>", "conv3d_wgrad_kernel<32, 32, 1>")}
+# profiler scope name -> kernel symbol in the rocprofv3 PMC summary (newest kernel first)
+_PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_roll_kernel<32, 1, 1>", "conv3d_roll_kernel<32, 1, 0>", "conv3d_roll_kernel<32, 1>",
+                                  "conv3d_m128_kernel<32, 1, 0>"),
+              "dgrad_m0_32_32": ("conv3d_roll_kernel<32, 0, 1>", "conv3d_roll_kernel<32, 0, 0>", "conv3d_roll_kernel<32, 0>",
+                                 "conv3d_roll_kernel<32, 2>", "conv3d_m128_kernel<32, 0, 0>"),
+              "conv_wgrad_s1_32_32": ("conv3d_wgrad_r16_kernel<1>", "conv3d_wgrad_r16_kernel<0>", "conv3d_wgrad_r16_kernel",
+                                      "conv3d_wgrad_x6_kernel<32, 32, 1>", "conv3d_wgrad_kernel<32, 32, 1>")}
 
 
 def pmc_traffic(scope_name, per_launch_work, pmc_json):
@@ -118,38 +119,68 @@ def held_clock(scope_name, clock_json):
     return None
 
 
-def roofline(prof, pmc_json=None, clock_json=None):
-    """roofline object for the kernel with the largest total time in the timed region among the kernels that
-    have the chip to themselves.  (In the backward pass the weight-gradient kernels run on the side stream
-    BESIDE the main stream's kernels, overlap.py: event-to-event durations there are those of kernels sharing
-    the chip -- a BatchNorm reduction waiting for wave slots reads 10x its solo time -- not single-kernel rates;
-    those entries are listed under `others` with "side_stream" / "beside_side_stream": true.)"""
+def _rate(r):
+    peak, unit = PEAK[r["bound"]]
+    basis = "fp32 MFMA dense" if r["bound"] == "mfma" else "HBM3E spec"
+    if r.get("peak"):
+        peak, basis = r["peak"]
+    work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
+    return work / (r["avg_ms"] * 1e-3), peak, basis, unit
+
+
+def roofline(prof, pmc_json=None, clock_json=None, ms_per_step=None, steps=1, solo=None):
+    """roofline object for the kernel with the LARGEST TOTAL TIME in the timed region (event-to-event durations on the
+    launch stream).  In the backward pass the weight-gradient kernels run on a side stream BESIDE the main stream's
+    kernels (overlap.py), so that duration is the one of a kernel sharing the chip: `frac` is the in-step figure,
+    `top_kernel_frac_solo` the same launch shape timed alone after the run (`solo`, from bench.py).  Scalars at the top
+    level (they survive parsers that drop nested objects): top_kernel_by_time, top_kernel_frac_in_step,
+    top_kernel_frac_solo, whole_step_tflops / whole_step_frac (all MFMA-bound scopes' algorithmic flops over the step
+    time, against the peak of the arithmetic most of them run in)."""
     if not prof:
         return None
+    name, r = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+    achieved, peak, peak_basis, unit = _rate(r)
     alone = [(k, v) for k, v in prof.items() if not (v.get("side_stream") or v.get("beside_side_stream"))]
-    name, r = max(alone or list(prof.items()), key=lambda kv: kv[1]["total_ms"])
-    peak, unit = PEAK[r["bound"]]
-    peak_basis = "fp32 MFMA dense" if r["bound"] == "mfma" else "HBM3E spec"
-    if r.get("peak"):
-        peak, peak_basis = r["peak"]
-    work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
-    achieved = work / (r["avg_ms"] * 1e-3)
-    # the kernel with the largest total time OVERALL is usually one that shares the chip (side stream): named too
-    oname, orec = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-    overall = {"kernel": oname, "total_ms": orec["total_ms"], "avg_ms": orec["avg_ms"], "launches": orec["launches"],
-               "overlapped": bool(orec.get("side_stream") or orec.get("beside_side_stream")),
-               "note": "event-to-event duration; overlapped = ran beside another stream's kernels, not a solo rate"}
-    return {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak,
-            "peak_basis": peak_basis, "unit": unit,
-            "frac": achieved / peak,
-            "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
-            "selection": "largest total time among the kernels that run alone (not beside the side stream)",
-            "largest_total_time_overall": overall,
-            "held_clock": held_clock(name, clock_json),
-            "avg_launch_ms": r["avg_ms"],
-            "launches_timed": r["launches"],
-            "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
-            "others": {k: dict({"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]},
-                               **({"side_stream": True} if v.get("side_stream") else {}),
-                               **({"beside_side_stream": True} if v.get("beside_side_stream") else {}))
-                       for k, v in prof.items() if k != name}}
+    aname, arec = max(alone or list(prof.items()), key=lambda kv: kv[1]["total_ms"])
+    a_ach, a_peak, a_basis, _ = _rate(arec)
+    out = {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak, "peak_basis": peak_basis, "unit": unit,
+           "frac": achieved / peak,
+           "selection": "largest total time in the timed region, overlapped kernels included; `frac` is its in-step rate",
+           "in_step_overlapped": bool(r.get("side_stream") or r.get("beside_side_stream")),
+           "top_kernel_by_time": name, "top_kernel_frac_in_step": achieved / peak,
+           "top_kernel_ms_in_step": r["avg_ms"], "top_kernel_launches_per_step": r["launches"] / max(steps, 1),
+           "top_kernel_frac_solo": None, "top_kernel_ms_solo": None,
+           "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
+           "held_clock": held_clock(name, clock_json),
+           "avg_launch_ms": r["avg_ms"], "launches_timed": r["launches"],
+           "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
+           "largest_alone": {"kernel": aname, "achieved": a_ach, "peak": a_peak, "peak_basis": a_basis, "frac": a_ach / a_peak,
+                             "avg_ms": arec["avg_ms"], "launches": arec["launches"],
+                             "note": "largest total time among the kernels that ran with the chip to themselves"}}
+    if solo and solo.get(name):
+        out["top_kernel_ms_solo"] = solo[name]
+        work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
+        out["top_kernel_frac_solo"] = work / (solo[name] * 1e-3) / peak
+    if solo:
+        out["solo_ms"] = solo
+    if ms_per_step:
+        mf = [v for v in prof.values() if v["bound"] == "mfma"]
+        flop_step = sum(v["flops"] * v["launches"] for v in mf) / max(steps, 1)
+        # the peak most of the matrix work runs against: flop-weighted vote over the scopes' own peaks
+        votes = {}
+        for v in mf:
+            pk = (v.get("peak") or (PEAK["mfma"][0], "fp32 MFMA dense"))
+            votes[pk] = votes.get(pk, 0.0) + v["flops"] * v["launches"]
+        wpeak, wbasis = max(votes.items(), key=lambda kv: kv[1])[0] if votes else (PEAK["mfma"][0], "fp32 MFMA dense")
+        out["whole_step_tflops"] = flop_step / 1e12 / (ms_per_step * 1e-3)
+        out["whole_step_frac"] = out["whole_step_tflops"] / wpeak
+        out["whole_step_peak"] = wpeak
+        out["whole_step_peak_basis"] = wbasis
+        out["whole_step_mfma_flop"] = flop_step
+        out["whole_step_note"] = ("algorithmic flops of every MFMA-bound scope of one step (the cost-volume convolution counted "
+                                  "in its factored form) over ms_per_step; HBM-bound kernels, Adam and torch glue are in the time")
+    out["others"] = {k: dict({"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]},
+                             **({"side_stream": True} if v.get("side_stream") else {}),
+                             **({"beside_side_stream": True} if v.get("beside_side_stream") else {}))
+                     for k, v in prof.items() if k != name}
+    return out

@@ -8,6 +8,12 @@ registered autograd formulas instead of Python autograd.Function objects.
     torch.ops.azhip.softargmin(logits)                             K6      nets/psmnet/psmnet_3.py:184-215
     torch.ops.azhip.warp_gather(img, disp)                         K7      utils/reprojection.py:13-35
     torch.ops.azhip.local_contrast_norm(image, kernel_size, eps)   K9      utils/reprojection.py:175-200
+    torch.ops.azhip.conv3d(x_ndhwc, weight, mode)                  K4/K5   nets/psmnet/psmnet_3.py:15-58 (Conv3d /
+                                                                           ConvTranspose3d 3x3x3; mode 0 stride 1, 1 stride 2,
+                                                                           2 transposed stride 2; channels-last volume)
+    torch.ops.azhip.bn3d(raw, scale, shift, residual?, relu)       --      psmnet_submodule_3.py:44-56 (the affine form of
+                                                                           BatchNorm3d (+ residual) (+ ReLU) on a conv output)
+    torch.ops.azhip.patch_reproj(left, right, disp, mask?, ps)     K8      utils/reprojection.py:81-172
 
 Importing this module registers the operators (idempotent).  There is no CPU implementation: calling one
 with CPU tensors raises, as every other entry of this package does.
@@ -185,3 +191,160 @@ torch.library.register_fake(
     "azhip::local_contrast_norm",
     lambda image, k, eps: (image.new_empty(image.shape[0], 1, image.shape[2], image.shape[3]),
                            image.new_empty(image.shape[0], 1, image.shape[2], image.shape[3])))
+
+
+# ---- K4/K5: 3x3x3 convolution of a channels-last volume ------------------------------------------------
+from . import conv3d as _c3  # noqa: E402
+
+_LIB.define("conv3d(Tensor x, Tensor weight, int mode) -> Tensor")
+_LIB.define("conv3d_input_grad(Tensor grad_out, Tensor weight, int mode) -> Tensor")
+_LIB.define("conv3d_weight_grad(Tensor x, Tensor grad_out, Tensor weight, int mode) -> Tensor")
+_LIB.define("bn3d(Tensor raw, Tensor scale, Tensor shift, Tensor? residual, bool relu) -> Tensor")
+_LIB.define("patch_reproj(Tensor left, Tensor right, Tensor disp, Tensor? mask, int ps) -> Tensor")
+_LIB.define("patch_reproj_bwd(Tensor grad_loss, Tensor left, Tensor right, Tensor disp, Tensor? mask, int ps) -> Tensor")
+
+
+def _c3_channels(weight, mode):
+    return (weight.shape[0], weight.shape[1]) if mode == _c3.DECONV_S2 else (weight.shape[1], weight.shape[0])
+
+
+def _conv3d(x, weight, mode):
+    with torch.cuda.device(x.device):
+        return _c3._conv(_chk(x.contiguous(), "x"), weight, mode, _c3.DEFAULT_ARITH.conv)
+
+
+def _conv3d_input_grad(g, weight, mode):
+    cin, cout = _c3_channels(weight, mode)
+    a = _c3.DEFAULT_ARITH
+    with torch.cuda.device(g.device):
+        return _c3._input_grad(_chk(g.contiguous(), "grad_out"), weight, mode, cin, cout, _c3.F16X3 if a.bwd16 else a.conv)
+
+
+def _conv3d_weight_grad(x, g, weight, mode):
+    cin, cout = _c3_channels(weight, mode)
+    a = _c3.DEFAULT_ARITH
+    with torch.cuda.device(g.device):
+        return _c3._weight_grad(_chk(x.contiguous(), "x"), _chk(g.contiguous(), "grad_out"), mode, cin, cout,
+                                _c3.F16X3 if a.bwd16 else a.wgrad)
+
+
+def _conv3d_fake(x, weight, mode):
+    b, d, h, w, _ = x.shape
+    do, ho, wo = _c3._out_dims(mode, d, h, w)
+    return x.new_empty(b, do, ho, wo, weight.shape[1] if mode == _c3.DECONV_S2 else weight.shape[0])
+
+
+def _conv3d_in_dims(g, weight, mode):
+    b, d, h, w, _ = g.shape
+    cin, _ = _c3_channels(weight, mode)
+    if mode == _c3.CONV_S1:
+        return g.new_empty(b, d, h, w, cin)
+    if mode == _c3.CONV_S2:
+        return g.new_empty(b, 2 * d, 2 * h, 2 * w, cin)
+    return g.new_empty(b, d // 2, h // 2, w // 2, cin)
+
+
+for _n, _f in (("conv3d", _conv3d), ("conv3d_input_grad", _conv3d_input_grad), ("conv3d_weight_grad", _conv3d_weight_grad)):
+    _LIB.impl(_n, _f, "CUDA")
+    _LIB.impl(_n, _no_cpu(_n), "CPU")
+torch.library.register_fake("azhip::conv3d", _conv3d_fake)
+torch.library.register_fake("azhip::conv3d_input_grad", _conv3d_in_dims)
+torch.library.register_fake("azhip::conv3d_weight_grad", lambda x, g, w, mode: torch.empty_like(w))
+
+
+def _conv3d_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+    ctx.mode = inputs[2]
+
+
+def _conv3d_backward(ctx, g):
+    x, w = ctx.saved_tensors
+    gx = torch.ops.azhip.conv3d_input_grad(g, w, ctx.mode) if ctx.needs_input_grad[0] else None
+    gw = torch.ops.azhip.conv3d_weight_grad(x, g, w, ctx.mode) if ctx.needs_input_grad[1] else None
+    return gx, gw, None
+
+
+torch.library.register_autograd("azhip::conv3d", _conv3d_backward, setup_context=_conv3d_setup)
+
+
+# ---- BatchNorm3d as its affine map (+ residual) (+ ReLU) on a channels-last tensor ------------------------
+def _bn3d(raw, scale, shift, residual, relu):
+    raw = _chk(raw.contiguous(), "raw")
+    c = raw.shape[-1]
+    y = torch.empty_like(raw)
+    with torch.cuda.device(raw.device):
+        _call("az_bn3d_apply", _p(y), _p(raw), _p(_chk(scale.contiguous(), "scale")), _p(_chk(shift.contiguous(), "shift")),
+              _p(_chk(residual.contiguous(), "residual")) if residual is not None else None, int(relu),
+              raw.numel() // c, c, None, _stream())
+    return y
+
+
+_LIB.impl("bn3d", _bn3d, "CUDA")
+_LIB.impl("bn3d", _no_cpu("bn3d"), "CPU")
+torch.library.register_fake("azhip::bn3d", lambda raw, scale, shift, residual, relu: torch.empty_like(raw))
+
+
+def _bn3d_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], output)
+    ctx.relu, ctx.has_res = inputs[4], inputs[3] is not None
+
+
+def _bn3d_backward(ctx, g):
+    raw, scale, y = ctx.saved_tensors
+    dz = g * (y > 0).to(g.dtype) if ctx.relu else g
+    red = tuple(range(raw.dim() - 1))
+    return dz * scale, (dz * raw).sum(dim=red), dz.sum(dim=red), (dz if ctx.has_res else None), None
+
+
+torch.library.register_autograd("azhip::bn3d", _bn3d_backward, setup_context=_bn3d_setup)
+
+
+# ---- K8: patch reprojection loss --------------------------------------------------------------------------
+def _pr_args(left, right, disp, mask):
+    pl, pr = _chk(left.detach().contiguous(), "left"), _chk(right.detach().contiguous(), "right")
+    d = _chk(disp.contiguous(), "disp")
+    b, c, h, w = pl.shape
+    if d.numel() != b * h * w:
+        raise RuntimeError("disp must be [B,1,H,W]")
+    m = _chk(mask.contiguous().to(torch.uint8), "mask", torch.uint8) if mask is not None else None
+    return pl, pr, d, m, (b, c, h, w)
+
+
+def _patch_reproj(left, right, disp, mask, ps):
+    pl, pr, d, m, (b, c, h, w) = _pr_args(left, right, disp, mask)
+    acc = torch.empty(2, dtype=torch.float64, device=pl.device)
+    with torch.cuda.device(pl.device):
+        _call("az_patch_reproj_fwd", _p(acc), _p(pl), _p(pr), _p(d), _p(m), b, c, h, w, int(ps), -1.0, _stream())
+    return (acc[0] / acc[1]).to(torch.float32)
+
+
+def _patch_reproj_bwd(gloss, left, right, disp, mask, ps):
+    pl, pr, d, m, (b, c, h, w) = _pr_args(left, right, disp, mask)
+    acc = torch.empty(2, dtype=torch.float64, device=pl.device)
+    gd = torch.empty_like(d)
+    with torch.cuda.device(pl.device):  # (the normaliser is recomputed: the dispatcher form saves tensors only)
+        _call("az_patch_reproj_fwd", _p(acc), _p(pl), _p(pr), _p(d), _p(m), b, c, h, w, int(ps), -1.0, _stream())
+        _call("az_patch_reproj_bwd", _p(gd), _p(gloss.to(torch.float32).contiguous()), _p(acc), _p(pl), _p(pr), _p(d), _p(m),
+              b, c, h, w, int(ps), -1.0, _stream())
+    return gd
+
+
+_LIB.impl("patch_reproj", _patch_reproj, "CUDA")
+_LIB.impl("patch_reproj", _no_cpu("patch_reproj"), "CPU")
+_LIB.impl("patch_reproj_bwd", _patch_reproj_bwd, "CUDA")
+torch.library.register_fake("azhip::patch_reproj", lambda l, r, d, m, ps: l.new_empty(()))
+torch.library.register_fake("azhip::patch_reproj_bwd", lambda g, l, r, d, m, ps: torch.empty_like(d))
+
+
+def _pr_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], inputs[2], *( [inputs[3]] if inputs[3] is not None else []))
+    ctx.has_mask, ctx.ps = inputs[3] is not None, inputs[4]
+
+
+def _pr_backward(ctx, g):
+    left, right, disp, *m = ctx.saved_tensors
+    gd = torch.ops.azhip.patch_reproj_bwd(g, left, right, disp, m[0] if ctx.has_mask else None, ctx.ps)
+    return None, None, gd, None, None
+
+
+torch.library.register_autograd("azhip::patch_reproj", _pr_backward, setup_context=_pr_setup)

@@ -180,13 +180,26 @@ def cpu_baseline(args):
             "sample": sample, "sample_seconds": dt, "config1": config1}
 
 
-TUNED_EAGER_JSON = os.path.join(REPO, "profiles", "r03_eager_tuned.json")
+TUNED_EAGER_JSON = os.path.join(REPO, "profiles", "r04_eager_tuned.json")
+# MIOpen's user find-db of a `bench.py --eager-tuned` run on this image, committed (round 4): with it the eager legs of a
+# DEFAULT run use the reference's own setting, cudnn.benchmark = True (train.py:38), LIVE -- the find phase reads its
+# results from the db instead of timing every solver for minutes.  The directory is only ever given to MIOpen, i.e. to
+# the eager legs; this library links no MIOpen.
+MIOPEN_DB_DIR = os.path.join(REPO, "profiles", "miopen_db")
+
+
+def _have_miopen_db():
+    return os.path.isdir(MIOPEN_DB_DIR) and any(f.endswith(".txt") or f.endswith(".db") for f in os.listdir(MIOPEN_DB_DIR))
 
 
 def _eager_mode(args):
     """(cudnn.benchmark, warm-up steps, timed steps, label)"""
     if args.eager_tuned:
         return True, 2, max(3, args.eager_steps), "cudnn.benchmark = True as train.py:38 sets it (MIOpen find phase in the warm-up steps)"
+    if _have_miopen_db() and os.environ.get("AZ_BENCH_EAGER_UNTUNED") != "1":
+        return True, 2, max(3, args.eager_steps), ("cudnn.benchmark = True as train.py:38 sets it; MIOpen's find results come from "
+                                                    "the committed user find-db profiles/miopen_db (made by a --eager-tuned run on "
+                                                    "this image), so the tuned solvers run LIVE in this run")
     return False, 1, args.eager_steps, ("UNTUNED MIOpen: cudnn.benchmark off (immediate-mode solvers; the find phase of the 3-D "
                                         "convolutions takes minutes) -- a lower bound of what the reference's configuration reaches; "
                                         "the tuned number is eager_gpu.tuned")
@@ -290,24 +303,62 @@ def eager_stage(args, model, device):
             "ratio": lib / eag}
 
 
+def solo_probe(args, device):
+    """The V0 launch shapes (B x 48 x 136 x 240 voxels, 32 -> 32 channels: the kernels with the most time in the step)
+    timed ALONE, after the timed region: HIP events over 10 launches behind 30 warm-up launches.  The in-step durations of
+    the same scopes are those of kernels sharing the chip with the other stream."""
+    from activezero_amd import conv3d
+    hp = args.height + (-args.height) % 32
+    shape = (args.batch, args.maxdisp // 4, hp // 4, args.width // 4, 32)
+    g = torch.Generator(device=device).manual_seed(5)
+    x = torch.randn(shape, device=device, generator=g)
+    dy = torch.randn(shape, device=device, generator=g) * 1e-4
+    w = torch.randn(32, 32, 3, 3, 3, device=device, generator=g) * 0.05
+    A = conv3d.DEFAULT_ARITH
+    bwd = conv3d.F16X3 if A.bwd16 else A.conv
+    fns = {"conv3d_m0_32_32": lambda: conv3d._conv(x, w, conv3d.CONV_S1, A.conv, stats=True),
+           "dgrad_m0_32_32": lambda: conv3d._input_grad(dy, w, conv3d.CONV_S1, 32, 32, bwd),
+           "conv_wgrad_s1_32_32": lambda: conv3d._weight_grad(x, dy, conv3d.CONV_S1, 32, 32, conv3d.F16X3 if A.bwd16 else A.wgrad)}
+    with torch.no_grad():
+        for _ in range(10):
+            for f in fns.values():
+                f()
+        out = {}
+        for name, f in fns.items():
+            for _ in range(5):
+                f()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(10):
+                f()
+            b.record()
+            torch.cuda.synchronize()
+            out[name] = a.elapsed_time(b) / 10
+    return out
+
+
 def hbm_probe(device):
     """Measured device-to-device copy rate on this box (the second denominator beside the 8 TB/s spec
-    figure): a 1 GiB fp32 tensor, torch's copy kernel, read + write bytes over the median of 5 runs."""
+    figure): a 1 GiB fp32 tensor through this library's float4 grid-stride copy kernel (az_hbm_copy_probe: the stream
+    MI355X_MICROARCH.md quotes 6.29 TB/s for), read + write bytes over the median of 7 runs after a warm-up."""
+    from activezero_amd.ops import _call, _p, _stream
     n = 1 << 28
     x = torch.empty(n, dtype=torch.float32, device=device).normal_()
     y = torch.empty_like(x)
-    y.copy_(x)
+    for _ in range(3):
+        _call("az_hbm_copy_probe", _p(y), _p(x), n, _stream())
     ts = []
-    for _ in range(5):
+    for _ in range(7):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        y.copy_(x)
+        _call("az_hbm_copy_probe", _p(y), _p(x), n, _stream())
         b.record()
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
     ms = sorted(ts)[len(ts) // 2]
-    return {"kind": "device-to-device copy, 1 GiB fp32, read + write", "GB/s": 2.0 * n * 4 / 1e9 / (ms * 1e-3),
-            "spec_GB/s": 8000.0}
+    return {"kind": "float4 grid-stride copy kernel (az_hbm_copy_probe), 1 GiB fp32, read + write",
+            "GB/s": 2.0 * n * 4 / 1e9 / (ms * 1e-3), "spec_GB/s": 8000.0, "guide_GB/s": 6290.0}
 
 
 def raft_workload(args, rank, local_rank, world):
@@ -475,6 +526,12 @@ def main():
         return dry_run(args, rank, world)
     if args.workload == "raft":
         return raft_workload(args, rank, local_rank, world)
+    if _have_miopen_db() or args.eager_tuned:
+        # (before anything initialises MIOpen; read by the eager legs only)
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", MIOPEN_DB_DIR if _have_miopen_db() else os.path.join(REPO, "gpurun_out", "miopen_db"))
+        os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+        if not args.eager_tuned and os.environ.get("AZ_BENCH_EAGER_UNTUNED") != "1":
+            args.eager_batch = args.batch  # the db holds the shapes of the full batch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.single_device:
@@ -595,13 +652,17 @@ def main():
                        "width": args.width, "maxdisp": args.maxdisp,
                        "parallelism": f"dp{world}",
                        "dist_backend": (args.dist_backend + " (RCCL)" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None,
-                       "arithmetic": f"fp32 results; conv/deconv/dgrad MFMA arithmetic {cname}, wgrad {wname} "
-                                     "(bf16x6 = exact 3-way bf16 split, six MFMAs per product), fp32 accumulation "
+                       "arithmetic": f"fp32 results; forward MFMA arithmetic {cname}, input / weight gradients {wname} "
+                                     "(f16x3 = operands scaled by a power of two from the tensor's max |.| and split into "
+                                     "two fp16 parts, three MFMAs per product, where a kernel for the shape exists; "
+                                     "bf16x6 = exact 3-way bf16 split, six MFMAs per product), fp32 accumulation "
                                      "everywhere; every convolution on this library's kernels"},
             "loss": float(loss.item()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
-            "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "r03_pmc_traffic_b4.json"),
-                                          os.path.join(REPO, "profiles", "r03_pmc_clock_b4.json")),
+            "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "r04_pmc_traffic_b4.json"),
+                                          os.path.join(REPO, "profiles", "r04_pmc_clock_b4.json"),
+                                          ms_per_step=1e3 * dt / args.steps, steps=args.steps,
+                                          solo=solo_probe(args, device) if (world == 1 and not mixed) else None),
             "cpu_baseline": None,
             "eager_gpu": None,
             "eager_stage": None,
@@ -631,7 +692,7 @@ def main():
                 os.makedirs(os.path.dirname(TUNED_EAGER_JSON), exist_ok=True)
                 json.dump({"eager_gpu": out["eager_gpu"], "eager_stage": out["eager_stage"],
                            "this_library_pairs_per_s": out["value"], "command": " ".join(sys.argv)},
-                          open(os.path.join(REPO, "gpurun_out", "r03_eager_tuned.json")
+                          open(os.path.join(REPO, "gpurun_out", "r04_eager_tuned.json")
                                if os.path.isdir(os.path.join(REPO, "gpurun_out")) else TUNED_EAGER_JSON, "w"), indent=1)
         if not args.no_cpu_baseline and world == 1:
             note("timing the CPU baseline samples")

@@ -37,6 +37,13 @@ extern "C" {
 const char *az_strerror(int code);
 /* ABI version: bumped when a signature changes. */
 int az_abi_version(void);
+/* the value of one A/B switch as the library read it at its first use (name = the environment variable, e.g.
+ * "AZ_WGRAD_R16"; DESIGN.md lists them): switches are read once per process into one immutable struct.
+ * AZ_EINVAL: no such switch. */
+int az_option(const char *name);
+/* measurement only: dst[0..n) = src[0..n) as a float4 grid-stride stream (n % 4 == 0, 16-byte aligned) -- the copy rate
+ * bench.py reports beside the HBM spec figure */
+int az_hbm_copy_probe(float *dst, const float *src, long long n, void *stream);
 
 /* ---- K1/K2: integer scatter warp ------------------------------------------
  * replaces utils/warp_ops.py:22-45 (CUDA-C apply_disparity_pos/_neg) and the
@@ -224,6 +231,15 @@ int az_conv2d_fwd_stats_f16(float *out, float *partials, float *counts, const fl
                             const float *in_amax, const float *w_amax, int groups, int B, int H, int W,
                             int cin, int cout, int in_cstride, int out_cstride, int kh, int kw, int dilation,
                             void *stream);
+/* plain-bf16 forms for the backward pass of the RAFT-Stereo GRU update in the reference's autocast arithmetic
+ * (nets/raft/raft_stereo.py:142-172, train.py:303-309; forward: az_conv2d_bf16_fwd): the flipped weight image of the
+ * input gradient (call with cin / cout and the two strides swapped) and the 3x3 weight gradient with operands rounded
+ * to bf16 once, one MFMA per block, fp32 accumulation */
+int az_conv2d_pack_weights_bf16_flipped(float *packed, const float *w, int cin, int cout, long long stride_out,
+                                        long long stride_in, int kh, int kw, void *stream);
+int az_conv2d_wgrad_bf16(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                         const float *in, int B, int H, int W, int cm, int cn, int cm_real, int cn_real,
+                         int go_cstride, int in_cstride, void *stream);
 /* az_conv2d_wgrad on f16x3: go_amax / in_amax = amax arrays of grad_out and in */
 int az_conv2d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
                         const float *in, const float *go_amax, const float *in_amax, int B, int H, int W,

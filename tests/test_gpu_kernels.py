@@ -351,3 +351,49 @@ def test_dispatcher_ops_match_the_python_wrappers():
     assert torch.equal(w1, w2)
     w1.sum().backward(); w2.sum().backward()
     assert torch.equal(d1.grad, d2.grad)
+
+
+@pytest.mark.parametrize("mode,cin,cout", [(0, 32, 32), (1, 32, 64), (2, 64, 32)])
+def test_dispatcher_conv3d_bn3d_patch_reproj(mode, cin, cout):
+    """torch.ops.azhip.conv3d / bn3d / patch_reproj: values and registered gradients against torch's own operators in
+    fp64 (conv) and against the Python wrappers (patch reprojection)"""
+    import torch.nn.functional as F
+    import activezero_amd.torch_ops  # noqa: F401
+
+    b, d, h, w = 2, 4, 6, 16
+    x = seeded((b, d, h, w, cin), 911).to(DEV).requires_grad_()
+    wshape = (cin, cout, 3, 3, 3) if mode == 2 else (cout, cin, 3, 3, 3)
+    wt = (0.1 * seeded(wshape, 912)).to(DEV).requires_grad_()
+    y = torch.ops.azhip.conv3d(x, wt, mode)
+    xd = x.detach().double().permute(0, 4, 1, 2, 3).requires_grad_()
+    wd = wt.detach().double().requires_grad_()
+    if mode == 2:
+        yd = F.conv_transpose3d(xd, wd, stride=2, padding=1, output_padding=1)
+    else:
+        yd = F.conv3d(xd, wd, stride=1 + mode, padding=1)
+    ydl = yd.permute(0, 2, 3, 4, 1)
+    assert y.shape == ydl.shape
+    sc_ = float(ydl.abs().max())
+    assert float((y.double() - ydl).abs().max()) <= 3e-6 * sc_
+    # bn3d on top (affine + residual + ReLU) and a backward through both
+    scale, shift = (1.0 + 0.1 * seeded((cout,), 913)).to(DEV).requires_grad_(), (0.1 * seeded((cout,), 914)).to(DEV).requires_grad_()
+    res = seeded(tuple(y.shape), 915).to(DEV).requires_grad_()
+    z = torch.ops.azhip.bn3d(y, scale, shift, res, True)
+    zd = F.relu(ydl * scale.detach().double() + shift.detach().double() + res.detach().double())
+    assert float((z.double() - zd).abs().max()) <= 1e-5 * max(1.0, float(zd.abs().max()))
+    ct = seeded(tuple(z.shape), 916).to(DEV)
+    z.backward(ct)
+    (zd * ct.double()).sum().backward()
+    gx_ref = xd.grad.permute(0, 2, 3, 4, 1)
+    assert float((x.grad.double() - gx_ref).abs().max()) <= 1e-5 * float(gx_ref.abs().max())
+    assert float((wt.grad.double() - wd.grad).abs().max()) <= 1e-5 * float(wd.grad.abs().max())
+    if mode == 0:  # patch reprojection once
+        pl = (seeded((1, 1, 32, 48), 917) > 0.4).float().to(DEV)
+        pr = pl.roll(2, 3).contiguous()
+        dsp = (3.0 * seeded((1, 1, 32, 48), 918).abs()).to(DEV)
+        d1, d2 = dsp.clone().requires_grad_(), dsp.clone().requires_grad_()
+        l1 = torch.ops.azhip.patch_reproj(pl, pr, d1, None, 5)
+        l2 = ops.patch_reprojection(pl, pr, d2, None, 5, want_vis=False)[0]
+        assert torch.equal(l1, l2)
+        l1.backward(); l2.backward()
+        assert torch.allclose(d1.grad, d2.grad, rtol=1e-5, atol=1e-7)

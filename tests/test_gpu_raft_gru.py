@@ -12,6 +12,7 @@ shape sweeps.  Checked besides:
     arithmetic (the same formula under CPU autocast(bfloat16)): ours must not be worse;
   * the autograd path (bf16x6 kernels) against torch fp32, values and gradients.
 """
+import numpy as np
 import pytest
 import torch
 import torch.nn as nn
@@ -105,6 +106,7 @@ def test_gru_autograd_path():
     torch.manual_seed(2)
     ref = _TorchGRU(64, 64)
     mod = ConvGRU(64, 64)
+    mod.train_arithmetic = "bf16x6"  # (the fp32-class route; the default, the reference's autocast arithmetic, is pinned by G12)
     mod.load_state_dict(ref.state_dict())
     mod.cuda()
     hid, ctx, xs = _inputs(1, 64, (64,), 12, 20, seed=9)
@@ -168,11 +170,46 @@ def test_gru_matches_reference_golden(golden, tag, capsys):
     assert e_hip64 <= 2e-2 and e_it <= 4e-2, (e_hip64, e_it)
 
 
-def test_gru_autograd_matches_reference_golden(golden):
-    """the differentiable route (bf16x6 kernels, fp32-class) against the reference's fp32 values and gradients"""
+def test_gru_training_arithmetic_matches_reference_autocast(golden, capsys):
+    """The TRAINING route in the reference's arithmetic (update block under autocast, raft_stereo.py:142-172,
+    train.py:303-309): forward, input gradient and weight gradient with operands rounded to bf16 once.  G12 holds the
+    gradients of the imported class under CPU autocast(bfloat16) and in fp64; e_amp = |g_amp - g64| / |g64| is how far
+    the reference's own 16-bit evaluation sits from the exact gradient (2.5e-3 .. 5.6e-3 here).  This path keeps the
+    gates in fp32, so it must be at least as close to the exact gradient, and within the sum of both distances of the
+    reference's autocast result."""
     from tests._weights import seeded
     g = golden("g12_convgru")
     mod, hid, ctx, xs, lat, (b, hidden, h, w, sd) = _g12_case(g, "d")
+    assert mod.train_arithmetic == "bf16"
+    hg = hid.cuda().requires_grad_(True)
+    out = mod(hg, *[c.cuda() for c in ctx], *[x.cuda() for x in xs])
+    (out * seeded((b, hidden, h, w), sd + 9).cuda()).sum().backward()
+    # value: no further from fp64 than the reference's autocast forward
+    e_out, e_out_amp = abs(lat(out) - g["d_out64"]).max(), abs(g["d_outamp"].astype("f8") - g["d_out64"]).max()
+    assert e_out <= 1.1 * e_out_amp, (e_out, e_out_amp)
+    rel = lambda a, ref: float(np.linalg.norm(a - ref) / np.linalg.norm(ref))
+    rows = [("gh", hg.grad.cpu().double().numpy(), g["d_gh64"], g["d_gh_amp"].astype("f8"))]
+    for name in ("convz", "convr", "convq"):
+        rows.append((name + ".weight", getattr(mod, name).weight.grad.cpu().double().numpy(), g[f"d_gwfull64_{name}"],
+                     g[f"d_gwfull_amp_{name}"].astype("f8")))
+        rows.append((name + ".bias", getattr(mod, name).bias.grad.cpu().double().numpy(), g[f"d_gb64_{name}"],
+                     g[f"d_gb_amp_{name}"].astype("f8")))
+    lines = []
+    for name, got, r64, ramp in rows:
+        e_hip, e_amp, e_cross = rel(got, r64), rel(ramp, r64), rel(got, ramp)
+        lines.append(f"G12 train {name:14s} hip-ref64 {e_hip:.2e}  autocast-ref64 {e_amp:.2e}  hip-autocast {e_cross:.2e}")
+        assert e_hip <= 1.1 * e_amp + 1e-6, lines[-1]
+        assert e_cross <= e_hip + e_amp + 1e-6, lines[-1]
+    with capsys.disabled():
+        print("\n" + "\n".join(lines))
+
+
+def test_gru_autograd_matches_reference_golden(golden):
+    """the fp32-class differentiable route (train_arithmetic = "bf16x6") against the reference's fp32 values and gradients"""
+    from tests._weights import seeded
+    g = golden("g12_convgru")
+    mod, hid, ctx, xs, lat, (b, hidden, h, w, sd) = _g12_case(g, "d")
+    mod.train_arithmetic = "bf16x6"
     hg = hid.cuda().requires_grad_(True)
     out = mod(hg, *[c.cuda() for c in ctx], *[x.cuda() for x in xs])
     (out * seeded((b, hidden, h, w), sd + 9).cuda()).sum().backward()

@@ -1,0 +1,52 @@
+"""Every route that only an A/B switch reaches (DESIGN.md, table "A/B switches") is run through existing parity tests in a
+child process with the switch set: a route that ships is a route that is tested.  The switches are read once per
+process (az_options.h / module import), hence the child processes -- one at a time."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    # (environment, test file, -k expression)
+    ({"AZ_CONV_ROLL": "0"}, "tests/test_gpu_conv3d.py", "convbn3d_golden and bf16x6"),                # V0 layers on az_conv3d_m128.hip
+    ({"AZ_WGRAD_R16": "0"}, "tests/test_gpu_conv3d.py", "residual_relu_train and bf16x6"),             # one-kd-per-wave stride-1 weight gradient
+    ({"AZ_WGRAD_R16": "0", "AZ_WGRAD_FW": "0"}, "tests/test_gpu_conv3d.py", "residual_relu_train and bf16x6"),
+    ({"AZ_WGRAD_R16": "1"}, "tests/test_gpu_conv3d.py", "convbn3d_golden and bf16x6"),
+    ({"AZ_BN_BWD_FUSED": "0"}, "tests/test_gpu_conv3d.py", "convbn3d_golden and f16x3"),               # three-launch BatchNorm backward
+    ({"AZ_BWD_F16": "0"}, "tests/test_gpu_conv3d.py", "convbn3d_golden and bf16x6"),                   # bf16x6 gradients
+    ({"AZ_CONV_MAP": "0"}, "tests/test_gpu_conv3d.py", "conv_stride2_vs_torch"),                       # linear block -> tile map
+    ({"AZ_CONV2D_ROLL": "0"}, "tests/test_gpu_conv2d.py", "same"),                                     # 32/64-channel 3x3 layers on K13
+    ({"AZ_CONV2D_ROLL_NT4": "0"}, "tests/test_gpu_conv2d_roll.py", ""),
+    ({"AZ_CONV2D_WGRAD_R16": "0"}, "tests/test_gpu_conv2d.py", "same"),
+    ({"AZ_CORR_FP32": "1"}, "tests/test_gpu_raft_corr.py", ""),
+    ({"AZ_PATCH_TILED": "0"}, "tests/test_gpu_kernels.py", "patch"),
+    ({"AZ_PATCH_K": "1"}, "tests/test_gpu_kernels.py", "patch"),
+    ({"AZ_WGRAD_R16_WGS": "64", "AZ_ROLL_SEGLEN": "5"}, "tests/test_gpu_conv3d.py", "convbn3d_golden"),
+]
+
+
+@pytest.mark.parametrize("env,path,expr", CASES, ids=[" ".join(f"{k}={v}" for k, v in c[0].items()) for c in CASES])
+def test_route_behind_switch(env, path, expr):
+    cmd = [sys.executable, "-m", "pytest", path, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"]
+    if expr:
+        cmd += ["-k", expr]
+    r = subprocess.run(cmd, cwd=REPO, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, tail
+
+
+def test_switches_are_read_once_into_the_options_struct():
+    """az_option reports what the library holds; changing the environment afterwards changes nothing"""
+    code = ("import os; os.environ['AZ_WGRAD_R16_WGS']='77'; from activezero_amd import _lib; L=_lib.lib(); "
+            "a=L.az_option(b'AZ_WGRAD_R16_WGS'); os.environ['AZ_WGRAD_R16_WGS']='5'; b=L.az_option(b'AZ_WGRAD_R16_WGS'); "
+            "print(a, b, L.az_option(b'AZ_PATCH_K'), L.az_option(b'NOPE'))")
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-800:]
+    a, b, k, nope = r.stdout.split()
+    assert (a, b, k) == ("77", "77", "4") and int(nope) < 0

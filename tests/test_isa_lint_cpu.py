@@ -20,7 +20,8 @@ def test_no_packed_fp32_with_high_src1_selection():
     if not os.path.exists(_lib.LIB_PATH):
         pytest.skip("library not built")
     if not os.path.exists(isa_lint.OBJDUMP):
-        pytest.skip("llvm-objdump not available")
+        pytest.fail(f"{isa_lint.OBJDUMP} is missing although the library is built: the packed-fp32 lint cannot be skipped "
+                    "(a kernel with the form silently corrupts gradients beside MFMA waves, profiles/r03_pkfma_corun.md)")
     bad = isa_lint.risky_packed_ops(_lib.LIB_PATH)
     assert not bad, "\n".join(f"{k}: {i}" for k, i in bad[:20])
 

@@ -40,7 +40,10 @@ def scan_bundle(path):
 
 
 def match_trace(trace, risky):
-    names = sorted({r["Kernel_Name"] for r in csv.DictReader(open(trace)) if "at::native" in r["Kernel_Name"]})
+    if trace.endswith(".txt"):  # one kernel name per line (tools/trace_kernels.sh keeps this instead of the 50 MB csv)
+        names = sorted({l.strip() for l in open(trace) if "at::native" in l})
+    else:
+        names = sorted({r["Kernel_Name"] for r in csv.DictReader(open(trace)) if "at::native" in r["Kernel_Name"]})
     # mangled names spell functor / op names literally: compare on those fragments, and on the scalar type (a
     # float / double kernel of the trace is not its complex / Half / BFloat16 namesake)
     skip = ("anonymous", "namespace", "TensorIteratorBase", "operator")
@@ -62,15 +65,20 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--trace")
     ap.add_argument("--reuse", action="store_true", help="take <out>/risky_kernels.txt from an earlier run")
+    ap.add_argument("--lib", help="scan this shared library's gfx950 code objects instead of libtorch_hip.so (e.g. librccl.so)")
     a = ap.parse_args()
     if a.reuse:
         risky = [l.strip() for l in open(os.path.join(a.out, "risky_kernels.txt")) if l.strip()]
-        return match_trace(a.trace, risky)
+        for t in a.trace.split(","):
+            print("==", t)
+            match_trace(t, risky)
+        return
     import torch
     lib = os.path.join(os.path.dirname(torch.__file__), "lib")
     os.makedirs(a.out, exist_ok=True)
     fat = os.path.join(a.out, "fatbin.bin")
-    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", os.path.join(lib, "libtorch_hip.so"),
+    target_lib = a.lib or os.path.join(lib, "libtorch_hip.so")
+    subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", target_lib,
                     os.path.join(a.out, "discard.so")], check=True)
     os.remove(os.path.join(a.out, "discard.so"))
     blob = open(fat, "rb").read()
@@ -82,8 +90,8 @@ def main():
             open(p, "wb").write(blob[m.start():m.start() + fsize])
             pieces.append(p)
     os.remove(fat)
-    blas = [f for f in glob.glob(os.path.join(lib, "hipblaslt", "library", "TensileLibrary_SS_SS_*gfx950.co"))]
-    print(f"{len(pieces)} bundles in libtorch_hip.so, {len(blas)} fp32 hipBLASLt libraries")
+    blas = [] if a.lib else [f for f in glob.glob(os.path.join(lib, "hipblaslt", "library", "TensileLibrary_SS_SS_*gfx950.co"))]
+    print(f"{len(pieces)} bundles in {os.path.basename(target_lib)}, {len(blas)} fp32 hipBLASLt libraries")
     with ThreadPoolExecutor(6) as ex:
         res_t = list(ex.map(scan_bundle, pieces))
         res_b = list(ex.map(scan_bundle, blas))
@@ -91,11 +99,13 @@ def main():
         os.remove(p)
     risky = sorted({k for _, hits in res_t for k in hits})
     open(os.path.join(a.out, "risky_kernels.txt"), "w").write("\n".join(risky) + "\n")
-    print(f"libtorch_hip.so: {sum(t for t, _ in res_t)} packed-fp32 instructions, {sum(len(h) for _, h in res_t)} in the form, "
+    print(f"{os.path.basename(target_lib)}: {sum(t for t, _ in res_t)} packed-fp32 instructions, {sum(len(h) for _, h in res_t)} in the form, "
           f"in {len(risky)} kernels")
     print(f"hipBLASLt fp32 : {sum(t for t, _ in res_b)} packed-fp32 instructions, {sum(len(h) for _, h in res_b)} in the form")
     if a.trace:
-        match_trace(a.trace, risky)
+        for t in a.trace.split(","):
+            print("==", t)
+            match_trace(t, risky)
 
 if __name__ == "__main__":
     main()

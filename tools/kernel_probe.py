@@ -36,10 +36,10 @@ def main():
     for _ in range(REPS):
         # calibration: y = x*scale + shift  (reads x once, writes y once)
         _call("az_bn3d_apply", _p(y), _p(x), _p(scale), _p(shift), None, 0, x.numel() // C, C, None, _stream())
-        pk, cin, cout = conv3d._pack_forward(w, conv3d.CONV_S1, conv3d.DEFAULT_ARITH.conv)
-        conv3d._run_gather(x, pk, conv3d.CONV_S1, cin, cout, conv3d.DEFAULT_ARITH.conv, stats=True)        # forward + BN partials
-        conv3d._input_grad(g, w, conv3d.CONV_S1, C, C, conv3d.DEFAULT_ARITH.conv)
-        conv3d._wgrad(g, x, 1, C, C, "conv", conv3d.DEFAULT_ARITH.wgrad)
+        A = conv3d.DEFAULT_ARITH  # (round 4: f16x3 forward / input gradient / weight gradient)
+        conv3d._conv(x, w, conv3d.CONV_S1, A.conv, stats=True)                                  # forward + BN partials
+        conv3d._input_grad(g, w, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.conv)
+        conv3d._weight_grad(x, g, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.wgrad)
         torch.cuda.synchronize()
     print("probe done", x.numel() * 4 / 1e6, "MB per tensor")
 

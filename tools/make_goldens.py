@@ -470,6 +470,27 @@ def g12_convgru():
             for name in ("convz", "convr", "convq"):
                 out[f"d_gw_{name}"] = getattr(mod, name).weight.grad[:16, :32]
                 out[f"d_gb_{name}"] = getattr(mod, name).bias.grad
+            # round 4: the same gradients in the reference's TRAINING arithmetic -- the update block under autocast
+            # (raft_stereo.py:142-172, train.py:303-309; bfloat16 on the CPU) -- and in fp64: the distance between the two
+            # is what a valid 16-bit evaluation of these gradients may be off by (whole tensors: the norms matter)
+            mod.zero_grad(set_to_none=True)
+            hr = hid.clone().requires_grad_(True)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                o = mod(hr, *ctx, *xs)
+            (o.float() * cot).sum().backward()
+            out["d_gh_amp"] = hr.grad.float()
+            for name in ("convz", "convr", "convq"):
+                out[f"d_gwfull_amp_{name}"] = getattr(mod, name).weight.grad.float()
+                out[f"d_gb_amp_{name}"] = getattr(mod, name).bias.grad.float()
+            mod.zero_grad(set_to_none=True)
+            mod.double()
+            hr = hid.double().requires_grad_(True)
+            (mod(hr, *[c.double() for c in ctx], *[x.double() for x in xs]) * cot.double()).sum().backward()
+            out["d_gh64"] = hr.grad
+            for name in ("convz", "convr", "convq"):
+                out[f"d_gwfull64_{name}"] = getattr(mod, name).weight.grad
+                out[f"d_gb64_{name}"] = getattr(mod, name).bias.grad
+            mod.float()
     save("g12_convgru", **out)
 
 
