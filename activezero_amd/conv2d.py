@@ -250,7 +250,12 @@ def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=Non
     return gw
 
 
+_OVERLAP_2D = os.environ.get("AZ_2D_WGRAD_OVERLAP", "1") != "0"  # (scheduling experiment, tools/sched_ab.sh)
+
+
 def _leaf_sink(sink, weight):
+    if not _OVERLAP_2D:
+        return None
     """A sink lets a weight gradient be handed to autograd before its kernel has run; that is only sound when
     the next reader is the pass's own gate node (overlap.py), i.e. when `weight` is one of the sink's gated
     parameters -- not for derived tensors such as the merged kernels of the cost-volume convolution."""

@@ -20,25 +20,29 @@ extern "C" int az_abi_version(void) { return 5; }
 // Measurement only (bench.py roofline.measured_hbm; SURVEY.md 8d's second denominator beside the 8 TB/s spec figure): a
 // float4 grid-stride copy, 16 bytes per lane per access -- the stream MI355X_MICROARCH.md quotes 6.29 TB/s for.
 typedef float az_v4 __attribute__((ext_vector_type(4)));
+// variant 0: one float4 per thread, one block per 4 KB (no loop: the dispatcher keeps every CU supplied with short blocks);
+// variant 1: 4096 blocks, grid-stride loop (the form of this library's streaming kernels)
+template <int LOOP>
 __global__ void __launch_bounds__(256)
 hbm_copy_kernel(az_v4 *__restrict__ dst, const az_v4 *__restrict__ src, long long n4) {
-    // four 16-byte loads in flight per lane, streaming (nontemporal) in both directions
-    const long long stride = (long long)gridDim.x * 256;
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const az_v4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const az_v4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    if (!LOOP) {
+        if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+        return;
     }
-    for (; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    for (; i < n4; i += (long long)gridDim.x * 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 extern "C" int az_hbm_copy_probe(float *dst, const float *src, long long n, void *stream) {
     AZ_REQUIRE_PTR(dst); AZ_REQUIRE_PTR(src);
     AZ_REQUIRE(n > 0 && n % 4 == 0);
     if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) return AZ_EINVAL;
-    hipLaunchKernelGGL(hbm_copy_kernel, dim3(256 * 8), dim3(256), 0, az_stream(stream), reinterpret_cast<az_v4 *>(dst),
-                       reinterpret_cast<const az_v4 *>(src), n / 4);
+    const long long n4 = n / 4, blocks = (n4 + 255) / 256;
+    if (blocks <= 0x7fffffffLL)
+        hipLaunchKernelGGL(hbm_copy_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, az_stream(stream), reinterpret_cast<az_v4 *>(dst),
+                           reinterpret_cast<const az_v4 *>(src), n4);
+    else
+        hipLaunchKernelGGL(hbm_copy_kernel<1>, dim3(4096), dim3(256), 0, az_stream(stream), reinterpret_cast<az_v4 *>(dst),
+                           reinterpret_cast<const az_v4 *>(src), n4);
     return az_launch_status();
 }
 

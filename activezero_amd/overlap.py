@@ -57,6 +57,9 @@ _STREAMS_LOCK = threading.Lock()
 # HIP priority of the side stream (read once): larger = lower.  The backward pass's critical chain is the MAIN stream
 # (input gradients and BatchNorm backward); the weight gradients have slack until the join at the end.
 _SIDE_PRIORITY = int(os.environ.get("AZ_SIDE_PRIORITY", "0"))
+# AZ_SIDE_KEEP=1 (A/B, read once): round 3's protection of side-stream operands -- Python references held until the join
+# -- instead of Tensor.record_stream
+_KEEP_UNTIL_JOIN = os.environ.get("AZ_SIDE_KEEP", "0") == "1"
 
 
 def side_stream(device):
@@ -191,9 +194,12 @@ class scope:
             # stream has passed the point of the free.  Round 3 kept Python references until the join instead, so the
             # operands of every layer (x, dy: 0.2-0.8 GB each at V0) stayed allocated until the end of backward and the
             # peak grew with depth; now each is released as soon as autograd drops it and its kernel has run.
-            for t in self.operands:
-                if t is not None:
-                    t.record_stream(sink.stream)
+            if _KEEP_UNTIL_JOIN:
+                sink.keep.extend(t for t in self.operands if t is not None)
+            else:
+                for t in self.operands:
+                    if t is not None:
+                        t.record_stream(sink.stream)
             sink.stream.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(sink.stream)
             self.ctx.__enter__()

@@ -76,6 +76,8 @@ _PMC_NAMES = {"conv3d_m0_32_32": ("conv3d_roll_kernel<32, 1, 1>", "conv3d_roll_k
                                   "conv3d_m128_kernel<32, 1, 0>"),
               "dgrad_m0_32_32": ("conv3d_roll_kernel<32, 0, 1>", "conv3d_roll_kernel<32, 0, 0>", "conv3d_roll_kernel<32, 0>",
                                  "conv3d_roll_kernel<32, 2>", "conv3d_m128_kernel<32, 0, 0>"),
+              # (a scope of several launches: a tuple of tuples -- the launches' bytes are summed)
+              "bn3d_bwd_32": (("bn_bwd_reduce_kernel<32, true>",), ("bn_bwd_apply_kernel<32, true>",)),
               "conv_wgrad_s1_32_32": ("conv3d_wgrad_r16_kernel<1>", "conv3d_wgrad_r16_kernel<0>", "conv3d_wgrad_r16_kernel",
                                       "conv3d_wgrad_x6_kernel<32, 32, 1>", "conv3d_wgrad_kernel<32, 32, 1>")}
 
@@ -91,11 +93,22 @@ def pmc_traffic(scope_name, per_launch_work, pmc_json):
     if not os.path.exists(pmc_json) or scope_name not in _PMC_NAMES:
         return None
     data = json.load(open(pmc_json))
-    k = None
-    for sym in _PMC_NAMES[scope_name]:
-        k = k or data["kernels"].get(sym)
-    probe_flops = 2.0 * 27 * 32 * 32 * data["tensor_bytes"] / (4 * 32)
-    if not k or abs(probe_flops - per_launch_work) > 1e-6 * probe_flops:
+    syms = _PMC_NAMES[scope_name]
+    if syms and isinstance(syms[0], tuple):  # several launches per scope (BatchNorm backward: reduce + apply)
+        parts = []
+        for alts in syms:
+            hit = next((data["kernels"][a] for a in alts if a in data["kernels"]), None)
+            if hit is None:
+                return None
+            parts.append(hit)
+        k = {f: sum(p[f] for p in parts) for f in ("hbm_bytes", "read_bytes", "write_bytes")}
+        probe_work = 5.0 * data["tensor_bytes"]  # five tensor passes: (dy, raw) twice in, dx out
+    else:
+        k = None
+        for sym in syms:
+            k = k or data["kernels"].get(sym)
+        probe_work = 2.0 * 27 * 32 * 32 * data["tensor_bytes"] / (4 * 32)
+    if not k or abs(probe_work - per_launch_work) > 1e-6 * probe_work:
         return None
     return {"hbm_bytes": k["hbm_bytes"], "read_bytes": k["read_bytes"], "write_bytes": k["write_bytes"],
             "carried_from": "profiles/" + os.path.basename(pmc_json),

@@ -68,6 +68,9 @@ def parse():
                     help="CPU rehearsal of the N-rank launch path (rendezvous, assertions, sharded synthetic data, DDP "
                          "wrap, barrier + max-over-ranks timing, the JSON line) with a small stand-in model and "
                          "--dist-backend gloo: no GPU is touched, `value` is NOT a measurement (tests/test_bench_dryrun_cpu.py)")
+    ap.add_argument("--no-solo-probe", action="store_true",
+                    help="skip the stand-alone timing of the V0 launch shapes and the HBM copy probe after the timed region "
+                         "(kernel traces of the step: tools/trace_step.sh)")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="A/B: weight-gradient kernels in order on the main stream (activezero_amd/overlap.py)")
     return ap.parse_args()
@@ -319,6 +322,16 @@ def solo_probe(args, device):
     fns = {"conv3d_m0_32_32": lambda: conv3d._conv(x, w, conv3d.CONV_S1, A.conv, stats=True),
            "dgrad_m0_32_32": lambda: conv3d._input_grad(dy, w, conv3d.CONV_S1, 32, 32, bwd),
            "conv_wgrad_s1_32_32": lambda: conv3d._weight_grad(x, dy, conv3d.CONV_S1, 32, 32, conv3d.F16X3 if A.bwd16 else A.wgrad)}
+    # BatchNorm backward of a V0 tensor (reduce + apply, ReLU mask recomputed from raw, max |dx| taken): scope bn3d_bwd_32
+    from activezero_amd import _lib
+    from activezero_amd.ops import _call, _p, _stream
+    nv = x.numel() // 32
+    wsb = _lib.lib().az_bn3d_bwd_workspace(nv, 32)
+    ws, dx = torch.empty(wsb // 4, device=device), torch.empty_like(x)
+    cvec = [torch.ones(32, device=device) for _ in range(3)] + [torch.zeros(32, device=device)]
+    small = [torch.empty(32, device=device), torch.empty(32, device=device), torch.empty(32, 3, device=device), torch.zeros(1024, device=device)]
+    fns["bn3d_bwd_32"] = lambda: _call("az_bn3d_bwd", _p(dx), None, _p(small[0]), _p(small[1]), _p(small[2]), _p(ws), wsb, _p(dy), None,
+                                       _p(x), _p(cvec[3]), _p(cvec[0]), _p(cvec[1]), _p(cvec[2]), _p(cvec[3]), 1, nv, 32, _p(small[3]), _stream())
     with torch.no_grad():
         for _ in range(10):
             for f in fns.values():
@@ -662,14 +675,14 @@ def main():
             "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "r04_pmc_traffic_b4.json"),
                                           os.path.join(REPO, "profiles", "r04_pmc_clock_b4.json"),
                                           ms_per_step=1e3 * dt / args.steps, steps=args.steps,
-                                          solo=solo_probe(args, device) if (world == 1 and not mixed) else None),
+                                          solo=solo_probe(args, device) if (world == 1 and not mixed and not args.no_solo_probe) else None),
             "cpu_baseline": None,
             "eager_gpu": None,
             "eager_stage": None,
             "vs_baseline_basis": "null: BASELINE.md publishes no number for this metric; the PyTorch-eager legs "
                                  "(eager_gpu, eager_stage) are reported comparisons, not the baseline",
         }
-        if out["roofline"] is not None:
+        if out["roofline"] is not None and not args.no_solo_probe:
             out["roofline"]["measured_hbm"] = hbm_probe(device)
         if world == 1 and not mixed and args.eager_steps > 0:
             note(f"{1e3 * dt / args.steps:.1f} ms/step; timing the PyTorch-eager step on the GPU")

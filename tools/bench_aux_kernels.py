@@ -81,6 +81,26 @@ xv = torch.randn(B, d, h, w, C, device=dev)
 yv = torch.empty_like(xv)
 sc, sh = torch.ones(C, device=dev), torch.zeros(C, device=dev)
 row("`az_bn3d_apply` (V0, 32 ch)", timeit(lambda: ops._call("az_bn3d_apply", yv.data_ptr(), xv.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, 1, xv.numel() // C, C, None, ops._stream())), 8.0 * xv.numel())
+# BatchNorm backward of the same tensor (five tensor passes: 2 x (dy, raw) in, dx out) with max |dx| taken on the way
+from activezero_amd import _lib  # noqa: E402
+gy, raw = torch.randn_like(xv), torch.randn_like(xv)
+nv = xv.numel() // C
+mean, invstd, gamma = torch.zeros(C, device=dev), torch.ones(C, device=dev), torch.ones(C, device=dev)
+dgm, dbt, coef, dxa = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, 3, device=dev), torch.zeros(1024, device=dev)
+wsb = _lib.lib().az_bn3d_bwd_workspace(nv, C)
+wsp = torch.empty(wsb // 4, device=dev)
+row("`az_bn3d_bwd` (V0, 32 ch, ReLU mask recomputed, amax out)", timeit(lambda: ops._call(
+    "az_bn3d_bwd", yv.data_ptr(), None, dgm.data_ptr(), dbt.data_ptr(), coef.data_ptr(), wsp.data_ptr(), wsb, gy.data_ptr(), None,
+    raw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), 1, nv, C, dxa.data_ptr(),
+    ops._stream())), 20.0 * xv.numel(), "reduce + apply (partials merged in the apply prologue)")
+row("`az_absmax` (V0, 32 ch)", timeit(lambda: ops._call("az_absmax", dxa.data_ptr(), xv.data_ptr(), xv.numel(), ops._stream())), 4.0 * xv.numel(), "the stand-alone amax pass (f16x3 operand scale) where no producer kernel took it")
+row("`az_hbm_copy_probe` (float4 copy, 0.8 GB)", timeit(lambda: ops._call("az_hbm_copy_probe", yv.data_ptr(), xv.data_ptr(), xv.numel(), ops._stream())), 8.0 * xv.numel(), "bench.py's measured_hbm kernel")
+# 32 -> 1 classifier convolution (VALU kernels)
+wc = torch.randn(1, C, 3, 3, 3, device=dev) * 0.05
+lo = torch.empty(B, d, h, w, device=dev); gxc = torch.empty_like(xv); gwc = torch.empty_like(wc)
+row("K4c `az_conv3d_c1_fwd`", timeit(lambda: ops._call("az_conv3d_c1_fwd", lo.data_ptr(), xv.data_ptr(), wc.data_ptr(), None, None, None, B, d, h, w, ops._stream())), 4.0 * (xv.numel() + lo.numel()))
+row("K4c `az_conv3d_c1_dgrad`", timeit(lambda: ops._call("az_conv3d_c1_dgrad", gxc.data_ptr(), lo.data_ptr(), wc.data_ptr(), B, d, h, w, ops._stream())), 4.0 * (xv.numel() + lo.numel()))
+row("K4c `az_conv3d_c1_wgrad`", timeit(lambda: ops._call("az_conv3d_c1_wgrad", gwc.data_ptr(), xv.data_ptr(), lo.data_ptr(), None, None, B, d, h, w, ops._stream())), 4.0 * (xv.numel() + lo.numel()))
 # K10/K11 RAFT
 f1, f2 = torch.randn(B, 256, h, w, device=dev), torch.randn(B, 256, h, w, device=dev)
 ms = timeit(lambda: CorrBlock1D(f1, f2), reps=5)

@@ -58,6 +58,16 @@ def match_trace(trace, risky):
     print(f"{len(names)} ATen kernels in the trace; candidates among the kernels with the form (same op names, same scalar class): {len(bad)}")
     for n, k in bad:
         print("   ", n[:170], "\n        ~", k[:170])
+    # exact comparison of the full demangled names (the fragment matcher above over-reports: `tanh` matches `atanh`, a
+    # float multi_tensor_apply<multiplies> matches its complex / power_functor namesakes)
+    dem = subprocess.run(["c++filt"], input="\n".join(risky), capture_output=True, text=True).stdout.splitlines()
+    norm = lambda t: re.sub(r"\s+", "", t.replace(" [clone .kd]", "")).replace("(anonymousnamespace)", "{anon}")
+    rset = {norm(d) for d in dem}
+    allnames = [l.strip() for l in open(trace)] if trace.endswith(".txt") else names
+    exact = [n for n in allnames if n and norm(n) in rset]
+    print(f"exact demangled-name matches among ALL {len(allnames)} kernels of the trace: {len(exact)}")
+    for n in exact:
+        print("    EXACT", n[:200])
 
 
 def main():

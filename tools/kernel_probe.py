@@ -40,6 +40,14 @@ def main():
         conv3d._conv(x, w, conv3d.CONV_S1, A.conv, stats=True)                                  # forward + BN partials
         conv3d._input_grad(g, w, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.conv)
         conv3d._weight_grad(x, g, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.wgrad)
+        # BatchNorm backward of the same tensor (reduce + apply; ReLU mask recomputed from raw; max |dx| taken on the way)
+        from activezero_amd import _lib
+        nv = x.numel() // C
+        wsb = _lib.lib().az_bn3d_bwd_workspace(nv, C)
+        ws = torch.empty(wsb // 4, device=dev)
+        dgm, dbt, coef, am = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, 3, device=dev), torch.zeros(1024, device=dev)
+        _call("az_bn3d_bwd", _p(y), None, _p(dgm), _p(dbt), _p(coef), _p(ws), wsb, _p(g), None, _p(x), _p(shift), _p(scale),
+              _p(scale), _p(scale), _p(shift), 1, nv, C, _p(am), _stream())
         torch.cuda.synchronize()
     print("probe done", x.numel() * 4 / 1e6, "MB per tensor")
 

@@ -7,3 +7,5 @@ echo "== both"; AZ_BENCH_HP=1 AZ_WGRAD_R16_WGS=256 run
 echo "== high priority + 128 workgroups"; AZ_BENCH_HP=1 AZ_WGRAD_R16_WGS=128 run
 echo "== no overlap"; timeout -k 10 200 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --eager-steps 0 --no-stage-bench --no-wgrad-overlap 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.2f ms/step' % d['ms_per_step'])"
 echo "== default again"; run
+echo "== 2-D weight gradients in order on the main stream (3-D ones still on the side stream)"; AZ_2D_WGRAD_OVERLAP=0 run
+echo "== default once more"; run
