@@ -651,6 +651,10 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
 int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s,
                                const float *coarse_amax = nullptr, const float *fine_amax = nullptr);
 
+// stride 2, f16x3: eight waves sharing one staged set (az_conv3d_wgrad16s2.hip)
+int az_conv3d_wgrad_s2r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int Dc, int Hc, int Wc,
+                                 int Df, int Hf, int Wf, hipStream_t s, const float *coarse_amax, const float *fine_amax);
+
 extern "C" long long az_conv3d_wgrad_workspace(int cm, int cn) {
     if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32) return AZ_EINVAL;
     return 27LL * cm * cn * (long long)sizeof(float);
@@ -720,7 +724,9 @@ extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long wo
     int rc = AZ_EUNSUPPORTED;
     if (stride == 1 && Dc == Df && Hc == Hf && Wc == Wf)  // all 27 taps per wave on 16x16x32 tiles (az_conv3d_wgrad16.hip)
         rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s, coarse_amax, fine_amax);
-    if (rc == AZ_EUNSUPPORTED) {  // stride 2, or a batch element beyond that kernel's 32-bit offsets: one kd per wave
+    else if (stride == 2 && az_options().wgrad_s2r16)
+        rc = az_conv3d_wgrad_s2r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, Df, Hf, Wf, s, coarse_amax, fine_amax);
+    if (rc == AZ_EUNSUPPORTED) {  // shapes / sizes those kernels do not take (e.g. a batch element beyond 32-bit offsets): one kd per wave
         WgArgs a{};
         a.coarse = coarse; a.fine = fine; a.ws = workspace; a.coarse_amax = coarse_amax; a.fine_amax = fine_amax;
         a.B = B; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.Df = Df; a.Hf = Hf; a.Wf = Wf;

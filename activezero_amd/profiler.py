@@ -163,7 +163,7 @@ def roofline(prof, pmc_json=None, clock_json=None, ms_per_step=None, steps=1, so
            "top_kernel_by_time": name, "top_kernel_frac_in_step": achieved / peak,
            "top_kernel_ms_in_step": r["avg_ms"], "top_kernel_launches_per_step": r["launches"] / max(steps, 1),
            "top_kernel_frac_solo": None, "top_kernel_ms_solo": None,
-           "traffic": pmc_traffic(name, r["flops"], pmc_json) if pmc_json else None,
+           "traffic": pmc_traffic(name, r["flops"] if r["bound"] == "mfma" else r["bytes"], pmc_json) if pmc_json else None,
            "held_clock": held_clock(name, clock_json),
            "avg_launch_ms": r["avg_ms"], "launches_timed": r["launches"],
            "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],

@@ -240,3 +240,34 @@ def test_convbn_eval_mode_backward_vs_oracle(arith):
     close(unit[1].weight.grad, ref_unit[1].weight.grad, 1e-3, 1e-3)
     close(unit[1].bias.grad, ref_unit[1].bias.grad, 1e-3, 1e-3)
     assert int(unit[1].num_batches_tracked) == 0
+
+
+# Stride-2 weight gradients (conv1 / conv3 / conv5 / conv6 of an hourglass) against torch's fp64 gradient.  The f16x3 route of
+# the 64-channel-coarse shapes is az_conv3d_wgrad16s2.hip: 4 coarse rows x 8 positions per step, one workgroup per CU walking
+# several columns -- shapes with ragged rows / chunks, odd fine sizes, one row, and more columns than workgroups.
+@pytest.mark.parametrize("kind,cin,cout", [("conv", 32, 64), ("conv", 64, 64), ("deconv", 64, 32), ("deconv", 64, 64), ("conv", 32, 32)])
+@pytest.mark.parametrize("fine_dims", [(1, 4, 8, 16), (2, 6, 10, 36), (1, 3, 7, 13), (1, 2, 2, 50), (2, 24, 12, 192), (1, 5, 34, 20)])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "fp32"])
+def test_weight_grad_stride2_vs_torch(kind, cin, cout, fine_dims, prec):
+    precision = {"f16x3": conv3d.F16X3, "bf16x6": conv3d.BF16X6, "fp32": conv3d.FP32}[prec]
+    if prec != "f16x3" and fine_dims[2] > 10 and fine_dims != (1, 5, 34, 20):
+        pytest.skip("the large multi-column shape is there for the f16x3 kernel's column walk")
+    b, df, hf, wf = fine_dims
+    dc, hc, wc = (df + 1) // 2, (hf + 1) // 2, (wf + 1) // 2
+    if kind == "conv":
+        x = seeded((b, cin, df, hf, wf), 31).double().requires_grad_(False)
+        w = seeded((cout, cin, 3, 3, 3), 32, -0.2, 0.2).double().requires_grad_(True)
+        dy = seeded((b, cout, dc, hc, wc), 33)
+        F.conv3d(x, w, stride=2, padding=1).backward(dy.double())
+        got = conv3d._weight_grad(cl(x.float()), cl(dy), conv3d.CONV_S2, cin, cout, precision)
+    else:
+        if df % 2 or hf % 2 or wf % 2:
+            pytest.skip("output_padding = 1 always gives even fine sizes")
+        x = seeded((b, cin, dc, hc, wc), 34).double()
+        w = seeded((cin, cout, 3, 3, 3), 35, -0.2, 0.2).double().requires_grad_(True)
+        dy = seeded((b, cout, df, hf, wf), 36)
+        F.conv_transpose3d(x, w, stride=2, padding=1, output_padding=1).backward(dy.double())
+        got = conv3d._weight_grad(cl(x.float()), cl(dy), conv3d.DECONV_S2, cin, cout, precision)
+    ref = w.grad
+    err = (got.detach().cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * ref.abs().max().item() + 1e-6, err

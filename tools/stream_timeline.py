@@ -50,3 +50,22 @@ if side:
         if last is not None and k[0] > last: gaps += k[0] - last
         last = max(last or 0, k[1])
     print("main stream idle gaps over the step: %.2f ms" % (gaps / 1e6))
+
+# ---- the step in 3-ms buckets: busy time of the main and the side stream, and who is running -----------------------------
+if side:
+    w = 3e6
+    print("\n  t ms   main  side   main stream: top families (ms)  |  side stream")
+    sk_all = [k for s in side for k in by[s]]
+    t = t0
+    while t < t1:
+        def inside(kk):
+            c = collections.Counter()
+            for k in kk:
+                o = min(k[1], t + w) - max(k[0], t)
+                if o > 0:
+                    c[k[2].replace("void ", "").split("(")[0][:34]] += o / 1e6
+            return c
+        fm, fs = inside(by[main]), inside(sk_all)
+        print("%6.1f  %5.2f %5.2f   %s  |  %s" % ((t - t0) / 1e6, sum(fm.values()), sum(fs.values()),
+              ", ".join("%s %.2f" % nv for nv in fm.most_common(3)), ", ".join("%s %.2f" % nv for nv in fs.most_common(2))))
+        t += w
