@@ -11,8 +11,13 @@
 // staging, not for the matrix pipe.  A stride-2 layer has the fine tensor of a V0 layer behind a quarter of the flops
 // (every fine voxel meets 27/8 taps on average instead of 27), so the staging has to be shared as widely as possible and
 // hidden completely.  This kernel is az_conv3d_wgrad16.hip's design turned to that:
-//   * a workgroup of EIGHT waves owns a 64 x 32 (coarse channel, fine channel) tile of all 27 taps: each wave a 16 x 16 block
-//     (108 accumulator registers) on v_mfma_f32_16x16x32_f16; every staged byte is shared by eight waves;
+//   * a workgroup of EIGHT waves owns a 64 x 32 (coarse channel, fine channel) tile of all 27 taps on
+//     v_mfma_f32_16x16x32_f16: a wave takes SEVEN taps (a quarter of the 27, the last quarter one dummy) of a 64 x 16 block
+//     (112 accumulator registers), so a fine fragment read from LDS feeds four M blocks: twelve MFMAs per four transposing
+//     reads.  The first version gave a wave a 16 x 16 block of all 27 taps, the layout of az_conv3d_wgrad16.hip: every fine
+//     fragment was read four times over and the kernel was bound by LDS read bandwidth (112 reads x 512 B per wave and
+//     step against 81 MFMAs: 3 450 LDS cycles per step and CU against 2 600 matrix cycles per SIMD; 0.35 ms); every staged
+//     byte is shared by all eight waves;
 //   * K = 32 positions per MFMA = 4 coarse rows x 8 positions (V1: 68 x 120 and V2: 34 x 60 tile with at most half a
 //     chunk of padding); a step needs the 9-row window of three fine planes, 17 fine positions wide, of which 8 rows are
 //     new.  A fine row is kept in LDS as two images -- odd and even positions -- so that tap kw reads 8 CONSECUTIVE rows of
@@ -20,7 +25,12 @@
 //   * each plane keeps a ring of 17 fine rows (9 being read + 8 being written), the coarse chunk is double-buffered: one
 //     barrier per step; loads, zero padding and therefore vmcnt bookkeeping go through buffer instructions with
 //     out-of-range offsets (a step is one basic block); the set of step s+2 is requested in two halves while step s is
-//     multiplied, the set of step s+1 is split and written one piece every second tap;
+//     multiplied, the set of step s+1 is split and written two pieces per tap;
+//   * timing-only ablations (S2_ABL, tools/abl_wgrad_s2.sh; conv1's weight gradient, 0.37 ms on that box): no split / LDS
+//     writes 0.21, no MFMAs 0.24, no fine-fragment reads 0.38, every column on the same addresses (L2 hits) 0.34, no
+//     flush 0.35 -- the matrix work and the staging VALU work of a step add up instead of overlapping (HBM: 1.0-1.1 GB read for
+//     1.0 GB of operands).  Tried without effect: the request for step s+2 right behind each split pair instead of in two
+//     halves; the two waves of a SIMD staging behind different halves of the taps (two copies of the walk);
 //   * one workgroup per CU (127 KB of LDS), persistent over a list of (batch, coarse depth, 8-position chunk) columns,
 //     one atomic flush at the end into the tap-major workspace of az_conv3d_wgrad.hip.
 // Bank conflicts of the transposing reads: the two octets of a 32-lane half read fine rows two apart; the 32-byte channel
@@ -49,6 +59,9 @@ typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 #define S2_NFQ (3 * 8 * S2_FROWQ)                   // fine pieces per step: 3 264
 #define S2_NLD 8                                    // pieces per thread and step: 1 coarse + 7 fine (the last one partial)
 #define S2_OOB 0xffffff00u
+#ifndef S2_ABL
+#define S2_ABL 0  // timing-only ablations (tools/abl_wgrad_s2.sh): 1 no global loads, 2 no split / LDS writes, 4 no fine-fragment reads, 8 no MFMAs, 16 no flush, 32 every column loads the same addresses (L2 hits)
+#endif
 
 struct Wg16s2Args {
     const float *coarse, *fine;
@@ -67,16 +80,19 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
     unsigned char *const fring = lds + S2_FBASE;   // [plane kd][slot][S2_FROW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mi = wv >> 1, ni = wv & 1;
+    const int tq4 = wv >> 1, ni = wv & 1;  // a wave: taps 7 tq4 .. 7 tq4 + 6, all 64 coarse x 16 fine channels
+    const int tap0 = 7 * tq4;
     // workgroups b and b + 8 share an XCD: each XCD walks a contiguous run of columns (neighbouring depths of one chunk read
     // the same odd fine planes: one L2 serves both)
     const int tile = blockIdx.x / a.wgs, wgl = blockIdx.x - tile * a.wgs;
     const int wg0 = (a.wgs & 7) ? wgl : az_xcd_map(wgl, a.wgs);
     const int n0 = tile * 32;
 
-    f32x4 acc[27];
+    f32x4 acc[7][4];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[t][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax));
     const int kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
     const float c_scale = az_pow2(kc), f_scale = az_pow2(kf), o_scale = ldexpf(1.f, -(kc + kf));
@@ -85,16 +101,10 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
     // octet = one coarse row of the step; lane 4q + p supplies the address of k-row q (position q, then q + 4), channels
     // 4p..4p+3, and receives channel (lane & 15)
     const int oct = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    const unsigned a_lane = (unsigned)(mi >> 1) * S2_CIMG + (unsigned)(8 * oct + tq) * S2_ROWB +
-                            (((unsigned)(16 * (mi & 1) + 4 * tp) * 2) ^ ((unsigned)(oct & 1) << 5));
-    unsigned b_off[3][2];  // tap kw -> first LDS row of its image: odd image row 0, even image row 9, odd image row 1
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const unsigned rowi = (unsigned)((kw == 0 ? 0 : kw == 1 ? 9 : 1) + tq + 4 * h2);
-            b_off[kw][h2] = rowi * S2_ROWB + (((unsigned)(16 * ni + 4 * tp) * 2) ^ ((unsigned)(oct & 1) << 5));
-        }
+    // M block mb of the coarse chunk: image half mb >> 1, 16-channel group mb & 1 (= the other 32-byte half: ^ 32)
+    const unsigned a_lane = (unsigned)(8 * oct + tq) * S2_ROWB + (((unsigned)(4 * tp) * 2) ^ ((unsigned)(oct & 1) << 5));
+    // fine: tap kw starts at LDS row 0 (odd image), 9 (even image), 1 (odd image, one further) of a staged row
+    const unsigned b_lane = (unsigned)tq * S2_ROWB + (((unsigned)(16 * ni + 4 * tp) * 2) ^ ((unsigned)(oct & 1) << 5));
 
     auto frag2 = [&](const unsigned char *lo, const unsigned char *hi) -> az_f16x8 {  // k rows 0..3 at lo, 4..7 at hi
         const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lo));
@@ -152,14 +162,16 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
             colok |= (ok ? 1u : 0u) << (i + 1);
         }
         // (unsigned arithmetic: the base may lie "before" the tensor, base + rel of a valid piece never does)
-        const unsigned gbase_f = (unsigned)(2 * cd - 1) * plane_f + (unsigned)(2 * cw0 - 1) * vb_f;
-        const unsigned gbase_c = (unsigned)cd * plane_c + (unsigned)cw0 * vb_c;
+        const unsigned gbase_f = (S2_ABL & 32) ? plane_f + 15u * vb_f : (unsigned)(2 * cd - 1) * plane_f + (unsigned)(2 * cw0 - 1) * vb_f;
+        const unsigned gbase_c = (S2_ABL & 32) ? plane_c + 8u * vb_c : (unsigned)cd * plane_c + (unsigned)cw0 * vb_c;
 
         u32x4 pre[S2_NLD];
+        const bool s_abl_first = col == wg0;
         auto issue = [&](int crow0, int frow0, int it0, int it1) {  // coarse rows crow0..+3, fine rows frow0..+7 (frow0 >= 0)
 #pragma unroll
             for (int it = it0; it < it1; ++it) {
                 unsigned off = S2_OOB;
+                if (S2_ABL & 1) { if (s_abl_first) pre[it] = u32x4{1u, 2u, 3u, 4u}; continue; }
                 if (it == 0) {
                     if ((colok & 1u) && crow0 + (int)((tid >> 4) >> 3) < a.Hc)
                         off = gbase_c + (unsigned)crow0 * (unsigned)a.Wc * vb_c + relc_g;
@@ -173,6 +185,7 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
             }
         };
         auto commit_piece = [&](int it, int cbuf_idx, int frow0) {
+            if (S2_ABL & 2) return;
             float4 v = __builtin_bit_cast(float4, pre[it]);
             const float sc_ = it == 0 ? c_scale : f_scale;
             v.x *= sc_; v.y *= sc_; v.z *= sc_; v.w *= sc_;
@@ -207,62 +220,74 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
         __syncthreads();
 
         for (int s = 0; s < nsteps; ++s) {
-            const unsigned char *ca = cbuf + (s & 1) * S2_CBUF + a_lane;
-            // ring slot of this lane's fine row 8s + 2 oct - 1 + kh: (8s + 2 oct + kh) mod 17
-            const int sb = (8 * s) % S2_RING;
-            unsigned fb[3];
+            const int sb = (8 * s) % S2_RING;  // ring slot of this lane's fine row 8s + 2 oct - 1 + kh: (8s + 2 oct + kh) mod 17
+            az_f16x8 af[4][2];  // [M block][part]
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                int v = sb + 2 * oct + kh;
-                v = v >= S2_RING ? v - S2_RING : v;
-                fb[kh] = (unsigned)v * S2_FROW;
-            }
-            az_f16x8 af[2];
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) af[p] = frag2(ca + p * 2 * S2_CIMG, ca + p * 2 * S2_CIMG + 4 * S2_ROWB);
+                for (int p = 0; p < 2; ++p) {
+                    const unsigned char *cm = cbuf + (s & 1) * S2_CBUF + (mb >> 1) * S2_CIMG + (a_lane ^ ((mb & 1) ? 32u : 0u)) + p * 2 * S2_CIMG;
+                    af[mb][p] = frag2(cm, cm + 4 * S2_ROWB);
+                }
             az_f16x8 bf[2][2];
             auto load_b = [&](az_f16x8 (&bq)[2], int t) {
-                const int kd = t / 9, kh = (t % 9) / 3, kw = t % 3;
-                const unsigned char *fp = fring + kd * (S2_RING * S2_FROW) + fb[kh];
-                const unsigned flip = kh == 2 ? 32u : 0u;  // the row pair of kh = 2 is the next one: other half order
+                int tap = tap0 + t;            // wave-uniform; the 28th tap repeats the 27th (computed, never flushed)
+                tap = tap > 26 ? 26 : tap;
+                const int kd = tap / 9, r9 = tap - 9 * kd, kh = r9 / 3, kw = r9 - 3 * kh;
+                int v = sb + kh + 2 * oct;
+                v = v >= S2_RING ? v - S2_RING : v;
+                unsigned off = (unsigned)v * S2_FROW + b_lane + (unsigned)(kd * (S2_RING * S2_FROW) + (kw == 0 ? 0 : kw == 1 ? 9 : 1) * S2_ROWB);
+                off ^= kh == 2 ? 32u : 0u;  // the row pair of kh = 2 is the next one: other half order
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
-                    bq[p] = frag2(fp + (b_off[kw][0] ^ flip) + p * S2_FPART, fp + (b_off[kw][1] ^ flip) + p * S2_FPART);
+                for (int p = 0; p < 2; ++p) bq[p] = frag2(fring + off + p * S2_FPART, fring + off + 4 * S2_ROWB + p * S2_FPART);
             };
             load_b(bf[0], 0);
 #pragma unroll
-            for (int t = 0; t < 27; ++t) {
+            for (int t = 0; t < 7; ++t) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 1 < 27) load_b(bf[(t + 1) & 1], t + 1);
+                if (t + 1 < 7 && !((S2_ABL & 4) && s > 0)) load_b(bf[(t + 1) & 1], t + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                f32x4 c = acc[t];
                 const az_f16x8(&bq)[2] = bf[t & 1];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bq[0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bq[1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bq[0], c, 0, 0, 0);
-                acc[t] = c;
-                // the set of step s+1 (requested a step ago): one piece after every second tap; the request for step s+2 in
-                // two halves, each as soon as its registers are free
-                if (t <= 15 && (t & 1)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    commit_piece(t >> 1, (s + 1) & 1, 8 * (s + 1));
+                // four independent chains, each lo*hi, hi*lo, hi*hi into the running accumulator (smallest first)
+                if (!(S2_ABL & 8)) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb][1], bq[0], acc[t][mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb][0], bq[1], acc[t][mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mb][0], bq[0], acc[t][mb], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[t][mb][0] += __builtin_bit_cast(float, (int)af[mb][0][0] ^ (int)bq[0][1]);  // keep the operands live
                 }
-                if (t == 8 || t == 16) {
+                // the set of step s+1 (requested a step ago): two pieces behind each of four taps, and the request for the same
+                // two pieces of step s+2 as soon as their registers are free
+                if (t < 4) {
+                    const int pc = 2 * t;
                     __builtin_amdgcn_sched_barrier(0);
-                    issue(4 * (s + 2), 8 * (s + 2), t == 8 ? 0 : 4, t == 8 ? 4 : 8);
+                    commit_piece(pc, (s + 1) & 1, 8 * (s + 1));
+                    commit_piece(pc + 1, (s + 1) & 1, 8 * (s + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(4 * (s + 2), 8 * (s + 2), pc, pc + 2);
                 }
             }
             __syncthreads();  // next step's rows written by all eight waves; this step's no longer read
         }
     }
-    // D[i][j]: i = coarse channel 16 mi + 4 (lane >> 4) + r, j = fine channel 16 ni + (lane & 15)
+    // D[i][j]: i = coarse channel 16 mb + 4 (lane >> 4) + r, j = fine channel 16 ni + (lane & 15)
 #pragma unroll
-    for (int t = 0; t < 27; ++t)
+    for (int t = 0; t < 7; ++t) {
+        const int tap = tap0 + t;
+        if (tap > 26) break;  // (wave-uniform)
+        if ((S2_ABL & 16) && a.B > 0) break;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = 16 * mi + 4 * (lane >> 4) + r;
-            atomicAdd(&a.ws[((size_t)t * 64 + m) * a.CN + n0 + 16 * ni + (lane & 15)], acc[t][r] * o_scale);
-        }
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * mb + 4 * (lane >> 4) + r;
+                atomicAdd(&a.ws[((size_t)tap * 64 + m) * a.CN + n0 + 16 * ni + (lane & 15)], acc[t][mb][r] * o_scale);
+            }
+    }
 }
 
 // one persistent workgroup per CU over the fine-channel tiles; AZ_EUNSUPPORTED: shapes the kernel does not take (the caller

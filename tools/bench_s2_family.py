@@ -47,6 +47,12 @@ def case(name, per_step, mode, cin, cout, in_dims, kind):
         row.append(ms)
         tot[prec] += per_step * ms
     print(f"{name:44s} x{per_step:<7d} {row[0]:9.3f} {gf / row[0] / 833.3:7.2f} {row[1]:10.3f} {gf / row[1] / 416.7:7.2f}   ({gf:.1f} GFLOP)")
+ONLY_S2W = "--only-s2-wgrad" in sys.argv
+if ONLY_S2W:
+    case("conv_wgrad_s2_64_32  (conv1 wgrad)", 3, conv3d.CONV_S2, 32, 64, q, "wgrad")
+    case("deconv_wgrad_s2_64_32 (conv6 wgrad)", 3, conv3d.DECONV_S2, 64, 32, e, "wgrad")
+    case("conv_wgrad_s2_64_64  (conv3 wgrad)", 3, conv3d.CONV_S2, 64, 64, e, "wgrad")
+    sys.exit(0)
 case("conv3d_m1_32_64      (conv1 fwd)", 3, conv3d.CONV_S2, 32, 64, q, "fwd")
 case("conv3d_m2_64_32      (conv6 fwd)", 3, conv3d.DECONV_S2, 64, 32, e, "fwd")
 case("dgrad_m2_64_32       (conv1 dgrad)", 3, conv3d.CONV_S2, 32, 64, q, "dgrad")
@@ -58,6 +64,8 @@ case("conv3d_m0_64_64 @V1  (conv2 fwd)", 3, conv3d.CONV_S1, 64, 64, e, "fwd")
 case("dgrad_m0_64_64 @V1   (conv2 dgrad)", 3, conv3d.CONV_S1, 64, 64, e, "dgrad")
 case("conv_wgrad_s1_64_64 @V1 (conv2 wgrad)", 3, conv3d.CONV_S1, 64, 64, e, "wgrad")
 case("conv3d_m1_64_64      (conv3 fwd)", 3, conv3d.CONV_S2, 64, 64, e, "fwd")
+case("conv_wgrad_s2_64_64  (conv3 wgrad)", 3, conv3d.CONV_S2, 64, 64, e, "wgrad")
+case("deconv_wgrad_s2_64_64 (conv5 wgrad)", 3, conv3d.DECONV_S2, 64, 64, s16, "wgrad")
 case("conv3d_m2_64_64      (conv5 fwd)", 3, conv3d.DECONV_S2, 64, 64, s16, "fwd")
 case("V0 conv3d_m0_32_32   (fwd + BN partials)", 6, conv3d.CONV_S1, 32, 32, q, "fwd")
 case("V0 dgrad_m0_32_32", 6, conv3d.CONV_S1, 32, 32, q, "dgrad")
