@@ -59,7 +59,8 @@ struct Wg16Args {
     int CM, CN;  // channels of coarse / fine (32 or 64 each): one workgroup owns ONE 32 x 32 (m, n) tile
     int nwchunk;
     long long ncols;  // B * D * nwchunk columns of work
-    int wgs;          // persistent workgroups
+    int wgs;          // persistent workgroups per tile
+    int xcd;          // XCD-chunked column order
     const float *coarse_amax, *fine_amax;  // f16x3 (AR = 1): device scalars max |coarse|, max |fine|
 };
 
@@ -77,7 +78,10 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
     const int mi = wv >> 1, ni = wv & 1;
     // 64-channel operands: 2 x 2 (or 2 x 1 / 1 x 2) tiles in the grid; the workgroups of a tile are blockIdx.x / ntiles
     const int ntn = a.CN >> 5, ntiles = (a.CM >> 5) * ntn;
-    const int tile = blockIdx.x % ntiles, wg0 = blockIdx.x / ntiles;
+    // workgroups b and b + 8 share an XCD (and its L2): each XCD gets a contiguous run of the column list -- neighbouring depths
+    // of one chunk, which read the same fine planes -- instead of every eighth column (AZ_WGRAD_R16_XCD=0: the linear order)
+    const int tile = blockIdx.x / a.wgs, wgl = blockIdx.x - tile * a.wgs;
+    const int wg0 = (a.xcd && !(a.wgs & 7)) ? az_xcd_map(wgl, a.wgs) : wgl;
     const int m0 = (tile / ntn) * 32, n0 = (tile % ntn) * 32;
 
     f32x4 acc[27];
@@ -294,6 +298,7 @@ int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
     if (!az_fits_buffer_offset((long long)D * H * W * (cm > cn ? cm : cn) * 4)) return AZ_EUNSUPPORTED;  // one batch element through a 32-bit offset
     const int best = az_wgrad16_workgroups(a.ncols, slots, ntiles, az_options().wgrad_r16_wgs);
     a.wgs = best;
+    a.xcd = az_options().wgrad_r16_xcd;
     if (coarse_amax && fine_amax) hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<1>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<0>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
     return az_launch_status();

@@ -47,6 +47,10 @@ def case(name, per_step, mode, cin, cout, in_dims, kind):
         row.append(ms)
         tot[prec] += per_step * ms
     print(f"{name:44s} x{per_step:<7d} {row[0]:9.3f} {gf / row[0] / 833.3:7.2f} {row[1]:10.3f} {gf / row[1] / 416.7:7.2f}   ({gf:.1f} GFLOP)")
+if "--only-v0-wgrad" in sys.argv:
+    case("V0 conv_wgrad_s1_32_32", 6, conv3d.CONV_S1, 32, 32, q, "wgrad")
+    case("conv_wgrad_s1_64_64 @V1 (conv2 wgrad)", 3, conv3d.CONV_S1, 64, 64, e, "wgrad")
+    sys.exit(0)
 ONLY_S2W = "--only-s2-wgrad" in sys.argv
 if ONLY_S2W:
     case("conv_wgrad_s2_64_32  (conv1 wgrad)", 3, conv3d.CONV_S2, 32, 64, q, "wgrad")

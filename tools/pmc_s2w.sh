@@ -1,11 +1,11 @@
 #!/bin/bash
-# HBM traffic of the stride-2 weight-gradient kernel: FETCH_SIZE pass over tools/bench_s2_family.py --only-s2-wgrad
+# HBM read traffic of the weight-gradient kernels: FETCH_SIZE pass over tools/bench_s2_family.py --only-s2-wgrad | --only-v0-wgrad
 set -e -o pipefail
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/pmc_s2w
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out -o fetch -- python3 $root/tools/bench_s2_family.py --only-s2-wgrad > $out/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out -o fetch -- python3 $root/tools/bench_s2_family.py ${1:---only-s2-wgrad} > $out/fetch.log 2>&1
 cd $root
 python3 - <<PY
 import csv, glob, json, collections
