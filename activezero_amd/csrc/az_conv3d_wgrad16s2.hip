@@ -47,10 +47,10 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 #define S2_ROWB 64                                  // bytes of one (position, 32 channels) fp16 row
-#define S2_FPOS 17                                  // fine positions staged per row: odd image 9, even image 8
+#define S2_FPOS AZ_S2W_FPOS                                  // fine positions staged per row: odd image 9, even image 8
 #define S2_FPART (S2_FPOS * S2_ROWB)                // one part of a fine row                                1 088 B
 #define S2_FROW (2 * S2_FPART)                      // [part][odd 9 | even 8][32 ch]                         2 176 B
-#define S2_RING 17
+#define S2_RING AZ_S2W_RING
 #define S2_CIMG (32 * S2_ROWB)                      // one (part, 32-channel half) image of a coarse chunk   2 048 B
 #define S2_CBUF (4 * S2_CIMG)                       // [part][half][k = 4 rows x 8][32 ch]                   8 192 B
 #define S2_FBASE (2 * S2_CBUF)
@@ -133,9 +133,8 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
         const int f = tid + 512 * i;
-        const int kd = f / (8 * S2_FROWQ), g = f - kd * (8 * S2_FROWQ);
-        const int jj = g / S2_FROWQ, pp = (g - jj * S2_FROWQ) >> 3;
-        const int lrow = (pp & 1) ? 9 + (pp >> 1) : (pp >> 1);  // pp even: an odd fine position
+        int kd, jj, pp, lrow;
+        az_s2w_fine_piece(f, kd, jj, pp, lrow);  // (az_launch_math.h: swept on the CPU)
         rel_g[i] = (unsigned)kd * plane_f + (unsigned)(jj * a.Wf + pp) * vb_f + (unsigned)(f & 7) * 16u;
         rel_l[i] = (unsigned)(S2_FBASE + kd * (S2_RING * S2_FROW) + lrow * S2_ROWB + (f & 7) * 8);
         jpack |= (unsigned)jj << (3 * i);
@@ -145,10 +144,8 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
     const bool live7 = tid + 512 * 6 < S2_NFQ;
 
     for (long long col = wg0; col < a.ncols; col += a.wgs) {
-        long long r_ = col;
-        const int cd = (int)(r_ % a.Dc); r_ /= a.Dc;
-        const int wc = (int)(r_ % a.nwchunk);
-        const int b = (int)(r_ / a.nwchunk);
+        int cd, wc, b;
+        az_s2w_col_decode(col, a.Dc, a.nwchunk, cd, wc, b);
         const int cw0 = wc * 8;
         const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coarse) + (size_t)b * (vol_c / 4), 0, vol_c, 0x00020000);
         const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.fine) + (size_t)b * (vol_f / 4) + n0, 0, vol_f, 0x00020000);
@@ -197,7 +194,7 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
                 d1 = d0 + 2 * S2_CIMG;
             } else {
                 const int fr = frow0 + (int)((jpack >> (3 * (it - 1))) & 7u);
-                int slot = (frow0 + 1) % S2_RING + (fr - frow0);
+                int slot = az_s2w_ring_slot(frow0) + (fr - frow0);
                 slot = slot >= S2_RING ? slot - S2_RING : slot;
                 d0 = (rel_l[it - 1] + (unsigned)slot * S2_FROW) ^ ((unsigned)(((fr + 1) >> 1) & 1) << 5);
                 d1 = d0 + S2_FPART;
@@ -236,7 +233,7 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
                 const int kd = tap / 9, r9 = tap - 9 * kd, kh = r9 / 3, kw = r9 - 3 * kh;
                 int v = sb + kh + 2 * oct;
                 v = v >= S2_RING ? v - S2_RING : v;
-                unsigned off = (unsigned)v * S2_FROW + b_lane + (unsigned)(kd * (S2_RING * S2_FROW) + (kw == 0 ? 0 : kw == 1 ? 9 : 1) * S2_ROWB);
+                unsigned off = (unsigned)v * S2_FROW + b_lane + (unsigned)(kd * (S2_RING * S2_FROW) + az_s2w_tap_row(kw) * S2_ROWB);
                 off ^= kh == 2 ? 32u : 0u;  // the row pair of kh = 2 is the next one: other half order
 #pragma unroll
                 for (int p = 0; p < 2; ++p) bq[p] = frag2(fring + off + p * S2_FPART, fring + off + 4 * S2_ROWB + p * S2_FPART);

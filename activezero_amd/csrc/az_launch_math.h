@@ -89,5 +89,31 @@ inline int az_wgrad16_workgroups(long long ncols, int slots, int ntiles, int cap
     return best;
 }
 
+// az_conv3d_wgrad16s2.hip (stride-2 weight gradient): a step stages 3 planes x 8 new fine rows x 17 positions x 8 float4
+// pieces.  Piece f -> plane pk, row j, position pp (fine x = 2 cw0 - 1 + pp) and the LDS row of the position inside a
+// staged row: the ODD fine positions (pp even) are rows 0..8, the EVEN ones rows 9..16, so that tap kw of coarse position x
+// reads row x (kw = 0), 9 + x (kw = 1), 1 + x (kw = 2).
+#define AZ_S2W_FPOS 17
+#define AZ_S2W_FROWQ (AZ_S2W_FPOS * 8)
+#define AZ_S2W_NFQ (3 * 8 * AZ_S2W_FROWQ)
+#define AZ_S2W_RING 17
+AZ_HD bool az_s2w_fine_piece(int f, int &pk, int &j, int &pp, int &lrow) {
+    pk = f / (8 * AZ_S2W_FROWQ);
+    const int g = f - pk * (8 * AZ_S2W_FROWQ);
+    j = g / AZ_S2W_FROWQ;
+    pp = (g - j * AZ_S2W_FROWQ) >> 3;
+    lrow = (pp & 1) ? 9 + (pp >> 1) : (pp >> 1);
+    return f < AZ_S2W_NFQ;
+}
+AZ_HD int az_s2w_tap_row(int kw) { return kw == 0 ? 0 : kw == 1 ? 9 : 1; }
+// ring slot of fine row fr >= -1 (17 slots: the 9 rows a step reads + the 8 it writes for the next one)
+AZ_HD int az_s2w_ring_slot(int fr) { return (fr + 1) % AZ_S2W_RING; }
+// column -> (coarse depth, 8-position chunk, batch); consecutive columns = consecutive depths of one chunk
+AZ_HD void az_s2w_col_decode(long long col, int Dc, int nwchunk, int &cd, int &wc, int &b) {
+    cd = (int)(col % Dc); col /= Dc;
+    wc = (int)(col % nwchunk);
+    b = (int)(col / nwchunk);
+}
+
 // a tensor slice addressed through one 32-bit buffer offset must stay below the out-of-range marker the kernels use
 inline bool az_fits_buffer_offset(long long bytes) { return bytes > 0 && bytes < 0xffffff00LL; }

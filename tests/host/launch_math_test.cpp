@@ -91,6 +91,86 @@ int main() {
     // 6. the 32-bit buffer-offset guard
     CHECK(az_fits_buffer_offset(1) && az_fits_buffer_offset(0xfffffeffLL) && !az_fits_buffer_offset(0xffffff00LL) &&
           !az_fits_buffer_offset(1LL << 33) && !az_fits_buffer_offset(0), "buffer offset guard");
+    // 7. stride-2 weight gradient (az_conv3d_wgrad16s2.hip): staging pieces, tap rows, ring slots, column walk, offsets
+    {
+        // every (plane, row, position, float4) of a step's fine set is one piece; the LDS rows of a staged row are a permutation
+        std::vector<char> seen(AZ_S2W_NFQ, 0);
+        for (int f = 0; f < AZ_S2W_NFQ + 600; ++f) {
+            int pk, j, pp, lrow;
+            const bool live = az_s2w_fine_piece(f, pk, j, pp, lrow);
+            CHECK(live == (f < AZ_S2W_NFQ), "piece %d liveness", f);
+            if (!live) continue;
+            CHECK(pk >= 0 && pk < 3 && j >= 0 && j < 8 && pp >= 0 && pp < AZ_S2W_FPOS && lrow >= 0 && lrow < AZ_S2W_FPOS, "piece %d -> %d %d %d %d", f, pk, j, pp, lrow);
+            const int id = ((pk * 8 + j) * AZ_S2W_FPOS + pp) * 8 + (f & 7);
+            CHECK(id == f && !seen[f], "piece %d is not its own index (%d)", f, id);
+            seen[f] = 1;
+        }
+        char rows[AZ_S2W_FPOS] = {0};
+        for (int pp = 0; pp < AZ_S2W_FPOS; ++pp) {
+            int pk, j, p2, lrow;
+            az_s2w_fine_piece(pp * 8, pk, j, p2, lrow);
+            CHECK(p2 == pp && !rows[lrow], "LDS row %d of position %d taken", lrow, pp);
+            rows[lrow] = 1;
+            // tap kw of coarse position x reads fine position offset pp = 2x + kw: its row must be tap_row(kw) + x
+            for (int kw = 0; kw < 3; ++kw)
+                if ((pp - kw) >= 0 && (pp - kw) % 2 == 0 && (pp - kw) / 2 < 8)
+                    CHECK(lrow == az_s2w_tap_row(kw) + (pp - kw) / 2, "pp %d kw %d: row %d", pp, kw, lrow);
+        }
+        // ring: the 9 rows step s reads and the 8 rows it writes for step s+1 sit in 17 distinct slots
+        for (int s2 = 0; s2 < 200; ++s2) {
+            char slot[AZ_S2W_RING] = {0};
+            for (int fr = 8 * s2 - 1; fr <= 8 * s2 + 15; ++fr) {
+                const int sl = az_s2w_ring_slot(fr);
+                CHECK(sl >= 0 && sl < AZ_S2W_RING && !slot[sl], "step %d row %d: slot %d", s2, fr, sl);
+                if (sl >= 0 && sl < AZ_S2W_RING) slot[sl] = 1;
+            }
+            // the kernel's per-lane form: (8s mod 17 + 2 oct + kh), minus 17 once
+            for (int oct = 0; oct < 4; ++oct)
+                for (int kh = 0; kh < 3; ++kh) {
+                    int v = (8 * s2) % AZ_S2W_RING + 2 * oct + kh;
+                    v = v >= AZ_S2W_RING ? v - AZ_S2W_RING : v;
+                    CHECK(v == az_s2w_ring_slot(8 * s2 + 2 * oct - 1 + kh), "lane slot s %d oct %d kh %d", s2, oct, kh);
+                }
+        }
+        // columns: the persistent workgroups (with the XCD map) visit every column once; global offsets of valid pieces,
+        // formed the way the kernel forms them (32-bit wrap-around base + per-piece relative part), stay inside the tensor
+        const int shapes[][7] = {{4, 24, 68, 120, 48, 136, 240}, {4, 12, 34, 60, 24, 68, 120}, {1, 2, 4, 7, 3, 7, 13}, {2, 3, 5, 18, 6, 10, 36},
+                                 {8, 1, 136, 240, 1, 272, 480}, {1, 1, 1, 25, 2, 2, 50}};
+        for (const auto &sh : shapes) {
+            const int B = sh[0], Dc = sh[1], Wc = sh[3], Df = sh[4], Hf = sh[5], Wf = sh[6], CN = 32;
+            const int nwchunk = (Wc + 7) / 8;
+            const long long ncols = (long long)B * Dc * nwchunk;
+            const int wgs = az_wgrad16_workgroups(ncols, 256, 1, 0);
+            std::vector<char> seen_col((size_t)ncols, 0);
+            for (int wgl = 0; wgl < wgs; ++wgl) {
+                const int wg0 = (wgs & 7) ? wgl : az_xcd_map(wgl, wgs);
+                for (long long col = wg0; col < ncols; col += wgs) {
+                    CHECK(!seen_col[(size_t)col], "column %lld twice", col);
+                    seen_col[(size_t)col] = 1;
+                    int cd, wc, b;
+                    az_s2w_col_decode(col, Dc, nwchunk, cd, wc, b);
+                    CHECK(cd >= 0 && cd < Dc && wc >= 0 && wc < nwchunk && b >= 0 && b < B, "column %lld -> %d %d %d", col, cd, wc, b);
+                    if (col % 7) continue;  // (offsets: a sample of the columns)
+                    const unsigned vb_f = CN * 4u, plane_f = (unsigned)Hf * Wf * vb_f;
+                    const long long vol_f = (long long)Df * plane_f;
+                    const int cw0 = wc * 8;
+                    const unsigned gbase = (unsigned)(2 * cd - 1) * plane_f + (unsigned)(2 * cw0 - 1) * vb_f;
+                    for (int frow0 = 0; frow0 < Hf + 8; frow0 += 8)
+                        for (int f = 0; f < AZ_S2W_NFQ; f += 5) {
+                            int pk, j, pp, lrow;
+                            az_s2w_fine_piece(f, pk, j, pp, lrow);
+                            const int fd = 2 * cd - 1 + pk, fr = frow0 + j, fw = 2 * cw0 - 1 + pp;
+                            if (fd < 0 || fd >= Df || fr >= Hf || fw < 0 || fw >= Wf) continue;
+                            const unsigned rel = (unsigned)pk * plane_f + (unsigned)(j * Wf + pp) * vb_f + (unsigned)(f & 7) * 16u;
+                            const unsigned off = gbase + (unsigned)frow0 * (unsigned)Wf * vb_f + rel;
+                            const long long want = (long long)fd * plane_f + ((long long)fr * Wf + fw) * vb_f + (f & 7) * 16;
+                            CHECK((long long)off == want && want + 16 <= vol_f, "offset %u vs %lld (volume %lld)", off, want, vol_f);
+                        }
+                }
+            }
+            for (long long c = 0; c < ncols; ++c) CHECK(seen_col[(size_t)c], "column %lld never walked", c);
+        }
+    }
     std::printf("launch math: %d failures\n", fails);
     return fails ? 1 : 0;
 }

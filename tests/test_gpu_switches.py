@@ -27,6 +27,8 @@ CASES = [
     ({"AZ_PATCH_TILED": "0"}, "tests/test_gpu_kernels.py", "patch"),
     ({"AZ_PATCH_K": "1"}, "tests/test_gpu_kernels.py", "patch"),
     ({"AZ_WGRAD_R16_WGS": "64", "AZ_ROLL_SEGLEN": "5"}, "tests/test_gpu_conv3d.py", "convbn3d_golden"),
+    ({"AZ_WGRAD_S2R16": "0"}, "tests/test_gpu_conv3d.py", "weight_grad_stride2 and f16x3"),            # stride-2 f16x3 weight gradient, one kd per wave
+    ({"AZ_WGRAD_R16_XCD": "0"}, "tests/test_gpu_conv3d.py", "residual_relu_train and f16x3"),           # K4w columns in linear order
 ]
 
 
