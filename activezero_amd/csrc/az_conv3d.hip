@@ -756,12 +756,14 @@ extern "C" long long az_conv3d_packed_floats_f16(int cin, int cout) {
 
 // which kernel serves (mode, cout) in f16x3 -- the two read different packed-weight layouts
 static bool f16_on_roll(int mode, int cout) { return mode == 0 && cout == 32; }
+// the transposed 64 -> 32 layers on the depth-rolling kernel of az_conv3d_t2roll.hip (AZ_CONV_T2ROLL=0: az_conv3d_t2.hip)
+static bool f16_on_t2roll(int mode, int cin, int cout) { return mode == 2 && cin == 64 && cout == 32 && az_options().conv_t2roll != 0; }
 
 extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
                                           long long stride_out, long long stride_in, int flip, int mode, void *stream) {
     AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
     if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return AZ_EUNSUPPORTED;
-    if (f16_on_roll(mode, cout))
+    if (f16_on_roll(mode, cout) || f16_on_t2roll(mode, cin, cout))
         return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream));
     const int total = 27 * cin * cout * 2;
     hipLaunchKernelGGL(conv3d_pack_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, az_stream(stream),
@@ -771,6 +773,11 @@ extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const f
 
 static int conv_f16_dispatch(ConvArgs &a, int mode, int cin, int cout, int epi, hipStream_t s) {
     if (f16_on_roll(mode, cout)) return az_conv3d_roll_launch_f16(a, cin, epi, s);
+    if (f16_on_t2roll(mode, cin, cout)) {
+        const int rc = az_conv3d_t2roll_launch(a, epi, s);
+        if (rc != AZ_EUNSUPPORTED) return rc;
+        return AZ_EUNSUPPORTED;  // (the weights are packed for that kernel: the caller takes the bf16x6 route)
+    }
     return epi ? dispatch_mode<1>(a, mode, 3, cin, cout, 0, s) : dispatch_mode<0>(a, mode, 3, cin, cout, 0, s);
 }
 
@@ -788,6 +795,11 @@ extern "C" int az_conv3d_fwd_f16(float *out, const float *in, const float *packe
 extern "C" long long az_conv3d_stats_tiles_f16(int mode, int B, int cin, int cout, int Di, int Hi, int Wi) {
     if (mode < 0 || mode > 2) return AZ_EINVAL;
     if (f16_on_roll(mode, cout)) return az_conv3d_stats_tiles(mode, 2, B, cin, cout, Di, Hi, Wi);
+    if (f16_on_t2roll(mode, cin, cout)) {
+        ConvArgs a{};
+        if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
+        return az_conv3d_t2roll_stats_tiles(a);
+    }
     return az_conv3d_num_tiles(mode, B, Di, Hi, Wi);
 }
 

@@ -37,6 +37,11 @@ long long az_conv3d_roll_stats_tiles(const ConvArgs &a);  // rows of the BatchNo
 int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long long stride_out, long long stride_in,
                        int flip, hipStream_t s);
 
+// f16x3, stride-2 transposed, 64 -> 32 channels, depth-rolling workgroups of eight waves (az_conv3d_t2roll.hip); weights
+// packed by az_conv3d_pack_r16_f16(cin = 64, cout = 32)
+int az_conv3d_t2roll_launch(ConvArgs a, int epi, hipStream_t s);
+long long az_conv3d_t2roll_stats_tiles(const ConvArgs &a);
+
 // bf16x6, stride-2 transposed, 32 output channels: one workgroup owns all 8 output-parity phases of a coarse
 // patch (az_conv3d_t2.hip)
 int az_conv3d_t2_launch(const ConvArgs &a, int cin, int epi, hipStream_t s);
