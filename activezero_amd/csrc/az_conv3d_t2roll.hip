@@ -36,6 +36,9 @@
 #define T2R_LDS (4 * R_SLAB_BYTES)       // [plane buffer][chunk]
 #define T2R_TAPF4 (2 * 2 * 2 * 64)       // float4 per tap of the packed image [tap][cc(2)][n16(2)][part(2)][lane]
 #define T2R_CCF4 (2 * 2 * 64)
+#ifndef T2R_ABL
+#define T2R_ABL 0  // timing-only ablations: 1 no output stores / residual loads, 2 no weight refills, 4 no slab staging, 8 no fragment reads
+#endif
 
 __host__ __device__ constexpr int t2r_k(int p, int o) { return p == 0 ? 1 : (o == 0 ? 2 : 0); }
 // the 27 taps of a stage in chain order: row offset oh, kd group g (0: kd = 0 into the carried set, 1: kd = 1, 2: kd = 2
@@ -175,11 +178,11 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 const f32x4 c = acc[s][p][m];
                 float4 y = make_float4(fmaf(c[0], sch.x, sfh.x), fmaf(c[1], sch.y, sfh.y), fmaf(c[2], sch.z, sfh.z), fmaf(c[3], sch.w, sfh.w));
                 if (EPI == 0) {
-                    const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
+                    const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (T2R_ABL & 1) ? R_OOB : off, 0, 0));
                     y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
                     y.x = fmaxf(y.x, floor_); y.y = fmaxf(y.y, floor_); y.z = fmaxf(y.z, floor_); y.w = fmaxf(y.w, floor_);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rs_out, (T2R_ABL & 1) ? R_OOB : off, 0, 0);
                 if (EPI == 1) {
                     h_n += vok ? 1 : 0;
                     const float d0 = vok ? y.x - hk[0] : 0.f, d1 = vok ? y.y - hk[1] : 0.f, d2 = vok ? y.z - hk[2] : 0.f, d3 = vok ? y.w - hk[3] : 0.f;
@@ -217,7 +220,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
         finish(1, 2 * z - 2, z - 1 >= c0);
         rotate();
         __builtin_amdgcn_sched_barrier(0);
-        issue(z + 1);
+        if (!(T2R_ABL & 4)) issue(z + 1);
         float4 xf[2][2][2];  // [tile][ow][part] of the current (chunk, oh)
         int chain = 0;       // (static after unrolling)
         int pend_g = -1, pend_p = 0;
@@ -229,7 +232,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 const T2rEnt e = T.e[i];
                 const int n = cc * 27 + i;  // tap step of the stage
                 __builtin_amdgcn_sched_barrier(0);
-                if (i == 0 || T.e[i].oh != T.e[i > 0 ? i - 1 : 0].oh) {  // the fragments of this chunk's row offset oh
+                if ((i == 0 || T.e[i].oh != T.e[i > 0 ? i - 1 : 0].oh) && !((T2R_ABL & 8) && (z > c0 || n > 0))) {  // the fragments of this chunk's row offset oh
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -242,7 +245,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 // the next tap's weights (the next chunk's / next stage's first tap at the end)
                 {
                     const int ni = (i + 1) % 27, ncc = i + 1 < 27 ? cc : (cc + 1) & 1;
-                    load_w(wk[(n + 1) & 1], T.e[ni].tap * T2R_TAPF4 + ncc * T2R_CCF4);
+                    if (!((T2R_ABL & 2) && z > c0)) load_w(wk[(n + 1) & 1], T.e[ni].tap * T2R_TAPF4 + ncc * T2R_CCF4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 &t0 = tq[chain & 1][0], &t1 = tq[chain & 1][1];
@@ -262,7 +265,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 // the next plane: one piece behind every fourth tap of the second chunk
                 if (cc == 1 && i >= 3 && i < 27 && (i - 3) % 4 == 0 && (i - 3) / 4 < T2R_NLD) {
                     __builtin_amdgcn_sched_barrier(0);
-                    commit_piece((i - 3) / 4, pn);
+                    if (!(T2R_ABL & 4)) commit_piece((i - 3) / 4, pn);
                 }
             }
         }
