@@ -22,6 +22,13 @@
 //   * a stage is straight-line code: validity (patch overhang, segment ends, the zero plane behind the last coarse plane)
 //     is a buffer bound, never a branch; the next plane is requested at the top of the stage and split / written in its
 //     second half; one barrier per stage.
+// Measured (B = 4, V1 -> V0, alone): 0.49-0.51 ms for either use (az_conv3d_t2.hip: 0.58 / 0.72).  Timing-only builds (T2R_ABL):
+// without the output stores 0.36 ms, without slab staging 0.41, without fragment reads 0.49 -- the 802 MB of output cost their
+// full HBM time on top of the matrix work (as in az_conv3d_roll.hip: -0.09 ms of 0.88 without stores); requesting the weights of
+// the first 3 / 6 / 9 taps of a stage in front of the previous stage's stores changed nothing (0.50-0.51), so it is not the
+// in-order vmcnt wait behind the stores.  What separates the matrix side (242 TFLOP/s without stores) from the stride-1
+// kernel's (438): a weight fragment serves two tiles instead of four, 288 accumulate-adds per 324 MFMAs instead of 144, one
+// tap of weight prefetch, and 35 stage-times per CU for 27 stages of work (5 rounds of 6-plane segments + their closing stage).
 // BatchNorm partials (EPI 1): per-lane shifted running sums of its four channels over everything it stores, merged once
 // after the walk: one row per (batch, depth segment, patch, quarter of the patch).
 #include <type_traits>
