@@ -29,6 +29,7 @@ CASES = [
     ({"AZ_WGRAD_R16_WGS": "64", "AZ_ROLL_SEGLEN": "5"}, "tests/test_gpu_conv3d.py", "convbn3d_golden"),
     ({"AZ_WGRAD_S2R16": "0"}, "tests/test_gpu_conv3d.py", "weight_grad_stride2 and f16x3"),            # stride-2 f16x3 weight gradient, one kd per wave
     ({"AZ_WGRAD_R16_XCD": "0"}, "tests/test_gpu_conv3d.py", "residual_relu_train and f16x3"),           # K4w columns in linear order
+    ({"AZ_CONV_T2ROLL": "0"}, "tests/test_gpu_conv3d.py", "(deconv or hourglass_golden) and f16x3"),       # transposed 64 -> 32 on az_conv3d_t2.hip
 ]
 
 
