@@ -22,13 +22,15 @@
 //   * a stage is straight-line code: validity (patch overhang, segment ends, the zero plane behind the last coarse plane)
 //     is a buffer bound, never a branch; the next plane is requested at the top of the stage and split / written in its
 //     second half; one barrier per stage.
-// Measured (B = 4, V1 -> V0, alone): 0.49-0.51 ms for either use (az_conv3d_t2.hip: 0.58 / 0.72).  Timing-only builds (T2R_ABL):
+// Measured (B = 4, V1 -> V0, alone): 0.46 ms for either use (az_conv3d_t2.hip: 0.58 / 0.72; 0.49-0.51 before the closing stage
+// of a segment was cut down to its nine kd = 0 taps).  Timing-only builds (T2R_ABL):
 // without the output stores 0.36 ms, without slab staging 0.41, without fragment reads 0.49 -- the 802 MB of output cost their
 // full HBM time on top of the matrix work (as in az_conv3d_roll.hip: -0.09 ms of 0.88 without stores); requesting the weights of
 // the first 3 / 6 / 9 taps of a stage in front of the previous stage's stores changed nothing (0.50-0.51), so it is not the
 // in-order vmcnt wait behind the stores.  What separates the matrix side (242 TFLOP/s without stores) from the stride-1
-// kernel's (438): a weight fragment serves two tiles instead of four, 288 accumulate-adds per 324 MFMAs instead of 144, one
-// tap of weight prefetch, and 35 stage-times per CU for 27 stages of work (5 rounds of 6-plane segments + their closing stage).
+// kernel's (438): a weight fragment serves two tiles instead of four, 288 accumulate-adds per 324 MFMAs instead of 144, and
+// ~32 stage-times per CU for 27 stages of work (rounds of short segments, each with a closing stage; weights two taps
+// ahead instead of one: no gain).
 // BatchNorm partials (EPI 1): per-lane shifted running sums of its four channels over everything it stores, merged once
 // after the walk: one row per (batch, depth segment, patch, quarter of the patch).
 #include <type_traits>
@@ -50,7 +52,7 @@
 __host__ __device__ constexpr int t2r_k(int p, int o) { return p == 0 ? 1 : (o == 0 ? 2 : 0); }
 // the 27 taps of a stage in chain order: row offset oh, kd group g (0: kd = 0 into the carried set, 1: kd = 1, 2: kd = 2
 // into the set the next stage carries), column parity pw, row parity ph >= oh, column offset ow <= pw
-struct T2rEnt { int oh, g, ph, pw, ow, tap, first, last; };
+struct T2rEnt { int oh, g, ph, pw, ow, tap, first, last, nxc; };  // nxc: the next entry with g == 0 (27: none left in this chunk)
 struct T2rTab { T2rEnt e[27]; };
 __host__ __device__ constexpr T2rTab t2r_make() {
     T2rTab t{};
@@ -61,9 +63,12 @@ __host__ __device__ constexpr T2rTab t2r_make() {
                 for (int ph = oh; ph < 2; ++ph)
                     for (int ow = 0; ow <= pw; ++ow) {
                         const int kd = g == 0 ? 0 : g == 1 ? 1 : 2;
-                        t.e[n] = T2rEnt{oh, g, ph, pw, ow, (kd * 3 + t2r_k(ph, oh)) * 3 + t2r_k(pw, ow), ow == 0, ow == pw};
+                        t.e[n] = T2rEnt{oh, g, ph, pw, ow, (kd * 3 + t2r_k(ph, oh)) * 3 + t2r_k(pw, ow), ow == 0, ow == pw, 27};
                         ++n;
                     }
+    for (int i = 0; i < 27; ++i)
+        for (int j = 26; j > i; --j)
+            if (t.e[j].g == 0) t.e[i].nxc = j;
     return t;
 }
 
@@ -155,6 +160,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
         if (a.shift) sfh = *reinterpret_cast<const float4 *>(a.shift + cqh);
     }
     sch.x = ldexpf(sch.x, out_exp); sch.y = ldexpf(sch.y, out_exp); sch.z = ldexpf(sch.z, out_exp); sch.w = ldexpf(sch.w, out_exp);
+    const float osc = ldexpf(1.f, out_exp);  // (EPI 1: the only scale -- a scalar register instead of eight vector ones)
     const float floor_ = (EPI == 0 && a.relu) ? 0.f : -__builtin_inff();
     float hk[4] = {0.f, 0.f, 0.f, 0.f}, hs1[4] = {0.f, 0.f, 0.f, 0.f}, hs2[4] = {0.f, 0.f, 0.f, 0.f};
     int h_n = 0;
@@ -167,8 +173,8 @@ conv3d_t2roll_kernel(const ConvArgs a) {
         if (EPI == 1) {  // the shift of the running sums: the first value this lane sees (any value near the data serves)
             const f32x4 c = acc[s][0][0];
             const bool take = h_first && plane_ok;
-            hk[0] = take ? c[0] * sch.x : hk[0]; hk[1] = take ? c[1] * sch.y : hk[1];
-            hk[2] = take ? c[2] * sch.z : hk[2]; hk[3] = take ? c[3] * sch.w : hk[3];
+            hk[0] = take ? c[0] * osc : hk[0]; hk[1] = take ? c[1] * osc : hk[1];
+            hk[2] = take ? c[2] * osc : hk[2]; hk[3] = take ? c[3] * osc : hk[3];
             h_first = h_first && !plane_ok;
         }
 #pragma unroll
@@ -183,7 +189,8 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 const bool vok = row_ok && fx < a.Wo;
                 const unsigned off = vok ? row_off + (unsigned)fx * 128u : R_OOB;
                 const f32x4 c = acc[s][p][m];
-                float4 y = make_float4(fmaf(c[0], sch.x, sfh.x), fmaf(c[1], sch.y, sfh.y), fmaf(c[2], sch.z, sfh.z), fmaf(c[3], sch.w, sfh.w));
+                float4 y = EPI == 1 ? make_float4(c[0] * osc, c[1] * osc, c[2] * osc, c[3] * osc)
+                                    : make_float4(fmaf(c[0], sch.x, sfh.x), fmaf(c[1], sch.y, sfh.y), fmaf(c[2], sch.z, sfh.z), fmaf(c[3], sch.w, sfh.w));
                 if (EPI == 0) {
                     const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (T2R_ABL & 1) ? R_OOB : off, 0, 0));
                     y.x += rr.x; y.y += rr.y; y.z += rr.z; y.w += rr.w;
@@ -210,7 +217,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
             }
     };
 
-    float4 wk[2][2];  // [tap parity][part]: the weights of the tap being multiplied and of the next one
+    float4 wk[2][2];  // [tap parity][part]: the weights of the tap being multiplied and of the next one (two taps ahead: no gain)
     auto load_w = [&](float4 (&w)[2], int f4) __attribute__((always_inline)) {  // f4: float4 index of the tap's (chunk) block in the packed image (static)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -219,7 +226,9 @@ conv3d_t2roll_kernel(const ConvArgs a) {
     f32x4 tq[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};
 
     // ---- one stage: coarse plane z in plane buffer `buf` ------------------------------------------------------------------
-    auto stage = [&](int z, int buf) __attribute__((always_inline)) {
+    // CLOSE: the last stage of a segment (plane c1) only completes fine plane 2 c1 - 1: the nine kd = 0 taps, no next plane
+    auto stage = [&](auto close_tag, int z, int buf) __attribute__((always_inline)) {
+        constexpr bool CLOSE = decltype(close_tag)::value != 0;
         const unsigned char *pl = slab + buf * (2 * R_SLAB_BYTES);
         unsigned char *pn = slab + (buf ^ 1) * (2 * R_SLAB_BYTES);
         // the planes completed by the stage before: fine 2(z-1) - 1 (set 0) and 2(z-1) (set 1)
@@ -227,9 +236,11 @@ conv3d_t2roll_kernel(const ConvArgs a) {
         finish(1, 2 * z - 2, z - 1 >= c0);
         rotate();
         __builtin_amdgcn_sched_barrier(0);
-        if (!(T2R_ABL & 4)) issue(z + 1);
+        if (!(T2R_ABL & 4) && !CLOSE) issue(z + 1);
         float4 xf[2][2][2];  // [tile][ow][part] of the current (chunk, oh)
         int chain = 0;       // (static after unrolling)
+        int k = 0;           // taps multiplied so far: the parity of the weight buffers
+        int oh_have = -1;    // row offset of the fragments in xf
         int pend_g = -1, pend_p = 0;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -237,9 +248,10 @@ conv3d_t2roll_kernel(const ConvArgs a) {
             for (int i = 0; i < 27; ++i) {
                 constexpr T2rTab T = TAB;
                 const T2rEnt e = T.e[i];
-                const int n = cc * 27 + i;  // tap step of the stage
+                if (CLOSE && e.g != 0) continue;
                 __builtin_amdgcn_sched_barrier(0);
-                if ((i == 0 || T.e[i].oh != T.e[i > 0 ? i - 1 : 0].oh) && !((T2R_ABL & 8) && (z > c0 || n > 0))) {  // the fragments of this chunk's row offset oh
+                if (oh_have != cc * 2 + e.oh) {  // the fragments of this chunk's row offset oh
+                    oh_have = cc * 2 + e.oh;
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -251,12 +263,14 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 }
                 // the next tap's weights (the next chunk's / next stage's first tap at the end)
                 {
-                    const int ni = (i + 1) % 27, ncc = i + 1 < 27 ? cc : (cc + 1) & 1;
-                    if (!((T2R_ABL & 2) && z > c0)) load_w(wk[(n + 1) & 1], T.e[ni].tap * T2R_TAPF4 + ncc * T2R_CCF4);
+                    const int nx = CLOSE ? e.nxc : i + 1;                      // next tap of this chunk (27: the chunk is done)
+                    const int ni = nx < 27 ? nx : 0, ncc = nx < 27 ? cc : cc + 1;  // (entry 0 has g = 0: first in both forms)
+                    if (!(CLOSE && ncc == 2)) load_w(wk[(k + 1) & 1], T.e[ni].tap * T2R_TAPF4 + (ncc & 1) * T2R_CCF4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 &t0 = tq[chain & 1][0], &t1 = tq[chain & 1][1];
-                const float4(&w)[2] = wk[n & 1];
+                const float4(&w)[2] = wk[k & 1];
+                ++k;
                 if (e.first) { t0 = f32x4{0.f, 0.f, 0.f, 0.f}; t1 = f32x4{0.f, 0.f, 0.f, 0.f}; }
                 t0 = R_MH(t0, w[0], xf[0][e.ow][0]);
                 t1 = R_MH(t1, w[0], xf[1][e.ow][0]);
@@ -270,7 +284,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 t1 = R_MH(t1, w[1], xf[1][e.ow][0]);
                 if (e.last) { pend_g = e.g; pend_p = e.ph * 2 + e.pw; ++chain; }
                 // the next plane: one piece behind every fourth tap of the second chunk
-                if (cc == 1 && i >= 3 && i < 27 && (i - 3) % 4 == 0 && (i - 3) / 4 < T2R_NLD) {
+                if (!CLOSE && cc == 1 && i >= 3 && i < 27 && (i - 3) % 4 == 0 && (i - 3) / 4 < T2R_NLD) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(T2R_ABL & 4)) commit_piece((i - 3) / 4, pn);
                 }
@@ -289,10 +303,11 @@ conv3d_t2roll_kernel(const ConvArgs a) {
     for (int it = 0; it < T2R_NLD; ++it) commit_piece(it, slab);
     __syncthreads();
     int buf = 0;
-    for (int z = c0; z <= c1; ++z) {
-        stage(z, buf);
+    for (int z = c0; z < c1; ++z) {
+        stage(std::integral_constant<int, 0>{}, z, buf);
         buf ^= 1;
     }
+    stage(std::integral_constant<int, 1>{}, c1, buf);
     // after stage c1: set 0 holds fine plane 2 c1 - 1 (complete); sets 1 / 2 belong to the next segment's planes
     finish(0, 2 * c1 - 1, c1 - 1 >= c0);
 
@@ -332,7 +347,7 @@ static void t2roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
         const int len = (a.Di + n - 1) / n;
         if ((a.Di + len - 1) / len != n) continue;
         const long long rounds = (patches * n + 255) / 256;
-        const long long cost = rounds * (len + 1) * 4 + 1;  // stages per workgroup (+ the closing one) + its fixed cost
+        const long long cost = rounds * (len * 4 + 2) + 1;  // stages per workgroup (the closing one: nine of the 27 taps) + its fixed cost
         if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
     }
 }
