@@ -51,6 +51,15 @@ def _fits32(x, cin, cout):
     return d * h * w * max(cin, cout) * 4 < _OFF32
 
 
+def _fits32_transposed(x, op_cin, op_cout):
+    """transposed 64 -> 32 launches (the depth-rolling kernel of az_conv3d_t2roll.hip, 32-bit offsets): both the coarse
+    input and the eight-times-larger fine output of a batch element must stay below 4 GiB"""
+    if not (op_cin == 64 and op_cout == 32):
+        return True
+    _, d, h, w, _ = x.shape
+    return d * h * w * 64 * 4 < _OFF32 and 8 * d * h * w * 32 * 4 < _OFF32
+
+
 def _layout(precision, mode, op_cout, fits32=True):
     """precision code the C ABI is called with (packing and launch must agree)"""
     if precision == BF16X6 and mode == CONV_S1 and op_cout == 32 and _ROLL and fits32:
@@ -403,6 +412,8 @@ def _conv(x, weight, mode, precision, scale=None, shift=None, residual=None, rel
     fits = _fits32(x, cin, cout)
     if precision == F16X3 and not fits and mode == CONV_S1 and cout == 32:
         precision = BF16X6  # (a batch element >= 4 GiB: the flat-address bf16x6 kernels)
+    if precision == F16X3 and mode == DECONV_S2 and not lazy and not _fits32_transposed(x, cin, cout):
+        precision = BF16X6
     if precision == F16X3 and not lazy and _f16_fwd_ok(mode, cin, cout):
         if mode == DECONV_S2:
             pk, w_amax = _pack_f16(weight, cin, cout, 27, cout * 27, False, mode, cache)
@@ -472,7 +483,8 @@ def _input_grad(dy, weight, mode, cin, cout, precision):
     """gradient of the layer's input from the gradient dy of its (raw) convolution output"""
     fits = _fits32(dy, cin, cout)
     if precision == F16X3:
-        if _f16_dgrad_ok(mode, cin, cout) and (fits or not (mode == CONV_S1 and cin == 32)):
+        if _f16_dgrad_ok(mode, cin, cout) and (fits or not (mode == CONV_S1 and cin == 32)) and \
+                (mode != CONV_S2 or _fits32_transposed(dy, cout, cin)):
             return _input_grad_f16(dy, weight, mode, cin, cout)
         precision = BF16X6
     if mode == CONV_S1:    # flipped taps, channels swapped
