@@ -340,16 +340,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
 
 // depth segments: one workgroup per CU (256 slots)
 static void t2roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
-    const long long patches = (long long)a.B * ((a.tiles_y + 1) / 2) * a.tiles_x;
-    long long best = -1;
-    nseg = 1; seg_len = a.Di;
-    for (int n = 1; n <= a.Di; ++n) {
-        const int len = (a.Di + n - 1) / n;
-        if ((a.Di + len - 1) / len != n) continue;
-        const long long rounds = (patches * n + 255) / 256;
-        const long long cost = rounds * (len * 4 + 2) + 1;  // stages per workgroup (the closing one: nine of the 27 taps) + its fixed cost
-        if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
-    }
+    az_t2roll_segments((long long)a.B * ((a.tiles_y + 1) / 2) * a.tiles_x, a.Di, nseg, seg_len);  // (az_launch_math.h: swept on the CPU)
 }
 
 long long az_conv3d_t2roll_stats_tiles(const ConvArgs &a) {

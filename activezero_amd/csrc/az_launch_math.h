@@ -38,6 +38,20 @@ inline void az_roll_segments(long long patches, int Do, int forced, int &nseg, i
     }
 }
 
+// az_conv3d_t2roll.hip: coarse-depth segments of a launch with ONE workgroup per CU (256 slots); a workgroup runs seg_len full
+// stages and a closing one of nine of the 27 taps.  Postconditions as az_roll_segments.
+inline void az_t2roll_segments(long long patches, int Di, int &nseg, int &seg_len) {
+    long long best = -1;
+    nseg = 1; seg_len = Di;
+    for (int n = 1; n <= Di; ++n) {
+        const int len = (Di + n - 1) / n;
+        if ((Di + len - 1) / len != n) continue;
+        const long long rounds = (patches * n + 255) / 256;
+        const long long cost = rounds * (len * 4 + 2) + 1;
+        if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
+    }
+}
+
 // az_conv2d_roll.hip: image segments per statistic group (patches = groups * patch rows * patch columns; N images)
 inline void az_c2r_segments(long long patches, int N, int &nseg, int &seg_len) {
     long long best = -1;

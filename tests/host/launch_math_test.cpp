@@ -44,6 +44,19 @@ int main() {
                 CHECK(d0 < d1 && d1 <= Do, "segment [%d, %d) of %d", d0, d1, Do);
             }
         }
+    // 2b. coarse-depth segments of the transposed depth-rolling kernel; its workgroups decode like the stride-1 kernel's
+    for (const auto &d : dims) {
+        const int B = d[0], Di = d[1], H = d[2], W = d[3];
+        const int tiles_y = (H + 3) / 4, tiles_x = (W + 15) / 16, tyb = (tiles_y + 1) / 2;
+        int nseg = -1, seg_len = -1;
+        az_t2roll_segments((long long)B * tyb * tiles_x, Di, nseg, seg_len);
+        CHECK(nseg >= 1 && seg_len >= 1 && seg_len <= Di && (long long)nseg * seg_len >= Di && (long long)(nseg - 1) * seg_len < Di,
+              "t2roll B%d Di%d: nseg %d len %d", B, Di, nseg, seg_len);
+        for (int seg = 0; seg < nseg; ++seg) {  // every segment owns at least one coarse plane (the kernel's c0 < c1)
+            const int c0 = seg * seg_len, c1 = c0 + seg_len < Di ? c0 + seg_len : Di;
+            CHECK(c0 < c1, "t2roll empty segment %d of %d (len %d, Di %d)", seg, nseg, seg_len, Di);
+        }
+    }
     // 3. image segments of the 2-D batch-walking kernel
     for (int N = 1; N <= 64; ++N)
         for (long long patches = 1; patches <= 4096; patches *= 3) {
