@@ -23,14 +23,16 @@
 //     is a buffer bound, never a branch; the next plane is requested at the top of the stage and split / written in its
 //     second half; one barrier per stage.
 // Measured (B = 4, V1 -> V0, alone): 0.46 ms for either use (az_conv3d_t2.hip: 0.58 / 0.72; 0.49-0.51 before the closing stage
-// of a segment was cut down to its nine kd = 0 taps).  Timing-only builds (T2R_ABL):
-// without the output stores 0.36 ms, without slab staging 0.41, without fragment reads 0.49 -- the 802 MB of output cost their
-// full HBM time on top of the matrix work (as in az_conv3d_roll.hip: -0.09 ms of 0.88 without stores); requesting the weights of
-// the first 3 / 6 / 9 taps of a stage in front of the previous stage's stores changed nothing (0.50-0.51), so it is not the
-// in-order vmcnt wait behind the stores.  What separates the matrix side (242 TFLOP/s without stores) from the stride-1
-// kernel's (438): a weight fragment serves two tiles instead of four, 288 accumulate-adds per 324 MFMAs instead of 144, and
-// ~32 stage-times per CU for 27 stages of work (rounds of short segments, each with a closing stage; weights two taps
-// ahead instead of one: no gain).
+// of a segment was cut down to its nine kd = 0 taps).  Counter pass (profiles/r04_pmc_*_b4.json): 0.27 GB read + 0.80 GB written
+// for 0.20 + 0.80 algorithmic, clock 2.19 GHz, MFMA pipe 0.29-0.30 busy.  Timing-only builds (T2R_ABL, 0.46 shipped on that box):
+// without the output stores 0.36, with only the first two taps' weight loads per stage 0.31, without slab staging 0.41, without
+// fragment reads 0.46; stores + weights + staging all off: 0.163 ms -- the matrix work itself at 0.8 of the pipe.  So the four
+// costs ADD: matrix 0.16 + weight fragments 0.15 + output stores 0.10-0.13 + staging 0.05.  The weight term is L1 bandwidth:
+// a wave holds two tiles, so every 1 KB fragment feeds six MFMAs (twelve in the stride-1 kernel) and the eight waves of a CU pull
+// 864 KB per stage through a 64 B/clk TCP -- 13.5 k cycles beside 10.4 k matrix cycles.  Requesting weights two taps ahead, or
+// the first 3 / 6 / 9 taps of a stage in front of the previous stage's stores, changed nothing.  What would: four tiles per wave
+// (needs the twelve phase accumulators of 4 tiles: 192 registers) or the weights of a chunk shared through LDS (108 KB beside
+// 138 KB of slabs: needs the slabs in a 128-byte voxel layout with a new conflict-free swizzle).
 // BatchNorm partials (EPI 1): per-lane shifted running sums of its four channels over everything it stores, merged once
 // after the walk: one row per (batch, depth segment, patch, quarter of the patch).
 #include <type_traits>
@@ -46,7 +48,7 @@
 #define T2R_TAPF4 (2 * 2 * 2 * 64)       // float4 per tap of the packed image [tap][cc(2)][n16(2)][part(2)][lane]
 #define T2R_CCF4 (2 * 2 * 64)
 #ifndef T2R_ABL
-#define T2R_ABL 0  // timing-only ablations: 1 no output stores / residual loads, 2 no weight refills, 4 no slab staging, 8 no fragment reads
+#define T2R_ABL 0  // timing-only ablations: 1 no output stores / residual loads, 2 the weights of a stage's first two taps only, 4 no slab staging, 8 no fragment reads
 #endif
 
 __host__ __device__ constexpr int t2r_k(int p, int o) { return p == 0 ? 1 : (o == 0 ? 2 : 0); }
@@ -265,7 +267,7 @@ conv3d_t2roll_kernel(const ConvArgs a) {
                 {
                     const int nx = CLOSE ? e.nxc : i + 1;                      // next tap of this chunk (27: the chunk is done)
                     const int ni = nx < 27 ? nx : 0, ncc = nx < 27 ? cc : cc + 1;  // (entry 0 has g = 0: first in both forms)
-                    if (!(CLOSE && ncc == 2)) load_w(wk[(k + 1) & 1], T.e[ni].tap * T2R_TAPF4 + (ncc & 1) * T2R_CCF4);
+                    if (!(CLOSE && ncc == 2) && !((T2R_ABL & 2) && k > 1)) load_w(wk[(k + 1) & 1], T.e[ni].tap * T2R_TAPF4 + (ncc & 1) * T2R_CCF4);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 &t0 = tq[chain & 1][0], &t1 = tq[chain & 1][1];

@@ -48,6 +48,17 @@ def main():
         dgm, dbt, coef, am = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, 3, device=dev), torch.zeros(1024, device=dev)
         _call("az_bn3d_bwd", _p(y), None, _p(dgm), _p(dbt), _p(coef), _p(ws), wsb, _p(g), None, _p(x), _p(shift), _p(scale),
               _p(scale), _p(scale), _p(shift), 1, nv, C, _p(am), _stream())
+        # round 4, second half: the stride-2 / transposed pair of an hourglass (conv1 32 -> 64 stride 2, conv6 64 -> 32 transposed)
+        if os.environ.get("AZ_PROBE_S2", "1") == "1":
+            F = conv3d.F16X3
+            w1 = torch.randn(64, C, 3, 3, 3, device=dev) * 0.05            # conv1 weight [co][ci]
+            w6 = torch.randn(64, C, 3, 3, 3, device=dev) * 0.05            # conv6 (ConvTranspose) weight [ci][co]
+            xc = torch.randn(B, D // 2, H // 2, W // 2, 64, device=dev)     # a V1 tensor
+            conv3d._conv(xc, w6, conv3d.DECONV_S2, F, stats=True)           # conv6 forward (K5'')
+            conv3d._input_grad(xc, w1, conv3d.CONV_S2, C, 64, F)            # conv1 input gradient (K5'')
+            conv3d._weight_grad(x, xc, conv3d.CONV_S2, C, 64, F)            # conv1 weight gradient (K4w-s2)
+            conv3d._weight_grad(xc, g, conv3d.DECONV_S2, 64, C, F)          # conv6 weight gradient (K4w-s2)
+            conv3d._conv(x, w1, conv3d.CONV_S2, F, stats=True)              # conv1 forward (K4)
         torch.cuda.synchronize()
     print("probe done", x.numel() * 4 / 1e6, "MB per tensor")
 
