@@ -57,9 +57,20 @@ _STREAMS_LOCK = threading.Lock()
 # HIP priority of the side stream (read once): larger = lower.  The backward pass's critical chain is the MAIN stream
 # (input gradients and BatchNorm backward); the weight gradients have slack until the join at the end.
 _SIDE_PRIORITY = int(os.environ.get("AZ_SIDE_PRIORITY", "0"))
-# AZ_SIDE_KEEP=1 (A/B, read once): round 3's protection of side-stream operands -- Python references held until the join
-# -- instead of Tensor.record_stream
-_KEEP_UNTIL_JOIN = os.environ.get("AZ_SIDE_KEEP", "0") == "1"
+# How the operands of a side-stream kernel (allocated on, and returned to, the MAIN stream's allocator pool) are protected
+# while that kernel has not run yet -- AZ_SIDE_RELEASE, read once:
+#   "join"   (default) Python references until the join at the end of backward: the operands of every layer (x, dy: 0.2-0.8 GB
+#            each at V0) stay allocated until then -- 32.9 GB at the peak of a B = 4 step -- and the allocator sees ordinary frees;
+#   "record" Tensor.record_stream: each operand is released as soon as autograd drops it, 29.1 GB allocated at the peak -- but the
+#            host runs several layers ahead of the GPU, the caching allocator holds such a block back until ITS event poll finds
+#            the side stream past the free, requests in between miss the pool and it calls hipMalloc: 75 calls inside 8 timed
+#            steps after 3 warm-up steps, 9 after 12 (profiles/r04_side_release_ab.txt).  Free on a fresh box; +50 ms per step
+#            on a box whose memory a previous process has just released.  For memory-constrained runs only.
+# (A third form -- references dropped when an event behind the kernel has completed, polled at every later launch -- behaves as
+#  "join": at enqueue time the GPU is far behind, nothing has completed yet.)
+_RELEASE = os.environ.get("AZ_SIDE_RELEASE", "join")
+if _RELEASE not in ("record", "join"):
+    _RELEASE = "join"
 
 
 def side_stream(device):
@@ -190,16 +201,13 @@ class scope:
         if sink is not None and sink.live:
             sink.ensure_callback()
             # Operands and outputs live in the MAIN stream's allocator pool and are read / written here on the side
-            # stream: tell the caching allocator (record_stream), which then holds a freed block back until the side
-            # stream has passed the point of the free.  Round 3 kept Python references until the join instead, so the
-            # operands of every layer (x, dy: 0.2-0.8 GB each at V0) stayed allocated until the end of backward and the
-            # peak grew with depth; now each is released as soon as autograd drops it and its kernel has run.
-            if _KEEP_UNTIL_JOIN:
-                sink.keep.extend(t for t in self.operands if t is not None)
-            else:
+            # stream, so they must outlive the kernel (see _RELEASE above)
+            if _RELEASE == "record":
                 for t in self.operands:
                     if t is not None:
                         t.record_stream(sink.stream)
+            else:
+                sink.keep.extend(t for t in self.operands if t is not None)
             sink.stream.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(sink.stream)
             self.ctx.__enter__()

@@ -630,6 +630,7 @@ def main():
     fence()
     note(f"timing {args.steps} steps")
     profiler.start()  # HIP events around the dominant kernel, on the launch stream
+    mem0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
     with on_stream():
         for _ in range(args.steps):
@@ -672,6 +673,10 @@ def main():
                                      "everywhere; every convolution on this library's kernels"},
             "loss": float(loss.item()),
             "peak_mem_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
+            "peak_reserved_gb": torch.cuda.max_memory_reserved(device) / 2 ** 30,
+            # hipMalloc / hipFree calls of the caching allocator INSIDE the timed steps (a steady state has none)
+            "allocator_in_timed_steps": {k: int(torch.cuda.memory_stats(device).get(k, 0) - mem0.get(k, 0))
+                                         for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")},
             "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "r04_pmc_traffic_b4.json"),
                                           os.path.join(REPO, "profiles", "r04_pmc_clock_b4.json"),
                                           ms_per_step=1e3 * dt / args.steps, steps=args.steps,
