@@ -15,6 +15,7 @@ struct AzOptions {
     int wgrad_fw;          // AZ_WGRAD_FW          1: stride-1 bf16x6 fallback kernel walks fine rows
     int wgrad_r16;         // AZ_WGRAD_R16         0 / 1 / 2: stride-1 3-D weight gradients on az_conv3d_wgrad16.hip (none / 32x32 / all)
     int wgrad_r16_wgs;     // AZ_WGRAD_R16_WGS     > 0: cap on that kernel's persistent workgroups
+    int conv2d_roll_h;     // AZ_CONV2D_ROLL_H     1: f16x3 2-D layers with 64 output channels on conv2d_roll64_kernel (half channels x half patch per wave)
     int conv_t2roll;       // AZ_CONV_T2ROLL       1: f16x3 transposed 64 -> 32 layers on az_conv3d_t2roll.hip
     int wgrad_r16_xcd;     // AZ_WGRAD_R16_XCD     1: that kernel's columns in XCD-contiguous runs
     int wgrad_s2r16;       // AZ_WGRAD_S2R16       1: f16x3 stride-2 3-D weight gradients on az_conv3d_wgrad16s2.hip

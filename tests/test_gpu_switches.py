@@ -30,6 +30,7 @@ CASES = [
     ({"AZ_WGRAD_S2R16": "0"}, "tests/test_gpu_conv3d.py", "weight_grad_stride2 and f16x3"),            # stride-2 f16x3 weight gradient, one kd per wave
     ({"AZ_WGRAD_R16_XCD": "0"}, "tests/test_gpu_conv3d.py", "residual_relu_train and f16x3"),           # K4w columns in linear order
     ({"AZ_CONV_T2ROLL": "0"}, "tests/test_gpu_conv3d.py", "(deconv or hourglass_golden) and f16x3"),       # transposed 64 -> 32 on az_conv3d_t2.hip
+    ({"AZ_CONV2D_ROLL_H": "0"}, "tests/test_gpu_conv2d_roll.py", ""),                                      # f16x3 64-channel 2-D layers on conv2d_roll_kernel<.., 4, 1>
 ]
 
 
