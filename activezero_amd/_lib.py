@@ -91,6 +91,11 @@ _SIGS = {
     "az_conv2d_packed_floats": [_INT] * 4,
     "az_conv2d_pack_weights": [_PTR, _PTR] + [_INT] * 4 + [_LL, _LL] + [_INT] * 3 + [_PTR],
     "az_conv2d_fwd": [_PTR] * 6 + [_INT] * 12 + [_PTR],
+    "az_gru_rh": [_PTR] * 3 + [_LL, _INT, _INT, _PTR],
+    "az_gru_out": [_PTR] * 4 + [_LL, _INT, _INT, _PTR],
+    "az_gru_bwd1": [_PTR] * 7 + [_LL, _INT, _INT, _PTR],
+    "az_gru_bwd2": [_PTR] * 5 + [_LL, _INT, _INT, _PTR],
+    "az_gru_bwd3": [_PTR] * 5 + [_LL, _INT, _INT, _PTR],
     "az_conv2d_pack_weights_bf16": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
     "az_conv2d_bf16_fwd": [_PTR] * 7 + [_INT] * 11 + [_PTR],
     "az_conv2d_wgrad_workspace": [_INT] * 4,

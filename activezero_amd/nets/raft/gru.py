@@ -31,6 +31,7 @@ from activezero_amd.ops import _call, _chk, _p, _stream
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GRU = range(5)
 PEAK_BF16 = (2500.0, "dense bf16 MFMA peak")
 _PACK_CACHE = {}
+_CTX_CACHE = {}
 
 
 def _pack_bf16(weights, cache):
@@ -110,8 +111,113 @@ class _Conv3x3Bf16(torch.autograd.Function):
         return gx, gw, gb
 
 
+def _pack_bf16_flipped(weights, cache):
+    """the one-part bf16 image of the INPUT-gradient convolution of [Cout_i, Cin, 3, 3] weights (concatenated along Cout)"""
+    key = None
+    if cache:
+        key = ("flip",) + _cache_key(*weights)
+        hit = _cache_get(_PACK_CACHE, key)
+        if hit is not None:
+            return hit[0]
+    w = torch.cat([x.detach().float() for x in weights], 0).contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(9 * cin * cout // 2, dtype=torch.float32, device=w.device)
+    _call("az_conv2d_pack_weights_bf16_flipped", _p(packed), _p(w), cout, cin, 9, cin * 9, 3, 3, _stream())
+    if key is not None:
+        _cache_put(_PACK_CACHE, key, (packed, weights), 64)
+    return packed
+
+
+class _GRUStepBf16(torch.autograd.Function):
+    """One ConvGRU update (update.py:32-41) under autograd as ONE node: the two convolutions, their input and weight gradients
+    in the reference's autocast arithmetic (bf16 operands, fp32 accumulation; `_Conv3x3Bf16`'s kernels), the gates in fp32
+    in the convolution epilogues (forward) and in five streaming kernels (az_gru_gates.hip).  Same arithmetic as the
+    operator-by-operator form ("bf16_ops"), a quarter of its launches and tensor passes."""
+
+    @staticmethod
+    def forward(ctx, h, cz, cr, cq, wz, wr, wq, bz, br, bq, *xs):
+        c, ci = h.shape[1], sum(t.shape[1] for t in xs)
+        with torch.cuda.device(h.device):
+            b, _, hh, ww = h.shape
+            npix = b * hh * ww
+            hx = h.new_empty(b, hh, ww, c + ci)  # [h | x_0 | x_1 ..] rows, written once (no torch.cat of the inputs)
+            hx[..., :c] = h.permute(0, 2, 3, 1)
+            at = c
+            for t in xs:
+                hx[..., at:at + t.shape[1]] = t.permute(0, 2, 3, 1)
+                at += t.shape[1]
+            # the context terms are the same tensors in all 22 updates of a step (raft_stereo.py:142-172): their rows once
+            key = _cache_key(cz, cr, cq)
+            hit = _cache_get(_CTX_CACHE, key)
+            if hit is None:
+                czr = torch.cat([cz.detach().permute(0, 2, 3, 1), cr.detach().permute(0, 2, 3, 1)], -1).float().contiguous()
+                hit = ((czr, _rows(cq.detach())), (cz, cr, cq))
+                _cache_put(_CTX_CACHE, key, hit, 2)
+            czr, cqr = hit[0]
+            bzr = torch.cat([bz, br]).detach().float().contiguous()
+            zr = conv3x3_bf16(hx, _pack_bf16((wz, wr), True), c + ci, 2 * c, bzr, czr, ACT_SIGMOID)
+            rhx = torch.empty_like(hx)
+            _call("az_gru_rh", _p(rhx), _p(zr), _p(hx), npix, c, ci, _stream())
+            q = conv3x3_bf16(rhx, _pack_bf16((wq,), True), c + ci, c, bq.detach().float().contiguous(), cqr, ACT_TANH)
+            hn = torch.empty_like(q)
+            _call("az_gru_out", _p(hn), _p(zr), _p(q), _p(hx), npix, c, ci, _stream())
+        ctx.save_for_backward(hx, rhx, zr, q, wz, wr, wq)
+        ctx.dims = (c, ci, tuple(t.shape[1] for t in xs))
+        return conv2d.image(hn)
+
+    @staticmethod
+    def backward(ctx, g_hn):
+        hx, rhx, zr, q, wz, wr, wq = ctx.saved_tensors
+        c, ci, xsplit = ctx.dims
+        b, hh, ww, ct = hx.shape
+        npix = b * hh * ww
+        need = ctx.needs_input_grad
+        with torch.cuda.device(g_hn.device):
+            g = _chk(conv2d.rows(g_hn), "grad")
+            dq = torch.empty_like(q)
+            dzr = torch.empty_like(zr)
+            dh_acc = torch.empty_like(q)
+            _call("az_gru_bwd1", _p(dq), _p(dzr), _p(dh_acc), _p(g), _p(zr), _p(q), _p(hx), npix, c, ci, _stream())
+            d_rhx = conv3x3_bf16(dq, _pack_bf16_flipped((wq,), True), c, ct)
+            _call("az_gru_bwd2", _p(dzr), _p(dh_acc), _p(d_rhx), _p(zr), _p(hx), npix, c, ci, _stream())
+            d_hx = conv3x3_bf16(dzr, _pack_bf16_flipped((wz, wr), True), 2 * c, ct)
+            dh = torch.empty_like(q)
+            dx = hx.new_empty(b, hh, ww, ci)
+            _call("az_gru_bwd3", _p(dh), _p(dx), _p(dh_acc), _p(d_rhx), _p(d_hx), npix, c, ci, _stream())
+
+            def wgrad(go, xin, cout):
+                gw = hx.new_empty(cout, ct, 3, 3)
+                ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cout, ct, 3, 3)
+                ws = hx.new_empty(ws_bytes // 4)
+                with profiler.scope(f"gru_wgrad_bf16_{cout}_{ct}", flops=18.0 * ct * cout * npix, peak=PEAK_BF16):
+                    _call("az_conv2d_wgrad_bf16", _p(gw), _p(ws), ws_bytes, _p(go), _p(xin), b, hh, ww, cout, ct, cout, ct,
+                          go.shape[-1], xin.shape[-1], _stream())
+                return gw
+
+            gwz = gwr = gwq = gbz = gbr = gbq = None
+            if need[4] or need[5]:
+                gwzr = wgrad(dzr, hx, 2 * c)
+                gwz, gwr = gwzr[:c], gwzr[c:]
+            if need[6]:
+                gwq = wgrad(dq, rhx, c)
+            if need[7] or need[8]:
+                gbzr = dzr.sum(dim=(0, 1, 2))
+                gbz, gbr = gbzr[:c], gbzr[c:]
+            if need[9]:
+                gbq = dq.sum(dim=(0, 1, 2))
+            img = lambda t: t.permute(0, 3, 1, 2)
+            gxs, at = [], 0
+            for i, n in enumerate(xsplit):
+                gxs.append(img(dx[..., at:at + n]) if need[10 + i] else None)
+                at += n
+            return (img(dh) if need[0] else None, img(dzr[..., :c]) if need[1] else None, img(dzr[..., c:]) if need[2] else None,
+                    img(dq) if need[3] else None, gwz, gwr, gwq, gbz, gbr, gbq, *gxs)
+
+
 class ConvGRU(nn.Module):
-    train_arithmetic = "bf16"  # "bf16": the reference's autocast arithmetic; "bf16x6": fp32-class convolutions (round 3)
+    # "bf16": the reference's autocast arithmetic, one fused autograd node per update; "bf16_ops": the same arithmetic
+    # operator by operator (first round-4 form); "bf16x6": fp32-class convolutions (round 3)
+    train_arithmetic = "bf16"
 
     def __init__(self, hidden_dim, input_dim, kernel_size=3):
         super().__init__()
@@ -153,17 +259,22 @@ class ConvGRU(nn.Module):
     def _forward_autograd(self, h, cz, cr, cq, *x_list):
         with torch.autocast("cuda", enabled=False):
             h, cz, cr, cq = h.float(), cz.float(), cr.float(), cq.float()
+            # (the fused node's convolutions need hidden % 32 == 0 and (hidden + input) % 32 == 0: the reference's 128 + 256;
+            #  every input part a multiple of 4 channels for the float4 kernels -- RAFT's 36 correlation + 220 context do)
+            if self.train_arithmetic == "bf16" and h.shape[1] % 32 == 0 and (h.shape[1] + self.input_dim) % 32 == 0:
+                return _GRUStepBf16.apply(h, cz, cr, cq, self.convz.weight, self.convr.weight, self.convq.weight,
+                                          self.convz.bias, self.convr.bias, self.convq.bias, *[t.float() for t in x_list])
             x = torch.cat([t.float() for t in x_list], 1)
             hx = torch.cat([h, x], 1).contiguous(memory_format=torch.channels_last)
 
-            if self.train_arithmetic == "bf16":
+            if self.train_arithmetic in ("bf16", "bf16_ops"):
                 def conv(m, t):
                     return _Conv3x3Bf16.apply(t, m.weight, m.bias)
             else:
                 def conv(m, t):
                     return conv2d.conv_same(t, m.weight) + m.bias.view(1, -1, 1, 1)
 
-            if self.train_arithmetic == "bf16":  # z and r read the same operand: one convolution with 2 x hidden outputs
+            if self.train_arithmetic in ("bf16", "bf16_ops"):  # z and r read the same operand: one convolution with 2 x hidden outputs
                 zr = _Conv3x3Bf16.apply(hx, torch.cat([self.convz.weight, self.convr.weight], 0),
                                         torch.cat([self.convz.bias, self.convr.bias], 0))
                 z, r = torch.sigmoid(zr[:, :self.hidden_dim] + cz), torch.sigmoid(zr[:, self.hidden_dim:] + cr)

@@ -401,6 +401,18 @@ int az_conv2d_bf16_fwd(float *out, const float *in, const float *packed_w, const
                        const float *residual, const float *gate_z, const float *gate_h, int act, int B, int H,
                        int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
                        int z_cstride, int h_cstride, void *stream);
+/* Gate arithmetic of the ConvGRU update under autograd (nets/raft/update.py:32-41 in training, train.py:303-309): dense
+ * [npix][channels] fp32 rows; hx = [h (hid) | x (inp)], zr = [z | r] (2 hid), rhx = [r * h | x]; see az_gru_gates.hip.
+ * forward: az_gru_rh (rhx from zr, hx), az_gru_out (h' = (1 - z) h + z q); backward: az_gru_bwd1 (g = dL/dh' -> dq_pre,
+ * dzr[:hid], dh_acc), az_gru_bwd2 (d_rhx -> dzr[hid:], dh_acc +=), az_gru_bwd3 (dh, dx from dh_acc, d_rhx, d_hx). */
+int az_gru_rh(float *rhx, const float *zr, const float *hx, long long npix, int hid, int inp, void *stream);
+int az_gru_out(float *hn, const float *zr, const float *q, const float *hx, long long npix, int hid, int inp, void *stream);
+int az_gru_bwd1(float *dq_pre, float *dzr, float *dh_acc, const float *g, const float *zr, const float *q, const float *hx,
+                long long npix, int hid, int inp, void *stream);
+int az_gru_bwd2(float *dzr, float *dh_acc, const float *d_rhx, const float *zr, const float *hx, long long npix, int hid, int inp,
+                void *stream);
+int az_gru_bwd3(float *dh, float *dx, const float *dh_acc, const float *d_rhx, const float *d_hx, long long npix, int hid, int inp,
+                void *stream);
 /* the extractor's first layer (psmnet_submodule_3.py:97-99: 3x3, stride 2, pad 1 on a 3- or 6-channel
  * image) as patch extraction + 1x1 convolution: patches[b,oy,ox, t*C + c] = x[b, 2oy-1+t/3, 2ox-1+t%3, c]
  * (zero outside the image and in channels [9C, Kp)); x: [B,H,W,C]; patches: [B,(H-1)/2+1,(W-1)/2+1,Kp].
