@@ -76,8 +76,8 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mi = wv >> 1, ni = wv & 1;
-    // 64-channel operands: 2 x 2 (or 2 x 1 / 1 x 2) tiles in the grid; the workgroups of a tile are blockIdx.x / ntiles
-    const int ntn = a.CN >> 5, ntiles = (a.CM >> 5) * ntn;
+    // 64-channel operands: 2 x 2 (or 2 x 1 / 1 x 2) tiles in the grid; the workgroups of tile t are blockIdx.x in [t wgs, (t + 1) wgs)
+    const int ntn = a.CN >> 5;
     // workgroups b and b + 8 share an XCD (and its L2): each XCD gets a contiguous run of the column list -- neighbouring depths
     // of one chunk, which read the same fine planes -- instead of every eighth column (AZ_WGRAD_R16_XCD=0: the linear order)
     const int tile = blockIdx.x / a.wgs, wgl = blockIdx.x - tile * a.wgs;
