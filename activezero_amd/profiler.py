@@ -163,13 +163,23 @@ def roofline(prof, pmc_json=None, clock_json=None, ms_per_step=None, steps=1, so
            "top_kernel_by_time": name, "top_kernel_frac_in_step": achieved / peak,
            "top_kernel_ms_in_step": r["avg_ms"], "top_kernel_launches_per_step": r["launches"] / max(steps, 1),
            "top_kernel_frac_solo": None, "top_kernel_ms_solo": None,
-           "traffic": pmc_traffic(name, r["flops"] if r["bound"] == "mfma" else r["bytes"], pmc_json) if pmc_json else None,
+           "traffic": None, "traffic_over_algorithmic": None,  # scalars: HBM bytes per launch (PMC passes), and over SURVEY 8d's bytes
+           "traffic_detail": pmc_traffic(name, r["flops"] if r["bound"] == "mfma" else r["bytes"], pmc_json) if pmc_json else None,
            "held_clock": held_clock(name, clock_json),
            "avg_launch_ms": r["avg_ms"], "launches_timed": r["launches"],
            "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
            "largest_alone": {"kernel": aname, "achieved": a_ach, "peak": a_peak, "peak_basis": a_basis, "frac": a_ach / a_peak,
                              "avg_ms": arec["avg_ms"], "launches": arec["launches"],
                              "note": "largest total time among the kernels that ran with the chip to themselves"}}
+    if out["traffic_detail"]:
+        out["traffic"] = out["traffic_detail"]["hbm_bytes"]
+        alg = r.get("bytes") or 0.0
+        if alg > 0:
+            out["traffic_over_algorithmic"] = out["traffic"] / alg
+    hc = out.get("held_clock")
+    if hc:  # (scalars for readers that drop nested objects)
+        out["held_clock_ghz"] = hc.get("clock_ghz")
+        out["mfma_pipe_busy"] = hc.get("mfma_pipe_busy")
     if solo and solo.get(name):
         out["top_kernel_ms_solo"] = solo[name]
         work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
