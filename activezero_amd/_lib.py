@@ -125,6 +125,14 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(az_[a-z0-9_]+)\s*\(", text)))
 
 
+def expected_abi_version():
+    """AZ_ABI_VERSION of include/azhip.h: the signatures _SIGS was written against"""
+    m = re.search(r"#define\s+AZ_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    if m is None:
+        raise RuntimeError(f"{HEADER} defines no AZ_ABI_VERSION")
+    return int(m.group(1))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -133,6 +141,12 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -m activezero_amd.build` "
                 "(there is no non-HIP fallback)")
         handle = _C.CDLL(LIB_PATH)
+        # a stale build (or a stale variant picked up through AZ_LIB_PATH) would read shifted arguments: refuse it
+        handle.az_abi_version.argtypes, handle.az_abi_version.restype = [], _INT
+        have, want = handle.az_abi_version(), expected_abi_version()
+        if have != want:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {have}, include/azhip.h declares {want}: rebuild it "
+                               "(`python -m activezero_amd.build --force`)")
         for name, args in _SIGS.items():
             fn = getattr(handle, name)
             fn.argtypes = args

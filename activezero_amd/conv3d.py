@@ -307,10 +307,28 @@ def _get_amax(t):
     return a[0] if (a is not None and a[1] == t._version) else None
 
 
+# AZ_DEBUG_AMAX=1 (read once): every amax attached to a tensor is checked against a fresh pass of az_absmax when it is
+# used (synchronises; include/azhip.h, "CONTRACT of a caller-supplied amax": too small = clipped operands)
+_DEBUG_AMAX = os.environ.get("AZ_DEBUG_AMAX", "0") not in ("", "0")
+
+
+def check_amax(t, am):
+    """raise if the amax array `am` is below the largest finite magnitude of t (a stale attribute)"""
+    fresh = t.new_empty(AMAX_SLOTS)
+    _call("az_absmax", _p(fresh), _p(t), t.numel(), _stream())
+    have, true = float(am.max()), float(fresh.max())
+    if not have >= true:
+        raise RuntimeError(f"stale amax: {have:.6g} attached to a tensor whose largest finite magnitude is {true:.6g} "
+                           "(written through a raw pointer or .data without conv3d._touched / a fresh conv3d.absmax?)")
+
+
 def absmax(t):
-    """device scalar max |t|, the operand scale of the f16x3 kernels: taken by the kernel that produced t where that is
-    one of this library's (BatchNorm apply / backward, residual sums), by a pass of az_absmax otherwise"""
+    """device scalar max |t| (largest finite magnitude), the operand scale of the f16x3 kernels: taken by the kernel that
+    produced t where that is one of this library's (BatchNorm apply / backward, residual sums), by a pass of az_absmax
+    otherwise"""
     am = _get_amax(t)
+    if am is not None and _DEBUG_AMAX:
+        check_amax(t, am)
     if am is None:
         am = t.new_empty(AMAX_SLOTS)
         with profiler.scope("absmax", bytes=4.0 * t.numel(), bound="hbm"):

@@ -1,6 +1,6 @@
 // max |x| of a tensor into an amax array (az_common.h, include/azhip.h) -- the operand scale of the f16x3 arithmetic of the backward kernels
 // (az_roll_common.h): a pure stream, one atomic per workgroup.  |x| is compared as its bit pattern (non-negative floats
-// order like unsigned integers; a NaN compares above everything and so reaches the result).
+// order like unsigned integers; inf / NaN elements are left out: the largest FINITE magnitude, az_common.h).
 #include "az_common.h"
 
 __global__ void __launch_bounds__(256)
@@ -11,10 +11,9 @@ absmax_kernel(unsigned *__restrict__ out, const float *__restrict__ x, long long
     const f32x4v *x4 = reinterpret_cast<const f32x4v *>(x);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const f32x4v v = __builtin_nontemporal_load(x4 + i);
-        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu,
-                max(__float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu)));
+        m = max(max(m, az_finite_abs_bits(v.x)), max(az_finite_abs_bits(v.y), max(az_finite_abs_bits(v.z), az_finite_abs_bits(v.w))));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7fffffffu);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, az_finite_abs_bits(x[(n4 << 2) + threadIdx.x]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
     __shared__ unsigned wmax[4];

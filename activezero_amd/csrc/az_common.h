@@ -46,7 +46,7 @@ __device__ __forceinline__ float4 az_ld16_or_zero(const float *base, size_t offs
 
 // ---- max |x| of a tensor, taken by the kernel that writes it (the operand scale of the f16x3 kernels that read it
 // next; az_absmax.hip is the stand-alone pass).  |x| is compared as a bit pattern: non-negative floats order like
-// unsigned integers and a NaN compares above everything.
+// unsigned integers; inf / NaN elements are left out (az_finite_abs_bits).
 // The maximum lives in AZ_AMAX_SLOTS words AZ_AMAX_STRIDE floats (256 B) apart -- an "amax array" is
 // AZ_AMAX_FLOATS = 1024 floats, all ZERO before the producing launch; a workgroup adds its maximum to the slot of its
 // block index with ONE atomic, readers take the largest slot.  Measured on a BatchNorm apply of a 67 MB tensor (20 us
@@ -54,9 +54,16 @@ __device__ __forceinline__ float4 az_ld16_or_zero(const float *base, size_t offs
 // drain through one memory channel at ~4 ns each, whatever the word), with every slot already at the maximum -- no atomic
 // issued, see below -- +0.1 us.  An atomic is issued only when the block's maximum beats what its slot holds; that read
 // bypasses L1 and may be stale (another XCD's L2), which only costs an atomic that changes nothing.
+// |x| as a bit pattern, ZERO for inf / NaN: an amax is the largest FINITE magnitude of its tensor.  (With a non-finite
+// amax the power-of-two scale would flush every finite element of the tensor to zero -- one bad voxel would wipe out all
+// outputs; this way the bad element alone becomes inf / NaN in fp16 and spoils exactly the outputs that read it, as it
+// does in an fp32 convolution.)
+__device__ __forceinline__ unsigned az_finite_abs_bits(float x) {
+    const unsigned b = __float_as_uint(x) & 0x7fffffffu;
+    return b < 0x7f800000u ? b : 0u;
+}
 __device__ __forceinline__ void az_amax_acc(unsigned &am, const float4 &o) {
-    am = max(max(am, __float_as_uint(o.x) & 0x7fffffffu), max(__float_as_uint(o.y) & 0x7fffffffu,
-             max(__float_as_uint(o.z) & 0x7fffffffu, __float_as_uint(o.w) & 0x7fffffffu)));
+    am = max(max(am, az_finite_abs_bits(o.x)), max(az_finite_abs_bits(o.y), max(az_finite_abs_bits(o.z), az_finite_abs_bits(o.w))));
 }
 // called by EVERY thread of the workgroup (a barrier inside); blockDim.x <= 1024
 __device__ __forceinline__ void az_amax_flush(unsigned *dst, unsigned am) {
@@ -72,8 +79,16 @@ __device__ __forceinline__ void az_amax_flush(unsigned *dst, unsigned am) {
         if (am > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, am);
     }
 }
-// the tensor's max |x| from its amax array; wave-uniform (call with all 64 lanes active)
+// MODE.FP16_OVFL (bit 23 of the wave's MODE register): an fp32 -> fp16 conversion whose result overflows returns
+// +-65504 instead of +-inf, while a true inf / NaN input still converts to inf / NaN.  The f16x3 operand scale leaves a
+// factor 2-4 of headroom above the tensor's amax (az_roll_common.h); a caller that passes an amax SMALLER than the
+// tensor's true maximum (a stale attribute) therefore gets saturated hi / lo parts -- a degraded value -- not an inf
+// that the products would spread over every output of the tile.  Costs nothing per element.
+__device__ __forceinline__ void az_fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
+// the tensor's max |x| from its amax array; wave-uniform (call with all 64 lanes active).  Every kernel that scales an
+// operand by an amax converts it to fp16 afterwards: the saturating conversion mode is switched on here, once per wave.
 __device__ __forceinline__ float az_amax_read(const float *p) {
+    az_fp16_saturate();
     unsigned v = reinterpret_cast<const unsigned *>(p)[(threadIdx.x & (AZ_AMAX_SLOTS - 1)) * AZ_AMAX_STRIDE];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));

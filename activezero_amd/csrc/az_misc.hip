@@ -15,7 +15,7 @@ extern "C" const char *az_strerror(int code) {
     }
 }
 
-extern "C" int az_abi_version(void) { return 5; }
+extern "C" int az_abi_version(void) { return AZ_ABI_VERSION; }
 
 // Measurement only (bench.py roofline.measured_hbm; SURVEY.md 8d's second denominator beside the 8 TB/s spec figure): a
 // float4 grid-stride copy, 16 bytes per lane per access -- the stream MI355X_MICROARCH.md quotes 6.29 TB/s for.

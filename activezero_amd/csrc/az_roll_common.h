@@ -61,8 +61,10 @@ __device__ __forceinline__ void r16_step(f32x4 &tnew, const float4 (&aq)[3], con
 // element).  Three products -- hi*hi, hi*lo, lo*hi, largest first -- are summed from zero by
 // v_mfma_f32_16x16x32_f16 and the block sum is added to the fp32 accumulator by VALU adds, as in r16_step; the
 // dropped lo*lo term is <= 2^-22 |x y|.  Half the matrix instructions of bf16x6 for a per-product error of about
-// 2^-22 instead of 2^-24: used for input and weight gradients only (tools/f16x3_probe.py has the per-layer errors
-// against fp64 next to torch's fp32 convolution); the forward pass stays on bf16x6.
+// 2^-22 instead of 2^-24.  Since round 4 the default arithmetic of every matrix kernel of the path, forward passes
+// included (tools/f16x3_probe.py has the per-layer errors against fp64 next to torch's fp32
+// convolution); the inference-time 2-D extractor alone stays on bf16x6.  The guaranteed bound and what a loose or a
+// stale amax costs: include/azhip.h ("CONTRACT of a caller-supplied amax"), tests/test_gpu_f16x3_contract.py.
 typedef _Float16 az_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 az_f16x2 __attribute__((ext_vector_type(2)));
 // k with 2^k * amax in [2^14, 2^15) (clamped so that 2^k is a normal float; amax = 0, inf or nan: any k works or

@@ -21,17 +21,42 @@ The file is deliberately not called update.py: the rest of that reference module
 multi-level block) is ordinary torch code outside this path and keeps resolving from the reference tree; the
 one-line edit there is `from nets.raft.gru import ConvGRU`.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
 from activezero_amd import _lib, conv2d, profiler
-from activezero_amd.conv3d import _cache_get, _cache_key, _cache_put
+from activezero_amd.conv3d import _CACHE_LOCK, _cache_get, _cache_key, _cache_put
 from activezero_amd.ops import _call, _chk, _p, _stream
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, ACT_GRU = range(5)
 PEAK_BF16 = (2500.0, "dense bf16 MFMA peak")
 _PACK_CACHE = {}
 _CTX_CACHE = {}
+CTX_CONVERSIONS = 0  # context-row conversions so far (tests: one per step and GRU level, whatever the inputs' dtype)
+
+
+def _context_rows(cz, cr, cq):
+    """fp32 rows [cz | cr] and cq of the context terms -- the same tensors in all 22 updates of a step
+    (raft_stereo.py:142-172) -- converted once.  Keyed on the CALLER's tensors (under the reference's mixed precision they
+    arrive as fp16, and a key taken after `.float()` would never hit); an entry holds detached rows and weak references:
+    it neither keeps the step's autograd graph alive nor answers for a recycled address, and entries whose sources have
+    died are dropped at the next conversion."""
+    global CTX_CONVERSIONS
+    key = _cache_key(cz, cr, cq)
+    hit = _cache_get(_CTX_CACHE, key)
+    if hit is not None and all(r() is t for r, t in zip(hit[1], (cz, cr, cq))):
+        return hit[0]
+    with torch.no_grad():
+        czr = torch.cat([cz.detach().permute(0, 2, 3, 1), cr.detach().permute(0, 2, 3, 1)], -1).float().contiguous()
+        cqr = _rows(cq.detach())
+    CTX_CONVERSIONS += 1
+    with _CACHE_LOCK:
+        for k in [k for k, v in _CTX_CACHE.items() if any(r() is None for r in v[1])]:
+            del _CTX_CACHE[k]
+    _cache_put(_CTX_CACHE, key, ((czr, cqr), tuple(weakref.ref(t) for t in (cz, cr, cq))), 4)
+    return czr, cqr
 
 
 def _pack_bf16(weights, cache):
@@ -135,7 +160,8 @@ class _GRUStepBf16(torch.autograd.Function):
     operator-by-operator form ("bf16_ops"), a quarter of its launches and tensor passes."""
 
     @staticmethod
-    def forward(ctx, h, cz, cr, cq, wz, wr, wq, bz, br, bq, *xs):
+    def forward(ctx, h, cz, cr, cq, czr, cqr, wz, wr, wq, bz, br, bq, *xs):
+        """czr / cqr: the fp32 rows of the context terms (`_context_rows`; cz / cr / cq themselves only receive gradients)"""
         c, ci = h.shape[1], sum(t.shape[1] for t in xs)
         with torch.cuda.device(h.device):
             b, _, hh, ww = h.shape
@@ -146,14 +172,6 @@ class _GRUStepBf16(torch.autograd.Function):
             for t in xs:
                 hx[..., at:at + t.shape[1]] = t.permute(0, 2, 3, 1)
                 at += t.shape[1]
-            # the context terms are the same tensors in all 22 updates of a step (raft_stereo.py:142-172): their rows once
-            key = _cache_key(cz, cr, cq)
-            hit = _cache_get(_CTX_CACHE, key)
-            if hit is None:
-                czr = torch.cat([cz.detach().permute(0, 2, 3, 1), cr.detach().permute(0, 2, 3, 1)], -1).float().contiguous()
-                hit = ((czr, _rows(cq.detach())), (cz, cr, cq))
-                _cache_put(_CTX_CACHE, key, hit, 2)
-            czr, cqr = hit[0]
             bzr = torch.cat([bz, br]).detach().float().contiguous()
             zr = conv3x3_bf16(hx, _pack_bf16((wz, wr), True), c + ci, 2 * c, bzr, czr, ACT_SIGMOID)
             rhx = torch.empty_like(hx)
@@ -195,23 +213,23 @@ class _GRUStepBf16(torch.autograd.Function):
                 return gw
 
             gwz = gwr = gwq = gbz = gbr = gbq = None
-            if need[4] or need[5]:
+            if need[6] or need[7]:
                 gwzr = wgrad(dzr, hx, 2 * c)
                 gwz, gwr = gwzr[:c], gwzr[c:]
-            if need[6]:
+            if need[8]:
                 gwq = wgrad(dq, rhx, c)
-            if need[7] or need[8]:
+            if need[9] or need[10]:
                 gbzr = dzr.sum(dim=(0, 1, 2))
                 gbz, gbr = gbzr[:c], gbzr[c:]
-            if need[9]:
+            if need[11]:
                 gbq = dq.sum(dim=(0, 1, 2))
             img = lambda t: t.permute(0, 3, 1, 2)
             gxs, at = [], 0
             for i, n in enumerate(xsplit):
-                gxs.append(img(dx[..., at:at + n]) if need[10 + i] else None)
+                gxs.append(img(dx[..., at:at + n]) if need[12 + i] else None)
                 at += n
             return (img(dh) if need[0] else None, img(dzr[..., :c]) if need[1] else None, img(dzr[..., c:]) if need[2] else None,
-                    img(dq) if need[3] else None, gwz, gwr, gwq, gbz, gbr, gbq, *gxs)
+                    img(dq) if need[3] else None, None, None, gwz, gwr, gwq, gbz, gbr, gbq, *gxs)
 
 
 class ConvGRU(nn.Module):
@@ -258,12 +276,15 @@ class ConvGRU(nn.Module):
 
     def _forward_autograd(self, h, cz, cr, cq, *x_list):
         with torch.autocast("cuda", enabled=False):
-            h, cz, cr, cq = h.float(), cz.float(), cr.float(), cq.float()
             # (the fused node's convolutions need hidden % 32 == 0 and (hidden + input) % 32 == 0: the reference's 128 + 256;
             #  every input part a multiple of 4 channels for the float4 kernels -- RAFT's 36 correlation + 220 context do)
             if self.train_arithmetic == "bf16" and h.shape[1] % 32 == 0 and (h.shape[1] + self.input_dim) % 32 == 0:
-                return _GRUStepBf16.apply(h, cz, cr, cq, self.convz.weight, self.convr.weight, self.convq.weight,
-                                          self.convz.bias, self.convr.bias, self.convq.bias, *[t.float() for t in x_list])
+                with torch.cuda.device(h.device):
+                    czr, cqr = _context_rows(cz, cr, cq)  # looked up on the caller's tensors, BEFORE any cast
+                return _GRUStepBf16.apply(h.float(), cz, cr, cq, czr, cqr, self.convz.weight, self.convr.weight,
+                                          self.convq.weight, self.convz.bias, self.convr.bias, self.convq.bias,
+                                          *[t.float() for t in x_list])
+            h, cz, cr, cq = h.float(), cz.float(), cr.float(), cq.float()
             x = torch.cat([t.float() for t in x_list], 1)
             hx = torch.cat([h, x], 1).contiguous(memory_format=torch.channels_last)
 

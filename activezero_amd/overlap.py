@@ -23,12 +23,14 @@ convention:
     layer's node and the gate nothing reads the tensor: the gate's input buffer holds a single defined gradient,
     so the engine has nothing to add up early -- also when several forward passes of the same module are
     back-propagated together (each pass has its own gates, tail and join).
-  * Operands AND outputs of side-stream kernels are recorded on the side stream (`Tensor.record_stream`), so the
-    caching allocator cannot hand their memory to later main-stream work while the side stream still reads or
-    writes it (the outputs matter when the engine drops a weight gradient at once, `backward(inputs=[...])` on a
-    subset: tests/test_gpu_overlap.py::test_partial_backward_still_joins_the_side_stream failed with 1e34-sized
-    BatchNorm gradients before they were protected).  Until round 4 they were kept referenced until the join, which
-    held every layer's operands to the end of the backward pass.
+  * Operands AND outputs of side-stream kernels are kept referenced by the pass's `Sink` until the join (the default,
+    AZ_SIDE_RELEASE=join), so the caching allocator cannot hand their memory to later main-stream work while the side
+    stream still reads or writes it (the outputs matter when the engine drops a weight gradient at once,
+    `backward(inputs=[...])` on a subset: tests/test_gpu_overlap.py::test_partial_backward_still_joins_the_side_stream
+    failed with 1e34-sized BatchNorm gradients before they were protected).  AZ_SIDE_RELEASE=record protects the
+    OPERANDS with `Tensor.record_stream` instead, which frees each layer's operands as soon as the side stream has
+    passed them (3.8 GB less at the allocated peak) but makes the allocator call hipMalloc inside the steps
+    (why it is not the default); outputs are held until the join either way.
 Backstops, so that the scheme cannot silently corrupt memory outside the case it was designed around:
   * the first kernel a pass sends to the side stream registers `sink.join` as an end-of-backward callback of the
     autograd engine: the join also happens when the engine never reaches `_Tail` (`backward(inputs=[...])` or

@@ -141,56 +141,51 @@ def _rate(r):
     return work / (r["avg_ms"] * 1e-3), peak, basis, unit
 
 
+# profiler scope (regex) -> the kernel symbol its launches carry in a rocprofv3 kernel trace: a rocprof row sums every
+# shape a kernel template runs at, a scope is one shape.  Used for `top_rocprof_kernel*` in the roofline object.
+_ROCPROF_FAMILY = [(r"^(conv|deconv)_wgrad_s1_", "conv3d_wgrad_r16_kernel"),
+                   (r"^(conv|deconv)_wgrad_s2_", "conv3d_wgrad_s2r16_kernel"),
+                   (r"^(conv3d|dgrad)_m0_(32|64)_32$", "conv3d_roll_kernel"),
+                   (r"^(conv3d|dgrad)_m2_64_32$", "conv3d_t2roll_kernel"),
+                   (r"^(conv3d|dgrad)_m1_", "conv3d_s2roll_kernel / conv3d_gather_kernel (stride 2)"),
+                   (r"^(conv3d|dgrad)_m", "conv3d_gather_kernel"),
+                   (r"^bn3d_bwd_", "bn_bwd_reduce_kernel + bn_bwd_apply_kernel (3-D)"),
+                   (r"^bn2d_bwd", "bn_bwd_reduce_kernel + bn_bwd_apply_kernel (2-D)"),
+                   (r"^bn3d_apply_", "bn_apply_kernel"),
+                   (r"^conv2d_wgrad", "conv2d_wgrad_*"),
+                   (r"^conv2d", "conv2d_*")]
+
+
+def _family(scope_name):
+    import re
+    for pat, fam in _ROCPROF_FAMILY:
+        if re.search(pat, scope_name):
+            return fam
+    return scope_name
+
+
 def roofline(prof, pmc_json=None, clock_json=None, ms_per_step=None, steps=1, solo=None):
     """roofline object for the kernel with the LARGEST TOTAL TIME in the timed region (event-to-event durations on the
     launch stream).  In the backward pass the weight-gradient kernels run on a side stream BESIDE the main stream's
     kernels (overlap.py), so that duration is the one of a kernel sharing the chip: `frac` is the in-step figure,
-    `top_kernel_frac_solo` the same launch shape timed alone after the run (`solo`, from bench.py).  Scalars at the top
-    level (they survive parsers that drop nested objects): top_kernel_by_time, top_kernel_frac_in_step,
-    top_kernel_frac_solo, whole_step_tflops / whole_step_frac (all MFMA-bound scopes' algorithmic flops over the step
-    time, against the peak of the arithmetic most of them run in)."""
+    `top_kernel_frac_solo` the same launch shape timed alone after the run (`solo`, from bench.py).
+
+    Layout (the driver's parser keeps the leading scalars of an object and drops what follows a nested
+    one): the contract's fields first, then every scalar a reader of the line alone needs -- the whole step's matrix rate,
+    the top kernel BY ROCPROF NAME (all shapes of one kernel template summed, the way a kernel trace ranks them) with its
+    in-step and solo fractions, the largest kernel that ran alone --, and the nested records LAST, under `detail`."""
     if not prof:
         return None
     name, r = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
     achieved, peak, peak_basis, unit = _rate(r)
-    alone = [(k, v) for k, v in prof.items() if not (v.get("side_stream") or v.get("beside_side_stream"))]
-    aname, arec = max(alone or list(prof.items()), key=lambda kv: kv[1]["total_ms"])
-    a_ach, a_peak, a_basis, _ = _rate(arec)
-    out = {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak, "peak_basis": peak_basis, "unit": unit,
-           "frac": achieved / peak,
-           "selection": "largest total time in the timed region, overlapped kernels included; `frac` is its in-step rate",
-           "in_step_overlapped": bool(r.get("side_stream") or r.get("beside_side_stream")),
-           "top_kernel_by_time": name, "top_kernel_frac_in_step": achieved / peak,
-           "top_kernel_ms_in_step": r["avg_ms"], "top_kernel_launches_per_step": r["launches"] / max(steps, 1),
-           "top_kernel_frac_solo": None, "top_kernel_ms_solo": None,
-           "traffic": None, "traffic_over_algorithmic": None,  # scalars: HBM bytes per launch (PMC passes), and over SURVEY 8d's bytes
-           "traffic_detail": pmc_traffic(name, r["flops"] if r["bound"] == "mfma" else r["bytes"], pmc_json) if pmc_json else None,
-           "held_clock": held_clock(name, clock_json),
-           "avg_launch_ms": r["avg_ms"], "launches_timed": r["launches"],
-           "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
-           "largest_alone": {"kernel": aname, "achieved": a_ach, "peak": a_peak, "peak_basis": a_basis, "frac": a_ach / a_peak,
-                             "avg_ms": arec["avg_ms"], "launches": arec["launches"],
-                             "note": "largest total time among the kernels that ran with the chip to themselves"}}
-    if out["traffic_detail"]:
-        out["traffic"] = out["traffic_detail"]["hbm_bytes"]
-        alg = r.get("bytes") or 0.0
-        if alg > 0:
-            out["traffic_over_algorithmic"] = out["traffic"] / alg
-    hc = out.get("held_clock")
-    if hc:  # (scalars for readers that drop nested objects)
-        out["held_clock_ghz"] = hc.get("clock_ghz")
-        out["mfma_pipe_busy"] = hc.get("mfma_pipe_busy")
-    if solo and solo.get(name):
-        out["top_kernel_ms_solo"] = solo[name]
-        work = r["flops"] / 1e12 if r["bound"] == "mfma" else r["bytes"] / 1e9
-        out["top_kernel_frac_solo"] = work / (solo[name] * 1e-3) / peak
-    if solo:
-        out["solo_ms"] = solo
+    work_of = lambda v: v["flops"] / 1e12 if v["bound"] == "mfma" else v["bytes"] / 1e9
+    out = {"kernel": name, "bound": r["bound"], "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
+           "traffic": None}
+    # ---- whole step ------------------------------------------------------------------------------------------
     if ms_per_step:
         mf = [v for v in prof.values() if v["bound"] == "mfma"]
         flop_step = sum(v["flops"] * v["launches"] for v in mf) / max(steps, 1)
-        # the peak most of the matrix work runs against: flop-weighted vote over the scopes' own peaks
-        votes = {}
+        votes = {}  # the peak most of the matrix work runs against: flop-weighted vote over the scopes' own peaks
         for v in mf:
             pk = (v.get("peak") or (PEAK["mfma"][0], "fp32 MFMA dense"))
             votes[pk] = votes.get(pk, 0.0) + v["flops"] * v["launches"]
@@ -198,12 +193,58 @@ def roofline(prof, pmc_json=None, clock_json=None, ms_per_step=None, steps=1, so
         out["whole_step_tflops"] = flop_step / 1e12 / (ms_per_step * 1e-3)
         out["whole_step_frac"] = out["whole_step_tflops"] / wpeak
         out["whole_step_peak"] = wpeak
-        out["whole_step_peak_basis"] = wbasis
-        out["whole_step_mfma_flop"] = flop_step
-        out["whole_step_note"] = ("algorithmic flops of every MFMA-bound scope of one step (the cost-volume convolution counted "
-                                  "in its factored form) over ms_per_step; HBM-bound kernels, Adam and torch glue are in the time")
-    out["others"] = {k: dict({"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]},
-                             **({"side_stream": True} if v.get("side_stream") else {}),
-                             **({"beside_side_stream": True} if v.get("beside_side_stream") else {}))
-                     for k, v in prof.items() if k != name}
+    # ---- top kernel by rocprof name ----------------------------------------------------------------------------
+    fams = {}
+    for k, v in prof.items():
+        fams.setdefault(_family(k), []).append((k, v))
+    fname, members = max(fams.items(), key=lambda kv: sum(v["total_ms"] for _, v in kv[1]))
+    f_ms = sum(v["total_ms"] for _, v in members)
+    lead_name, lead = max(members, key=lambda kv: kv[1]["total_ms"])
+    _, f_peak, f_basis, f_unit = _rate(lead)
+    f_work = sum(work_of(v) * v["launches"] for _, v in members)
+    out["top_rocprof_kernel"] = fname
+    out["top_rocprof_kernel_ms_per_step"] = f_ms / max(steps, 1)
+    out["top_rocprof_kernel_frac_in_step"] = f_work / (f_ms * 1e-3) / f_peak
+    out["top_rocprof_kernel_frac_solo"] = (work_of(lead) / (solo[lead_name] * 1e-3) / f_peak) if (solo and solo.get(lead_name)) else None
+    out["top_rocprof_kernel_bound"] = lead["bound"]
+    out["top_rocprof_kernel_lead_scope"] = lead_name
+    # ---- top scope (one launch shape) ------------------------------------------------------------------------------
+    out.update({"top_kernel_by_time": name, "top_kernel_frac_in_step": achieved / peak,
+                "top_kernel_ms_in_step": r["avg_ms"], "top_kernel_launches_per_step": r["launches"] / max(steps, 1),
+                "top_kernel_frac_solo": None, "top_kernel_ms_solo": None, "traffic_over_algorithmic": None})
+    if solo and solo.get(name):
+        out["top_kernel_ms_solo"] = solo[name]
+        out["top_kernel_frac_solo"] = work_of(r) / (solo[name] * 1e-3) / peak
+    # ---- the largest kernel that had the chip to itself ------------------------------------------------------------
+    alone = [(k, v) for k, v in prof.items() if not (v.get("side_stream") or v.get("beside_side_stream"))]
+    aname, arec = max(alone or list(prof.items()), key=lambda kv: kv[1]["total_ms"])
+    a_ach, a_peak, a_basis, _ = _rate(arec)
+    out.update({"largest_alone_kernel": aname, "largest_alone_frac": a_ach / a_peak, "largest_alone_ms": arec["avg_ms"],
+                "peak_basis": peak_basis, "in_step_overlapped": bool(r.get("side_stream") or r.get("beside_side_stream")),
+                "avg_launch_ms": r["avg_ms"], "launches_timed": r["launches"],
+                "per_launch_work": r["flops"] if r["bound"] == "mfma" else r["bytes"],
+                "selection": "largest total time in the timed region, overlapped kernels included; `frac` is its in-step rate"})
+    detail = {"traffic_detail": pmc_traffic(name, r["flops"] if r["bound"] == "mfma" else r["bytes"], pmc_json) if pmc_json else None,
+              "held_clock": held_clock(name, clock_json)}
+    if detail["traffic_detail"]:
+        out["traffic"] = detail["traffic_detail"]["hbm_bytes"]
+        alg = r.get("bytes") or 0.0
+        if alg > 0:
+            out["traffic_over_algorithmic"] = out["traffic"] / alg
+    hc = detail["held_clock"]
+    if hc:
+        out["held_clock_ghz"] = hc.get("clock_ghz")
+        out["mfma_pipe_busy"] = hc.get("mfma_pipe_busy")
+    if ms_per_step:
+        out["whole_step_note"] = (f"algorithmic flops of every MFMA-bound scope of one step (the cost-volume convolution counted in its "
+                                  f"factored form) over ms_per_step, against {wbasis}; HBM-bound kernels, Adam and torch glue are in the time")
+    if solo:
+        detail["solo_ms"] = solo
+    detail["families_ms_per_step"] = {f: round(sum(v["total_ms"] for _, v in m) / max(steps, 1), 3) for f, m in
+                                      sorted(fams.items(), key=lambda kv: -sum(v["total_ms"] for _, v in kv[1]))[:12]}
+    detail["others"] = {k: dict({"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"]},
+                                **({"side_stream": True} if v.get("side_stream") else {}),
+                                **({"beside_side_stream": True} if v.get("beside_side_stream") else {}))
+                        for k, v in prof.items() if k != name}
+    out["detail"] = detail
     return out

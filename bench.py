@@ -298,12 +298,13 @@ def eager_stage(args, model, device):
         dt_eager = timeit(eager_step, (feats[0][:eb], feats[1][:eb], gt[:eb]), nwarm, max(1, nsteps))
     torch.backends.cudnn.benchmark = False
     lib, eag = b / dt_lib, eb / dt_eager
-    return {"stage": "cost volume + 3-D aggregation (25 Conv3d/ConvTranspose3d + BatchNorm3d) + soft-argmin, fwd + loss + bwd "
+    # one level, scalars only
+    return {"ratio": lib / eag, "unit": "pairs/s",
+            "this_library_value": lib, "this_library_ms_per_step": 1e3 * dt_lib, "this_library_batch": b,
+            "eager_value": eag, "eager_ms_per_step": 1e3 * dt_eager, "eager_batch": eb, "eager_tuned": bench_flag,
+            "stage": "cost volume + 3-D aggregation (25 Conv3d/ConvTranspose3d + BatchNorm3d) + soft-argmin, fwd + loss + bwd "
                      "from the feature maps (psmnet_3.py:149-220)",
-            "this_library": {"value": lib, "unit": "pairs/s", "ms_per_step": 1e3 * dt_lib, "batch": b},
-            "eager": {"value": eag, "unit": "pairs/s", "ms_per_step": 1e3 * dt_eager, "batch": eb, "tuned": bench_flag,
-                      "what": label},
-            "ratio": lib / eag}
+            "eager_what": label}
 
 
 def solo_probe(args, device):
@@ -688,7 +689,11 @@ def main():
                                  "(eager_gpu, eager_stage) are reported comparisons, not the baseline",
         }
         if out["roofline"] is not None and not args.no_solo_probe:
-            out["roofline"]["measured_hbm"] = hbm_probe(device)
+            rf = out["roofline"]
+            detail = rf.pop("detail")  # (nested records stay last)
+            detail["measured_hbm"] = hbm_probe(device)
+            rf["measured_hbm_gbps"] = detail["measured_hbm"]["GB/s"]
+            rf["detail"] = detail
         if world == 1 and not mixed and args.eager_steps > 0:
             note(f"{1e3 * dt / args.steps:.1f} ms/step; timing the PyTorch-eager step on the GPU")
             del opt
@@ -696,16 +701,17 @@ def main():
                 out["eager_stage"] = eager_stage(args, model, device)
                 tuned = _carried_tuned("eager_stage")
                 if tuned is not None and not args.eager_tuned:
-                    # the carried record holds the tuned-eager time AND this library's time of THAT run: quote the
-                    # live-over-carried ratio next to it (same workload, same batch; the eager side is the carried one)
-                    tuned["ratio_live_over_carried_eager"] = out["eager_stage"]["this_library"]["value"] / tuned["eager"]["value"]
-                out["eager_stage"]["tuned"] = tuned
+                    # the committed record of the --eager-tuned run that wrote the find-db: its eager time next to this run's
+                    ce = tuned.get("eager_value", (tuned.get("eager") or {}).get("value"))
+                    out["eager_stage"].update({"carried_eager_value": ce, "carried_from": tuned.get("carried_from"),
+                                               "ratio_live_over_carried_eager": out["eager_stage"]["this_library_value"] / ce if ce else None})
             out["eager_gpu"] = eager_gpu(args, model, il, ir, gt, device)
             out["eager_gpu"]["x"] = out["value"] / out["eager_gpu"]["value"]
             tuned_run = _carried_tuned("eager_gpu")
             if tuned_run is not None and not args.eager_tuned:
-                tuned_run["x_live_over_carried_eager"] = out["value"] / tuned_run["value"]
-            out["eager_gpu"]["tuned_run"] = tuned_run
+                out["eager_gpu"].update({"carried_tuned_value": tuned_run["value"], "carried_tuned_ms_per_step": tuned_run.get("ms_per_step"),
+                                         "carried_from": tuned_run.get("carried_from"),
+                                         "x_live_over_carried_eager": out["value"] / tuned_run["value"]})
             if args.eager_tuned:  # the record a later default run quotes
                 os.makedirs(os.path.dirname(TUNED_EAGER_JSON), exist_ok=True)
                 json.dump({"eager_gpu": out["eager_gpu"], "eager_stage": out["eager_stage"],

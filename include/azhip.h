@@ -35,7 +35,9 @@ extern "C" {
 #define AZ_EWORKSPACE (-5)   /* workspace too small */
 
 const char *az_strerror(int code);
-/* ABI version: bumped when a signature changes. */
+/* ABI version: bumped when a signature changes.  A host binding compares az_abi_version() with the AZ_ABI_VERSION it
+ * was written against and refuses a library that answers anything else (activezero_amd/_lib.py does). */
+#define AZ_ABI_VERSION 6
 int az_abi_version(void);
 /* the value of one A/B switch as the library read it at its first use (name = the environment variable, e.g.
  * "AZ_WGRAD_R16"; DESIGN.md lists them): switches are read once per process into one immutable struct.
@@ -189,7 +191,23 @@ int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
  * is a slot, and the LARGEST slot is max |tensor| (the workgroups that write a tensor add their maxima to different
  * slots, in different 256-byte lines: thousands of atomics on one memory channel serialise; readers take the largest
  * slot).  Output amax arguments must be all ZERO before the call unless stated otherwise.
- * az_absmax: the amax array of x (16-byte aligned; n > 0), zeroing included; NaN propagates. */
+ * An amax is the largest FINITE magnitude: inf / NaN elements are left out by every kernel of this library that writes
+ * one, so that a non-finite element becomes inf / NaN in fp16 and spoils exactly the outputs that read it (an inf may
+ * come out as NaN) while every other output keeps its value; with amax = 0 the scale is finite and the result is 0.
+ *
+ * CONTRACT of a caller-supplied amax A for a tensor whose true largest finite magnitude is a (operand x, K products per
+ * output, the other operand w with amax exactly known):
+ *   - A >= a is legal.  Guaranteed for every output y = sum_k x_k w_k:
+ *       |y - y_exact| <= [3 * 2^-22 + (K / 32 + 3) * 2^-24] * sum_k |x_k w_k|
+ *                        + 2^-38 * (A * sum_k |w_k| + a_w * sum_k |x_k|)
+ *     -- the first term is the two-part split (hi + lo = x up to 2^-22 |x|, the dropped lo * lo) and the fp32 accumulation
+ *     of the 32-deep block sums; the second is the fp16 subnormal spacing: elements more than 2^17 below A lose low bits
+ *     of `lo`, an ABSOLUTE error of 2^-39 A each.  A loose bound A = 2^L a therefore costs L bits of that 2^17 range and
+ *     nothing else (tests/test_gpu_f16x3_contract.py: one element 10^6 / 10^8 times the bulk; A = 2^10 a).
+ *   - A < a (a stale value) is a caller error that the kernels survive: the fp32 -> fp16 conversions SATURATE at
+ *     +-65504 (MODE.FP16_OVFL, az_common.h), so elements above 2-4 A are clipped -- wrong values, but finite ones.
+ *     AZ_DEBUG_AMAX=1 makes the Python wrappers check every attached amax against a fresh az_absmax (synchronising).
+ * az_absmax: the amax array of x (16-byte aligned; n > 0), zeroing included. */
 #define AZ_AMAX_SLOTS 16
 #define AZ_AMAX_STRIDE 64
 #define AZ_AMAX_FLOATS (AZ_AMAX_SLOTS * AZ_AMAX_STRIDE)

@@ -23,9 +23,19 @@ def test_every_declared_symbol_is_exported_and_typed(handle):
 
 
 def test_error_strings_and_version(handle):
-    assert handle.az_abi_version() >= 1
+    assert handle.az_abi_version() == _lib.expected_abi_version()
     assert handle.az_strerror(0) == b"AZ_OK"
     assert handle.az_strerror(-4) == b"AZ_EUNSUPPORTED"
+
+
+def test_a_library_of_another_abi_version_is_refused(handle, monkeypatch):
+    """a stale libazhip.so (or AZ_LIB_PATH variant) would take shifted arguments: lib() must raise, not load it"""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "expected_abi_version", lambda: handle.az_abi_version() + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib() is not None
 
 
 def test_argument_validation_happens_before_any_launch(handle):

@@ -1,0 +1,219 @@
+"""GPU: the f16x3 arithmetic under operands its per-tensor power-of-two scale does not like (VERDICT r4 item 5;
+include/azhip.h, "CONTRACT of a caller-supplied amax"; activezero_amd/csrc/az_roll_common.h).
+
+One V0-shaped layer (32 -> 32, the depth-rolling kernel and the 16x16x32 weight-gradient kernel) and one 64 -> 64 layer
+(gather kernel, 2 x 2 tiles of the weight-gradient kernel); forward, input gradient and weight gradient against torch's
+fp64 convolution on the CPU:
+  (i)   one element 10^6 / 10^8 times the bulk: the documented bound holds -- elements more than 2^17 below the tensor's
+        largest lose low bits (absolute error 2^-39 of the largest), nothing else;
+  (ii)  an all-zero operand: exact zeros, nothing non-finite;
+  (iii) one inf and one NaN element: exactly the outputs that read them are non-finite, every other output keeps its
+        value (the amax is the largest FINITE magnitude);
+  (iv)  an amax passed 2^10 times too large (legal): the same bound with A = 2^10 a;
+  (v)   an amax that is too small (a stale attribute): finite, clipped results (saturating fp16 conversion), and the
+        AZ_DEBUG_AMAX check of the wrappers names it.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from activezero_amd import conv3d  # noqa: E402
+from tests._weights import seeded  # noqa: E402
+
+DEV = "cuda:0"
+LAYERS = [(32, (1, 6, 16, 32)), (64, (1, 4, 8, 16))]
+KINDS = ["fwd", "dgrad", "wgrad"]
+
+
+def cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+
+
+def ncdhw(x):
+    return x.detach().permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def amax_array(value):
+    am = torch.zeros(conv3d.AMAX_SLOTS, device=DEV)
+    am[0] = value
+    return am
+
+
+def run(kind, x, wt, dy, amax_x=None, amax_dy=None):
+    """x: input [B,C,D,H,W] (cpu), wt [C,C,3,3,3], dy: gradient of the output; returns the cpu result of `kind`"""
+    c = wt.shape[0]
+    xg, dg, wg = cl(x), cl(dy), wt.to(DEV)
+    if amax_x is not None:
+        conv3d._set_amax(xg, amax_array(amax_x))
+    if amax_dy is not None:
+        conv3d._set_amax(dg, amax_array(amax_dy))
+    with torch.no_grad():
+        if kind == "fwd":
+            return ncdhw(conv3d._conv(xg, wg, conv3d.CONV_S1, conv3d.F16X3))
+        if kind == "dgrad":
+            return ncdhw(conv3d._input_grad(dg, wg, conv3d.CONV_S1, c, c, conv3d.F16X3))
+        return conv3d._weight_grad(xg, dg, conv3d.CONV_S1, c, c, conv3d.F16X3).cpu()
+
+
+def exact(kind, x, wt, dy):
+    """fp64 result, and the three sums the contract's bound is written in: S = sum |a_k b_k| per output, and for each
+    operand the sum of the OTHER operand's magnitudes per output"""
+    x, wt, dy = x.double(), wt.double(), dy.double()
+    if kind == "fwd":
+        a, conv = x, lambda p, q: F.conv3d(p, q, padding=1)
+        return conv(a, wt), conv(a.abs(), wt.abs()), conv(torch.ones_like(a), wt.abs()), conv(a.abs(), torch.ones_like(wt))
+    if kind == "dgrad":
+        a, conv = dy, lambda p, q: F.conv_transpose3d(p, q, padding=1)
+        return conv(a, wt), conv(a.abs(), wt.abs()), conv(torch.ones_like(a), wt.abs()), conv(a.abs(), torch.ones_like(wt))
+
+    def wg(p, q):  # G[co][ci][tap] = sum_pos q[co, pos] p[ci, pos + tap - 1]
+        return torch.nn.grad.conv3d_weight(p, wt.shape, q, padding=1)
+    return wg(x, dy), wg(x.abs(), dy.abs()), wg(torch.ones_like(x), dy.abs()), wg(x.abs(), torch.ones_like(dy))
+
+
+def bound(s_ab, sum_b, sum_a, amax_a, amax_b):
+    """include/azhip.h for y = sum_k a_k b_k:  8 * 2^-22 * sum |a_k b_k|  +  2^-38 (A_a * sum |b_k| + A_b * sum |a_k|)
+    (first-term constant: the header's worst case 3 * 2^-22 + (K / 32 + 3) * 2^-24 is 10.5 * 2^-22 at K = 864; the block
+    roundings are a random walk in practice and 8 holds)"""
+    return 8 * 2.0 ** -22 * s_ab + 2.0 ** -38 * (amax_a * sum_b + amax_b * sum_a)
+
+
+def operands(c, dims, seed):
+    b, d, h, w = dims
+    x = seeded((b, c, d, h, w), seed)
+    wt = seeded((c, c, 3, 3, 3), seed + 1, -0.2, 0.2)
+    dy = seeded((b, c, d, h, w), seed + 2) * 1e-3
+    return x, wt, dy
+
+
+def amaxes(kind, x, wt, dy):
+    """(amax of the activation-side operand(s)) in the order the bound takes them"""
+    fin = lambda t: float(t[torch.isfinite(t)].abs().max()) if torch.isfinite(t).any() else 0.0
+    return {"fwd": (fin(x), fin(wt)), "dgrad": (fin(dy), fin(wt)), "wgrad": (fin(x), fin(dy))}[kind]
+
+
+@pytest.mark.parametrize("c,dims", LAYERS)
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("factor", [1e6, 1e8])
+def test_one_outlier_costs_what_the_contract_says(c, dims, kind, factor, capsys):
+    x, wt, dy = operands(c, dims, 4100)
+    x[0, 3, 2, 5, 7] *= factor   # a saturated pixel
+    dy[0, 5, 1, 3, 9] *= factor  # a masked-loss gradient spike
+    got = run(kind, x, wt, dy).double()
+    ref, s_ab, s_a, s_b = exact(kind, x, wt, dy)
+    a_a, a_b = amaxes(kind, x, wt, dy)
+    lim = bound(s_ab, s_a, s_b, a_a, a_b)
+    err = (got - ref).abs()
+    assert torch.isfinite(got).all()
+    worst = float((err / lim.clamp_min(1e-300)).max())
+    # what fp32 itself would be off by on the outputs that do not see the outlier, for the record
+    with capsys.disabled():
+        print(f"\nf16x3 outlier x{factor:g} {kind} C={c}: max err/bound {worst:.3f}; max |err| {float(err.max()):.3e}, "
+              f"median relative error {float((err / ref.abs().clamp_min(1e-30)).median()):.2e}")
+    assert worst <= 1.0
+
+
+@pytest.mark.parametrize("c,dims", LAYERS)
+@pytest.mark.parametrize("kind", KINDS)
+def test_all_zero_operand(c, dims, kind):
+    x, wt, dy = operands(c, dims, 4200)
+    zx, zdy = torch.zeros_like(x), torch.zeros_like(dy)
+    for xx, dd in ((zx, dy), (x, zdy)) if kind == "wgrad" else ((zx, zdy),):
+        got = run(kind, xx, wt, dd)
+        assert torch.isfinite(got).all() and float(got.abs().max()) == 0.0
+    got = run(kind, x, torch.zeros_like(wt), dy)
+    if kind != "wgrad":
+        assert torch.isfinite(got).all() and float(got.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("c,dims", LAYERS)
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_non_finite_elements_spoil_their_own_outputs_only(c, dims, kind, bad):
+    x, wt, dy = operands(c, dims, 4300)
+    clean = run(kind, x, wt, dy)
+    px, pd = (0, 3, 2, 5, 7), (0, 5, 1, 3, 9)
+    x[px] = bad
+    dy[pd] = bad
+    got = run(kind, x, wt, dy)
+    hit = torch.zeros_like(got, dtype=torch.bool)
+    if kind == "fwd":      # every output channel of the 3x3x3 neighbourhood of the bad input voxel
+        _, _, d, h, w = px
+        hit[0, :, max(d - 1, 0):d + 2, max(h - 1, 0):h + 2, max(w - 1, 0):w + 2] = True
+    elif kind == "dgrad":
+        _, _, d, h, w = pd
+        hit[0, :, max(d - 1, 0):d + 2, max(h - 1, 0):h + 2, max(w - 1, 0):w + 2] = True
+    else:                  # G[co][ci][tap]: the bad dy channel's rows, the bad x channel's columns
+        hit[pd[1], :, :, :, :] = True
+        hit[:, px[1], :, :, :] = True
+    assert (~torch.isfinite(got[hit])).all(), "an output that reads the bad element stayed finite"
+    assert torch.isfinite(got[~hit]).all(), "a non-finite element leaked into outputs that do not read it"
+    # ... and those keep their values (same scale as the clean run: the amax ignores non-finite elements)
+    if kind == "wgrad":  # (float-atomic flush: not bit-reproducible between runs)
+        torch.testing.assert_close(got[~hit], clean[~hit], rtol=1e-5, atol=1e-6 * float(clean.abs().max()))
+    else:
+        torch.testing.assert_close(got[~hit], clean[~hit], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("c,dims", LAYERS)
+@pytest.mark.parametrize("kind", KINDS)
+def test_a_loose_amax_bound_is_legal_and_costs_its_bits(c, dims, kind, capsys):
+    x, wt, dy = operands(c, dims, 4400)
+    x = x * (1.0 + 1e4 * (seeded(tuple(x.shape), 4410, 0.0, 1.0) > 0.999))  # a 10^4 dynamic range
+    a_x, a_dy = float(x.abs().max()), float(dy.abs().max())
+    loose = 2.0 ** 10
+    tight = run(kind, x, wt, dy).double()
+    got = run(kind, x, wt, dy, amax_x=a_x * loose, amax_dy=a_dy * loose).double()
+    ref, s_ab, s_a, s_b = exact(kind, x, wt, dy)
+    a_a, a_b = amaxes(kind, x, wt, dy)
+    a_a, a_b = (a_a * loose, a_b * loose) if kind == "wgrad" else (a_a * loose, a_b)  # (the weight's amax is exact)
+    lim = bound(s_ab, s_a, s_b, a_a, a_b)
+    e_loose, e_tight = (got - ref).abs(), (tight - ref).abs()
+    with capsys.disabled():
+        print(f"\nf16x3 amax 2^10 too large, {kind} C={c}: max err/bound {float((e_loose / lim).max()):.3f}; "
+              f"mean |err| loose {float(e_loose.mean()):.3e} vs tight {float(e_tight.mean()):.3e}")
+    assert torch.isfinite(got).all()
+    assert float((e_loose / lim.clamp_min(1e-300)).max()) <= 1.0
+
+
+@pytest.mark.parametrize("c,dims", LAYERS)
+@pytest.mark.parametrize("kind", KINDS)
+def test_a_stale_too_small_amax_clips_instead_of_overflowing(c, dims, kind):
+    """amax 64 times too small: scaled elements reach 2^21, far beyond fp16's 65504.  Without the saturating conversion
+    mode the hi parts become inf and inf - inf = NaN lo parts spread over every output that reads them."""
+    x, wt, dy = operands(c, dims, 4500)
+    a_x, a_dy = float(x.abs().max()), float(dy.abs().max())
+    got = run(kind, x, wt, dy, amax_x=a_x / 64, amax_dy=a_dy / 64)
+    assert torch.isfinite(got).all()
+    ref = exact(kind, x, wt, dy)[0]
+    # clipped operands: wrong, but of the right order (not garbage): within the result's own scale
+    assert float((got.double() - ref).abs().max()) <= 2.0 * float(ref.abs().max())
+
+
+def test_debug_amax_check_names_a_stale_attribute():
+    x = cl(seeded((1, 32, 4, 8, 16), 4600))
+    conv3d._set_amax(x, amax_array(float(x.abs().max()) / 8))
+    with pytest.raises(RuntimeError, match="stale amax"):
+        conv3d.check_amax(x, conv3d._get_amax(x))
+    conv3d._set_amax(x, amax_array(float(x.abs().max()) * 2))
+    conv3d.check_amax(x, conv3d._get_amax(x))  # a loose bound is legal
+    # the kernels' own producers: BatchNorm apply writes max |y| of what it stores
+    y = conv3d.add(x, x)
+    conv3d.check_amax(y, conv3d._get_amax(y))
+    assert abs(float(conv3d._get_amax(y).max()) - float(y.abs().max())) == 0.0
+
+
+def test_saturating_conversion_mode_is_what_the_isa_says():
+    """one element far above a deliberately small amax, alone in its receptive field: hi and lo both clip to 65504, so the
+    element is read as 2 * 65504 / scale -- finite -- and a true inf still comes out non-finite (previous test)"""
+    c, dims = 32, (1, 3, 8, 16)
+    x = torch.zeros(1, c, *dims[1:])
+    x[0, 0, 1, 4, 8] = 1000.0
+    wt = torch.zeros(c, c, 3, 3, 3)
+    wt[0, 0, 1, 1, 1] = 1.0
+    got = run("fwd", x, wt, torch.zeros_like(x), amax_x=1.0)  # scale 2^14: 1000 * 2^14 = 1.6e7 >> 65504
+    v = float(got[0, 0, 1, 4, 8])
+    assert np.isfinite(v) and abs(v - 2 * 65504.0 / 2.0 ** 14) <= 1e-3 * v, v

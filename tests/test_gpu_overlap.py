@@ -18,53 +18,50 @@ from tests._weights import load_procedural, seeded  # noqa: E402
 DEV = "cuda:0"
 
 
-def _steps(model, args, gt, md, n):
-    # plain SGD: Adam's first step is lr * sign(g), which turns the last-bit noise of the float atomics into
-    # parameter differences of 2 lr wherever a gradient is near zero, and the second step would compare those
-    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
-    grads, losses = [], []
-    for _ in range(n):
-        opt.zero_grad(set_to_none=True)
-        loss = po.psmnet_disp_loss(model(*args), gt, po.disparity_mask(gt, md))
-        loss.backward()
-        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
-        losses.append(loss.item())
-        opt.step()
-    return grads, losses
+def _grad_step(model, opt, args, gt, md):
+    opt.zero_grad(set_to_none=True)
+    loss = po.psmnet_disp_loss(model(*args), gt, po.disparity_mask(gt, md))
+    loss.backward()
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters()}, loss.item()
 
 
 @pytest.mark.parametrize("mod,nin", [(psm3, 3), (psm6, 6)])
 def test_side_stream_weight_gradients_equal_the_in_order_pass(mod, nin):
+    """Both schedules, two consecutive optimizer steps, every parameter -- and BOTH comparisons are made from ONE state:
+    step 2 of the two schedules starts from the in-order model's post-step-1 parameters and BatchNorm buffers (plain SGD
+    has no optimizer state), so the tight first-step bound applies to it as well.  (Rounds 3-4 let each schedule run its
+    own two steps and compared the second gradients against a yardstick of in-order run-to-run noise -- 0.4 % of
+    relative L2 after one update: the weight-gradient kernels flush with float atomics (az_conv3d_wgrad*.hip,
+    az_conv2d_wgrad*.hip, az_conv3d_c1.hip) and the soft-argmin / cost-assembly backward kernels add with them too, so two
+    runs differ in the last bits of every gradient, and ~85 train-mode BatchNorms in a model with random weights
+    amplify that between steps.  That comparison could pass or fail on noise: profiles/r04m_gpu_tests.log has a run at
+    4.003x of the yardstick.)"""
     md = 32
     base = load_procedural(mod.PSMNet(md), "g4.").to(DEV).train()
     imgs = [seeded((2, 3, 256, 256), 700 + i, -2.0, 2.0).to(DEV) for i in range(nin + 1)]
     args, gt = imgs[:2] if nin == 3 else imgs[:4], 1.0 + 28.0 * seeded((2, 1, 256, 256), 77, 0.0, 1.0).to(DEV)
     a, b = copy.deepcopy(base), copy.deepcopy(base).set_weight_grad_overlap(False)
-    c = copy.deepcopy(base).set_weight_grad_overlap(False)  # controls: two more in-order runs
-    d = copy.deepcopy(base).set_weight_grad_overlap(False)
     assert a.wgrad_overlap and not b.wgrad_overlap
-    ga, la = _steps(a, args, gt, md, 2)
-    gb, lb = _steps(b, args, gt, md, 2)
-    gc, _ = _steps(c, args, gt, md, 2)
-    gd, _ = _steps(d, args, gt, md, 2)
+    # plain SGD: Adam's first step is lr * sign(g), which turns last-bit noise into parameter differences of 2 lr
+    oa, ob = torch.optim.SGD(a.parameters(), lr=1e-3), torch.optim.SGD(b.parameters(), lr=1e-3)
 
     def dist(x, r):
         x, r = x.double().cpu().numpy(), r.double().cpu().numpy()
         assert np.isfinite(x).all()
         return np.linalg.norm(x - r) / (np.linalg.norm(r) + 1e-30)
 
-    # first step, identical parameters: equal up to the float atomics of the weight-gradient flushes
-    assert abs(la[0] - lb[0]) <= 1e-5 * abs(lb[0])
-    for k in gb[0]:
-        assert dist(ga[0][k], gb[0][k]) <= 2e-4, k
-    # second step: the model (train-mode BatchNorm, random weights) amplifies the last-bit differences of the
-    # first update; the yardstick is what IN-ORDER runs differ by among themselves -- the largest distance over two
-    # control pairs (with ONE pair the yardstick is itself a single draw of that noise: profiles/r04m_gpu_tests.log has a
-    # run at 4.003x of it, the next run of the same tree passed)
-    worst = max(max(dist(gc[1][k], gb[1][k]), dist(gd[1][k], gb[1][k]), dist(gd[1][k], gc[1][k])) for k in gb[1])
-    for k in gb[1]:
-        assert dist(ga[1][k], gb[1][k]) <= 4.0 * worst + 1e-5, (k, worst)
-    assert abs(la[1] - lb[1]) <= 1e-3 * abs(lb[1])
+    for step in range(2):
+        ga, la = _grad_step(a, oa, args, gt, md)
+        gb, lb = _grad_step(b, ob, args, gt, md)
+        # identical parameters and running statistics: equal up to the float atomics of the gradient flushes
+        assert abs(la - lb) <= 1e-5 * abs(lb), step
+        for k in gb:
+            assert dist(ga[k], gb[k]) <= 2e-4, (step, k)
+        oa.step()
+        ob.step()
+        # the side-stream schedule has now run a full step of its own (sink armed, joined, released, optimizer applied);
+        # its next step starts from the in-order model's state
+        a.load_state_dict(b.state_dict())
     # after backward nothing is left on the side stream un-joined: a plain synchronize of the main stream covers it
     torch.cuda.current_stream().synchronize()
     assert overlap.side_stream(DEV).query()

@@ -257,7 +257,10 @@ def test_full_model_d192_error_split(golden, arith, capsys):
         #     literal 1e-3 px bar is MISSED on the eval outputs at this disparity range (measured 1.11e-3 ..
         #     1.33e-3 px max over both arithmetic modes and both sizes) and met on the
         #     train-mode heads (<= 5.9e-4 px), which are what the headline workload computes
-        assert e_hr32.max() <= (1.4e-3 if "eval" in k else 7e-4), line
+        #     (round 5: the eval ceiling per arithmetic -- profiles/r04z_gpu_tests.log measured 1.06e-3 / 1.05e-3 for the
+        #     default f16x3, 1.15e-3 / 1.17e-3 for bf16x6, 1.33e-3 / 1.20e-3 for the bit-exact fp32 MFMA)
+        eval_ceiling = {"f16x3": 1.2e-3, "bf16x6": 1.3e-3}.get(arith, 1.4e-3)
+        assert e_hr32.max() <= (eval_ceiling if "eval" in k else 7e-4), line
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -31,6 +31,12 @@ CASES = [
     ({"AZ_WGRAD_R16_XCD": "0"}, "tests/test_gpu_conv3d.py", "residual_relu_train and f16x3"),           # K4w columns in linear order
     ({"AZ_CONV_T2ROLL": "0"}, "tests/test_gpu_conv3d.py", "(deconv or hourglass_golden) and f16x3"),       # transposed 64 -> 32 on az_conv3d_t2.hip
     ({"AZ_CONV2D_ROLL_H": "0"}, "tests/test_gpu_conv2d_roll.py", ""),                                      # f16x3 64-channel 2-D layers on conv2d_roll_kernel<.., 4, 1>
+    # the Python-level switches of the two-stream backward (overlap.py, conv2d.py)
+    ({"AZ_SIDE_RELEASE": "record"}, "tests/test_gpu_overlap.py", "in_order_pass or partial_backward or two_forward"),  # operands released through record_stream
+    ({"AZ_SIDE_PRIORITY": "-1"}, "tests/test_gpu_overlap.py", "in_order_pass"),             # side stream at the other HIP priority
+    ({"AZ_2D_WGRAD_OVERLAP": "0"}, "tests/test_gpu_overlap.py", "in_order_pass"),           # 2-D weight gradients in order
+    ({"AZ_PRESPLIT": "0"}, "tests/test_gpu_conv3d.py", "(convbn3d_golden or residual_relu_train or hourglass_golden) and f16x3"),  # fp32 gradient operands, split by the consumers
+    ({"AZ_DEBUG_AMAX": "1"}, "tests/test_gpu_conv3d.py", "(convbn3d_golden or residual_relu_train) and f16x3"),  # every attached amax checked against a fresh pass
 ]
 
 

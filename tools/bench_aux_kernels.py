@@ -94,7 +94,10 @@ row("`az_bn3d_bwd` (V0, 32 ch, ReLU mask recomputed, amax out)", timeit(lambda: 
     raw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), sc.data_ptr(), sh.data_ptr(), 1, nv, C, dxa.data_ptr(),
     ops._stream())), 20.0 * xv.numel(), "reduce + apply (partials merged in the apply prologue)")
 row("`az_absmax` (V0, 32 ch)", timeit(lambda: ops._call("az_absmax", dxa.data_ptr(), xv.data_ptr(), xv.numel(), ops._stream())), 4.0 * xv.numel(), "the stand-alone amax pass (f16x3 operand scale) where no producer kernel took it")
-row("`az_hbm_copy_probe` (float4 copy, 0.8 GB)", timeit(lambda: ops._call("az_hbm_copy_probe", yv.data_ptr(), xv.data_ptr(), xv.numel(), ops._stream())), 8.0 * xv.numel(), "bench.py's measured_hbm kernel")
+import bench as _bench  # the SAME probe bench.py's roofline.measured_hbm_gbps comes from (one implementation, one size: VERDICT r4 item 9)
+_hb = _bench.hbm_probe(dev)
+row("`az_hbm_copy_probe` (float4 copy, 1 GiB in + 1 GiB out; bench.hbm_probe)", 2.0 * (1 << 30) / 1e6 / _hb["GB/s"], 2.0 * (1 << 30), "bench.py's measured_hbm kernel, median of 7 after 3 warm-up launches")
+row("`az_hbm_copy_probe` on the V0 tensor above (0.8 GB in + 0.8 GB out), 10 launches behind 2", timeit(lambda: ops._call("az_hbm_copy_probe", yv.data_ptr(), xv.data_ptr(), xv.numel(), ops._stream())), 8.0 * xv.numel(), "the round-4 table's row: same kernel, this tool's generic timer")
 # 32 -> 1 classifier convolution (VALU kernels)
 wc = torch.randn(1, C, 3, 3, 3, device=dev) * 0.05
 lo = torch.empty(B, d, h, w, device=dev); gxc = torch.empty_like(xv); gwc = torch.empty_like(wc)

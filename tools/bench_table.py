@@ -9,7 +9,7 @@ r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "
                     "--eager-steps", "0", "--no-stage-bench"] + extra, capture_output=True, text=True)
 d = json.loads(r.stdout.strip().splitlines()[-1])
 print("%.2f ms/step  %.2f pairs/s  loss %.5f  peak %.1f GB" % (d["ms_per_step"], d["value"], d["loss"], d["peak_mem_gb"]))
-rows = [dict(name=k, **v) for k, v in d["roofline"]["others"].items()]
+rows = [dict(name=k, **v) for k, v in (d["roofline"].get("detail") or d["roofline"])["others"].items()]
 top = d["roofline"]
 rows.append(dict(name=top["kernel"], avg_ms=top["avg_launch_ms"], launches=top["launches_timed"]))
 for x in sorted(rows, key=lambda x: -x.get("avg_ms", 0) * x.get("launches", 0))[:n]:

@@ -451,6 +451,10 @@ def g12_convgru():
             out[f"{tag}_out32"] = lat(mod(hid, *ctx, *xs))
             with torch.autocast("cpu", dtype=torch.bfloat16):
                 out[f"{tag}_outamp"] = lat(mod(hid, *ctx, *xs).float())
+            # round 5: torch.cuda.amp.autocast (raft_stereo.py:14), the reference's own arithmetic for this
+            # block, is FLOAT16 on CUDA (11-bit operands, GradScaler) -- the bfloat16 yardstick above is 8x coarser
+            with torch.autocast("cpu", dtype=torch.float16):
+                out[f"{tag}_outamp16"] = lat(mod(hid, *ctx, *xs).float())
             hh = hid
             for _ in range(4):
                 hh = mod(hh, *ctx, *xs)
@@ -482,6 +486,15 @@ def g12_convgru():
             for name in ("convz", "convr", "convq"):
                 out[f"d_gwfull_amp_{name}"] = getattr(mod, name).weight.grad.float()
                 out[f"d_gb_amp_{name}"] = getattr(mod, name).bias.grad.float()
+            mod.zero_grad(set_to_none=True)
+            hr = hid.clone().requires_grad_(True)
+            with torch.autocast("cpu", dtype=torch.float16):  # (see _outamp16; unit cotangent scale: no GradScaler needed)
+                o = mod(hr, *ctx, *xs)
+            (o.float() * cot).sum().backward()
+            out["d_gh_amp16"] = hr.grad.float()
+            for name in ("convz", "convr", "convq"):
+                out[f"d_gwfull_amp16_{name}"] = getattr(mod, name).weight.grad.float()
+                out[f"d_gb_amp16_{name}"] = getattr(mod, name).bias.grad.float()
             mod.zero_grad(set_to_none=True)
             mod.double()
             hr = hid.double().requires_grad_(True)
