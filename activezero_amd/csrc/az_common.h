@@ -79,16 +79,13 @@ __device__ __forceinline__ void az_amax_flush(unsigned *dst, unsigned am) {
         if (am > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, am);
     }
 }
-// MODE.FP16_OVFL (bit 23 of the wave's MODE register): an fp32 -> fp16 conversion whose result overflows returns
-// +-65504 instead of +-inf, while a true inf / NaN input still converts to inf / NaN.  The f16x3 operand scale leaves a
-// factor 2-4 of headroom above the tensor's amax (az_roll_common.h); a caller that passes an amax SMALLER than the
-// tensor's true maximum (a stale attribute) therefore gets saturated hi / lo parts -- a degraded value -- not an inf
-// that the products would spread over every output of the tile.  Costs nothing per element.
-__device__ __forceinline__ void az_fp16_saturate() { __builtin_amdgcn_s_setreg(1 | (23 << 6), 1); }
-// the tensor's max |x| from its amax array; wave-uniform (call with all 64 lanes active).  Every kernel that scales an
-// operand by an amax converts it to fp16 afterwards: the saturating conversion mode is switched on here, once per wave.
+// (MODE.FP16_OVFL -- fp32 -> fp16 conversions that saturate at +-65504 instead of overflowing to inf -- is NOT used to
+// soften a too-small amax: with the bit set v_mfma_f32_16x16x32_f16 itself clamps an inf operand's products to
+// +-FLT_MAX and drops a NaN operand silently (tools/probes/fp16_ovfl_probe.hip, profiles/r05_fp16_ovfl_probe.txt), and
+// a wave cannot keep the bit on for its conversions and off for its MFMAs without pinning their order.  A stale amax
+// therefore overflows loudly -- inf / NaN in the outputs that read the element; AZ_DEBUG_AMAX=1 names the tensor.)
+// the tensor's max |x| from its amax array; wave-uniform (call with all 64 lanes active)
 __device__ __forceinline__ float az_amax_read(const float *p) {
-    az_fp16_saturate();
     unsigned v = reinterpret_cast<const unsigned *>(p)[(threadIdx.x & (AZ_AMAX_SLOTS - 1)) * AZ_AMAX_STRIDE];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));

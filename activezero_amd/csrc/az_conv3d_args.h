@@ -20,6 +20,7 @@ struct ConvArgs {
     // f16x3 launches (az_conv3d_bwd_f16): device scalars holding max |in| and max |w| (az_absmax); the kernels derive
     // the power-of-two scales from them (az_f16_scale_exp) -- the packed weights are already scaled
     const float *in_amax, *w_amax;
+    int in_split;  // f16x3: `in` is a pre-split tensor (az_roll_common.h, include/azhip.h "S2 format"); in_amax = its producer's bound
 };
 
 // bf16x6, stride-1, 32 output channels, 8x16-voxel tile per wave (az_conv3d_m128.hip)

@@ -60,7 +60,8 @@ extern "C" int az_debug_roll_stamps(unsigned long long *out10, int reset) {
 // AR: 0 = bf16x6 (three bf16 parts, six MFMAs per block), 1 = f16x3 (two scaled fp16 parts, three MFMAs: input
 // gradients only, az_roll_common.h); the slab keeps its 192-byte voxels either way (the third 64-byte part is then
 // unused), so addresses and the conflict-free swizzle are shared.
-template <int CIN, int EPI, int AR = 0>
+// PS (AR = 1 only): the input is a pre-split tensor (az_roll_common.h): staging copies its two fp16 parts.
+template <int CIN, int EPI, int AR = 0, bool PS = false>
 __global__ void __launch_bounds__(256, 2)
 conv3d_roll_kernel(const ConvArgs a) {
     constexpr int NCH = CIN / 32;            // 32-channel chunks per plane
@@ -155,10 +156,8 @@ conv3d_roll_kernel(const ConvArgs a) {
         }
         unsigned char *dst = dstbuf + (sy * R_SX + sx) * R_VB + ((((j >> 1) ^ ((sy & 1) << 1))) << 4) + (j & 1) * 8;
         if (AR) {
-            float4 v = __builtin_bit_cast(float4, raw);
-            v.x *= in_scale; v.y *= in_scale; v.z *= in_scale; v.w *= in_scale;
             uint2 hi, lo;
-            az_split2_f16x4(v, hi, lo);
+            az_stage_f16x4<PS>(raw, in_scale, hi, lo);
             *reinterpret_cast<uint2 *>(dst) = hi;
             *reinterpret_cast<uint2 *>(dst + 64) = lo;
         } else {
@@ -635,7 +634,7 @@ long long az_conv3d_roll_stats_tiles(const ConvArgs &a) {
     return (long long)a.B * nseg * a.tiles_y * a.tiles_x;
 }
 
-template <int CIN, int EPI, int AR = 0>
+template <int CIN, int EPI, int AR = 0, bool PS = false>
 static int launch_roll(ConvArgs a, hipStream_t s) {
     roll_segments(a, a.nseg, a.seg_len);
     if (EPI == 1) a.ntiles = (long long)a.B * a.nseg * a.tiles_y * a.tiles_x;
@@ -643,13 +642,19 @@ static int launch_roll(ConvArgs a, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     // the kernel addresses one batch element of a tensor through a 32-bit buffer offset
     if (!az_fits_buffer_offset((long long)a.Di * a.Hi * a.Wi * CIN * 4) || a.ntiles * 256 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI, AR>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI, AR, PS>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return az_launch_status();
 }
 
 int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, int epi, hipStream_t s) {
     if (!a.in_amax || !a.w_amax) return AZ_ENULL;
     const int e = epi ? 1 : (a.res ? 2 : 0);
+    if (a.in_split) {  // pre-split input: the input gradients of the 32 -> 32 / 32 -> 64 layers (no BatchNorm-partials epilogue)
+        if (e == 1) return AZ_EUNSUPPORTED;
+        if (cin == 32) return e == 2 ? launch_roll<32, 2, 1, true>(a, s) : launch_roll<32, 0, 1, true>(a, s);
+        if (cin == 64) return e == 2 ? launch_roll<64, 2, 1, true>(a, s) : launch_roll<64, 0, 1, true>(a, s);
+        return AZ_EUNSUPPORTED;
+    }
     if (cin == 32) return e == 1 ? launch_roll<32, 1, 1>(a, s) : e == 2 ? launch_roll<32, 2, 1>(a, s) : launch_roll<32, 0, 1>(a, s);
     if (cin == 64) return e == 1 ? launch_roll<64, 1, 1>(a, s) : e == 2 ? launch_roll<64, 2, 1>(a, s) : launch_roll<64, 0, 1>(a, s);
     return AZ_EUNSUPPORTED;

@@ -138,10 +138,8 @@ conv3d_t2roll_kernel(const ConvArgs a) {
             dst = live ? dst : slab + T2R_LDS + (tid & 7) * 8;
             dst2 = live ? dst2 : dst;
         }
-        float4 v = __builtin_bit_cast(float4, pre[it]);
-        v.x *= in_scale; v.y *= in_scale; v.z *= in_scale; v.w *= in_scale;
         uint2 hi, lo;
-        az_split2_f16x4(v, hi, lo);
+        az_stage_f16x4<PS>(pre[it], in_scale, hi, lo);
         *reinterpret_cast<uint2 *>(dst) = hi;
         *reinterpret_cast<uint2 *>(dst2) = lo;
     };

@@ -88,6 +88,32 @@ __device__ __forceinline__ void az_split2_f16x4(const float4 &v, uint2 &hi, uint
     az_split2_f16_pair(v.x, v.y, hi.x, lo.x);
     az_split2_f16_pair(v.z, v.w, hi.y, lo.y);
 }
+// ---- "pre-split" operands (round 5; include/azhip.h, "S2 format") -------------------------------------------------------
+// A tensor whose only readers are f16x3 matrix kernels can be STORED the way those kernels stage it: every aligned group
+// of four channels (16 bytes) holds  hi(c0) hi(c1) | hi(c2) hi(c3) | lo(c0) lo(c1) | lo(c2) lo(c3)  -- the two fp16 parts
+// of x * 2^k, k = az_f16_scale_exp(amax) with the amax array the producer wrote next to it -- in place of the four floats.
+// Same bytes in HBM; the consumer's staging is then a copy (two 8-byte LDS writes per piece) instead of four multiplies,
+// six conversions and four subtractions, and the bits it multiplies are the ones it would have computed itself from the
+// fp32 tensor with that amax.  The producer is the BatchNorm-backward apply pass (az_bn3d.hip), whose amax is an upper
+// BOUND of max |dx| known before the first element is written.
+// az_stage_f16x4<PS>: one staged 16-byte piece -> its (hi, lo) 8-byte halves; PS = the tensor is pre-split.
+template <bool PS>
+__device__ __forceinline__ void az_stage_f16x4(const u32x4 &raw, float scale, uint2 &hi, uint2 &lo) {
+    if (PS) {
+        hi = uint2{raw[0], raw[1]};
+        lo = uint2{raw[2], raw[3]};
+    } else {
+        float4 v = __builtin_bit_cast(float4, raw);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        az_split2_f16x4(v, hi, lo);
+    }
+}
+// the producer's side: four values (already scaled) -> the 16 bytes above
+__device__ __forceinline__ float4 az_presplit_f16x4(const float4 &v) {
+    uint2 hi, lo;
+    az_split2_f16x4(v, hi, lo);
+    return __builtin_bit_cast(float4, u32x4{hi.x, hi.y, lo.x, lo.y});
+}
 __device__ __forceinline__ unsigned short az_split2_f16_part(float x, int p) {
     const _Float16 h = (_Float16)x;
     const _Float16 l = (_Float16)(x - (float)h);

@@ -204,9 +204,11 @@ int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
  *     of the 32-deep block sums; the second is the fp16 subnormal spacing: elements more than 2^17 below A lose low bits
  *     of `lo`, an ABSOLUTE error of 2^-39 A each.  A loose bound A = 2^L a therefore costs L bits of that 2^17 range and
  *     nothing else (tests/test_gpu_f16x3_contract.py: one element 10^6 / 10^8 times the bulk; A = 2^10 a).
- *   - A < a (a stale value) is a caller error that the kernels survive: the fp32 -> fp16 conversions SATURATE at
- *     +-65504 (MODE.FP16_OVFL, az_common.h), so elements above 2-4 A are clipped -- wrong values, but finite ones.
- *     AZ_DEBUG_AMAX=1 makes the Python wrappers check every attached amax against a fresh az_absmax (synchronising).
+ *   - A < a (a stale value) is a caller error, and a loud one: elements above 2-4 A overflow fp16 and the outputs that
+ *     read them come out inf / NaN (the scale leaves a factor 2-4 of headroom: A maps to [2^14, 2^15), fp16 ends at
+ *     65504).  AZ_DEBUG_AMAX=1 makes the Python wrappers check every attached amax against a fresh az_absmax
+ *     (synchronising) and name the tensor.  A saturating conversion (MODE.FP16_OVFL) is deliberately not used: on gfx950
+ *     the same bit makes the fp16 MFMA clamp inf operands to FLT_MAX and drop NaN operands (tools/probes/fp16_ovfl_probe.hip).
  * az_absmax: the amax array of x (16-byte aligned; n > 0), zeroing included. */
 #define AZ_AMAX_SLOTS 16
 #define AZ_AMAX_STRIDE 64
