@@ -72,12 +72,16 @@ _SIGS = {
     "az_conv3d_wgrad_workspace": [_INT, _INT],
     "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 11 + [_PTR],
     "az_absmax": [_PTR, _PTR, _LL, _PTR],
+    "az_pack_f16_multi": [_PTR, _PTR, _PTR, _INT, _INT, _PTR],
     "az_conv3d_packed_floats_f16": [_INT, _INT],
+    "az_conv3d_f16_layout": [_INT, _INT, _INT],
     "az_conv3d_pack_weights_f16": [_PTR, _PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
-    "az_conv3d_fwd_f16": [_PTR] * 8 + [_INT] * 8 + [_PTR],
+    "az_conv3d_fwd_f16": [_PTR] * 5 + [_INT] + [_PTR] * 3 + [_INT] * 8 + [_PTR],
+    "az_conv3d_fwd_f16_split_ok": [_INT] * 7,
+    "az_conv3d_wgrad_f16_split_ok": [_INT] * 10,
     "az_conv3d_stats_tiles_f16": [_INT] * 7,
     "az_conv3d_fwd_stats_f16": [_PTR] * 7 + [_INT] * 7 + [_PTR],
-    "az_conv3d_wgrad_f16": [_PTR, _PTR, _LL] + [_PTR] * 4 + [_INT] * 10 + [_PTR],
+    "az_conv3d_wgrad_f16": [_PTR, _PTR, _LL] + [_PTR] * 4 + [_INT] * 11 + [_PTR],
     "az_conv3d_c1_fwd": [_PTR] * 6 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_dgrad": [_PTR] * 3 + [_INT] * 4 + [_PTR],
     "az_conv3d_c1_wgrad": [_PTR] * 5 + [_INT] * 4 + [_PTR],
@@ -86,7 +90,7 @@ _SIGS = {
     "az_bn3d_eval_affine": [_PTR] * 6 + [_C.c_float, _INT, _PTR],
     "az_bn3d_apply": [_PTR] * 5 + [_INT, _LL, _INT, _PTR, _PTR],
     "az_bn3d_bwd_workspace": [_LL, _INT],
-    "az_bn3d_bwd": [_PTR] * 6 + [_LL] + [_PTR] * 8 + [_INT, _LL, _INT, _PTR, _PTR],
+    "az_bn3d_bwd": [_PTR] * 6 + [_LL] + [_PTR] * 8 + [_INT, _LL, _INT, _PTR, _INT, _PTR],
     "az_add_relu": [_PTR] * 3 + [_INT, _LL, _PTR, _PTR],
     "az_conv2d_packed_floats": [_INT] * 4,
     "az_conv2d_pack_weights": [_PTR, _PTR] + [_INT] * 4 + [_LL, _LL] + [_INT] * 3 + [_PTR],

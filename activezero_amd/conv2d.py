@@ -78,6 +78,12 @@ def _pack_f16(weight, cin, cout, ci_real, co_real, s_out, s_in, kh, kw, flip, ca
         hit = _cache_get(_PACK2D_CACHE, key)
         if hit is not None:
             return hit[0]
+    if not cache:
+        hit = conv3d._planned_pack(weight, w, conv3d.PACK_2D_SAME, cin, cout, ci_real, co_real, s_out, s_in, kh * kw, flip,
+                                   lambda packed, w_amax: _call("az_conv2d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), cin,
+                                                                cout, ci_real, co_real, s_out, s_in, kh, kw, int(flip), _stream()))
+        if hit is not None:
+            return hit
     w_amax = _w_amax(weight, w)
     packed = torch.empty(kh * kw * cin * cout, dtype=torch.float32, device=w.device)
     _call("az_conv2d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), cin, cout, ci_real, co_real, s_out, s_in, kh, kw,
@@ -149,6 +155,11 @@ def _w_amax(weight, w):
 
 def _pack_roll_f16(weight, cin, cout, s_out, s_in, flip):
     w = _chk(weight.detach().contiguous(), "weight")
+    hit = conv3d._planned_pack(weight, w, conv3d.PACK_2D_ROLL, cin, cout, cin, cout, s_out, s_in, 9, flip,
+                               lambda packed, w_amax: _call("az_conv2d_roll_pack_f16", _p(packed), _p(w), _p(w_amax), cin, cout,
+                                                            s_out, s_in, int(flip), _stream()))
+    if hit is not None:
+        return hit
     w_amax = _w_amax(weight, w)
     packed = torch.empty(9 * cin * cout, dtype=torch.float32, device=w.device)
     _call("az_conv2d_roll_pack_f16", _p(packed), _p(w), _p(w_amax), cin, cout, s_out, s_in, int(flip), _stream())

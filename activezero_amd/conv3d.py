@@ -32,6 +32,11 @@ _PREC = {"fp32": FP32, "bf16x6": BF16X6, "f16x3": F16X3}
 # matrix kernels it is on by default with a bf16x6 forward; AZ_BWD_F16=0 (read once) keeps every gradient on the
 # forward's arithmetic, for A/B runs.
 _BWD_F16 = os.environ.get("AZ_BWD_F16", "1") != "0"
+# Pre-split gradients (round 5; include/azhip.h "S2 format"): the BatchNorm-backward apply pass writes d(raw) as the two
+# scaled fp16 parts its two readers -- the layer's f16x3 input- and weight-gradient kernels -- would otherwise compute
+# while staging, wherever BOTH of them take such an operand (az_conv3d_*_split_ok).  AZ_PRESPLIT=0 (read once): fp32
+# gradients everywhere, split by the consumers (round 4), for A/B runs.
+PRESPLIT = os.environ.get("AZ_PRESPLIT", "1") != "0"
 # include/azhip.h precision 2: the bf16x6 arithmetic on the depth-rolling 16x16x32 kernel (az_conv3d_roll.hip),
 # which reads its own packed-weight layout.  Not an arithmetic a caller chooses: _layout() routes the stride-1
 # layers with 32 output channels (the V0 layers and their input gradients) there.  AZ_CONV_ROLL=0 (read once)
@@ -316,7 +321,7 @@ def check_amax(t, am):
     """raise if the amax array `am` is below the largest finite magnitude of t (a stale attribute)"""
     fresh = t.new_empty(AMAX_SLOTS)
     _call("az_absmax", _p(fresh), _p(t), t.numel(), _stream())
-    have, true = float(am.max()), float(fresh.max())
+    have, true = float(am[::64].max()), float(fresh[::64].max())  # (the slots: every 64th float of an amax array)
     if not have >= true:
         raise RuntimeError(f"stale amax: {have:.6g} attached to a tensor whose largest finite magnitude is {true:.6g} "
                            "(written through a raw pointer or .data without conv3d._touched / a fresh conv3d.absmax?)")
@@ -335,6 +340,196 @@ def absmax(t):
             _call("az_absmax", _p(am), _p(t), t.numel(), _stream())
         _set_amax(t, am)
     return am
+
+
+# ---- pack plan (round 5): every f16x3 weight image of a model in ONE launch per optimizer step ----------------------------
+# A training step used to pack each convolution weight twice (forward image, flipped / swapped input-gradient image), one
+# launch and one allocation each: ~175 launches of ~4 us per step on the main stream.  The plan remembers, per device, which
+# images the registered parameters were asked for (recorded by the first step's per-call packs), keeps ONE persistent buffer
+# per image and a descriptor table on the device, and `prepack` rewrites all of them with az_pack_f16_multi when the
+# parameters' version counters have moved.  _pack_f16 (here and in conv2d.py) then returns the plan's buffer.
+#   * persistent buffers are safe in stream order: only main-stream kernels (forward, input gradient) read packed images,
+#     and the next step's prepack is enqueued behind them on the same stream;
+#   * only tensors registered through prepack() -- live nn.Parameters, held by weak reference -- have entries: derived
+#     weights (the merged kernels of K3', DataParallel replicas) change address every step and keep the per-call route;
+#   * an entry is valid for one (address, version counter): optimizer steps and load_state_dict write in place and bump it.
+PACK_2D_SAME, PACK_2D_ROLL, PACK_3D_GATHER, PACK_3D_ROLL = 0, 1, 2, 3
+_PLAN_ON = os.environ.get("AZ_PACK_PLAN", "1") != "0"  # (read once) 0: every image packed by its own launch, as in round 4
+
+
+class _PackEntry:
+    __slots__ = ("wref", "kind", "cin", "cout", "ci_real", "co_real", "s_co", "s_ci", "taps", "flip", "packed", "amax",
+                 "version", "index")
+
+
+class PackPlan:
+    """the images of one device"""
+    DESC_BYTES = 72  # sizeof(AzPackDesc): 3 pointers, 2 long long, 8 ints
+
+    def __init__(self, device):
+        self.device = device
+        self.lock = threading.RLock()
+        self.registered = {}   # data_ptr -> weakref of the parameter
+        self.entries = {}      # (data_ptr, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip) -> _PackEntry
+        self.amax_rows = {}    # data_ptr -> (row tensor [AMAX_SLOTS], weakref)
+        self.amax_blocks = []  # [tensor [256, AMAX_SLOTS], next row]
+        self.table = None      # (descs, block_desc, first_block, nd, nblocks, entry list) on the device
+        self.launches = 0      # az_pack_f16_multi launches so far (tests)
+
+    # -- weight amax rows: persistent, so that the descriptor table stays valid across steps
+    def amax_row(self, w):
+        ptr = w.data_ptr()
+        hit = self.amax_rows.get(ptr)
+        if hit is not None and hit[1]() is not None:
+            return hit[0]
+        if not self.amax_blocks or self.amax_blocks[-1][1] >= self.amax_blocks[-1][0].shape[0]:
+            self.amax_blocks.append([torch.zeros(256, AMAX_SLOTS, dtype=torch.float32, device=self.device), 0])
+        blk = self.amax_blocks[-1]
+        row = blk[0][blk[1]]
+        blk[1] += 1
+        return row
+
+    def alive(self, ptr):
+        r = self.registered.get(ptr)
+        return r is not None and r() is not None
+
+    def purge(self):
+        dead = [p for p, r in self.registered.items() if r() is None]
+        if dead:
+            dead = set(dead)
+            for p in dead:
+                del self.registered[p]
+                self.amax_rows.pop(p, None)
+            self.entries = {k: e for k, e in self.entries.items() if k[0] not in dead}
+            self.table = None
+
+    def lookup(self, weight, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip):
+        """(entry, fresh): the entry of this image of a registered live parameter (created on first request), and whether its
+        buffer already holds the image of the parameter's current version; None for unregistered tensors"""
+        ptr = weight.data_ptr()
+        with self.lock:
+            if not self.alive(ptr):
+                return None, False
+            key = (ptr, kind, cin, cout, ci_real, co_real, int(s_co), int(s_ci), taps, bool(flip))
+            e = self.entries.get(key)
+            if e is None:
+                e = _PackEntry()
+                e.wref, e.kind, e.cin, e.cout, e.ci_real, e.co_real = self.registered[ptr], kind, cin, cout, ci_real, co_real
+                e.s_co, e.s_ci, e.taps, e.flip = int(s_co), int(s_ci), taps, bool(flip)
+                e.packed = torch.empty(taps * cin * cout, dtype=torch.float32, device=self.device)  # two fp16 parts per weight
+                e.amax, e.version = None, -1
+                self.entries[key] = e
+                self.table = None  # rebuilt at the next prepack
+            return e, e.version == weight._version
+
+    def _build_table(self, todo):
+        import numpy as np
+        nd = len(todo)
+        raw = np.zeros(nd * self.DESC_BYTES, dtype=np.uint8)
+        q = raw.view(np.int64).reshape(nd, self.DESC_BYTES // 8)
+        ints = raw.view(np.int32).reshape(nd, self.DESC_BYTES // 4)
+        block_desc, first = [], []
+        nblocks = 0
+        for i, e in enumerate(todo):
+            w = e.wref()
+            q[i, 0], q[i, 1], q[i, 2] = e.packed.data_ptr(), w.data_ptr(), e.amax.data_ptr()
+            q[i, 3], q[i, 4] = e.s_co, e.s_ci
+            ints[i, 10:17] = (e.kind, e.cin, e.cout, e.ci_real, e.co_real, e.taps, int(e.flip))
+            nb = (2 * e.taps * e.cin * e.cout + 255) // 256
+            first.append(nblocks)
+            block_desc.append(np.full(nb, i, dtype=np.int32))
+            nblocks += nb
+        dev = self.device
+        self.table = (torch.from_numpy(raw).to(dev), torch.from_numpy(np.concatenate(block_desc)).to(dev),
+                      torch.tensor(first, dtype=torch.int32, device=dev), nd, nblocks, list(todo))
+
+    def prepack(self, weights):
+        """register `weights` (nn.Parameters) and bring every recorded image of theirs up to their current version in one
+        launch; the amax arrays of all of them in three (prime_weight_amax)"""
+        with self.lock:
+            self.purge()
+            import weakref
+            for w in weights:
+                if w is None or not w.is_cuda or w.dtype != torch.float32 or w.device != self.device:
+                    continue
+                r = self.registered.get(w.data_ptr())
+                if r is None or r() is not w:
+                    self.registered[w.data_ptr()] = weakref.ref(w)
+            stale = [e for e in self.entries.values() if e.wref() is not None and e.version != e.wref()._version]
+            if not stale:
+                return
+            with torch.no_grad(), torch.cuda.device(self.device):
+                # amax rows of the weights behind the stale images (persistent rows: slot 0 rewritten in place)
+                ws = {}
+                for e in stale:
+                    w = e.wref()
+                    ws[w.data_ptr()] = w
+                wl = list(ws.values())
+                rows = []
+                for w in wl:
+                    row = self.amax_row(w)
+                    self.amax_rows[w.data_ptr()] = (row, self.registered[w.data_ptr()])
+                    rows.append(row)
+                maxes = torch._foreach_norm([w.detach() for w in wl], float("inf"))
+                torch._foreach_copy_([r[0:1] for r in rows], [m.reshape(1) for m in maxes])
+                for w, row in zip(wl, rows):
+                    _cache_put(_W_AMAX, (w.data_ptr(), w._version, w.device.index, w.numel()), (row, w), 512)
+                for e in stale:
+                    e.amax = self.amax_rows[e.wref().data_ptr()][0]
+                todo = list(self.entries.values())
+                if self.table is None or self.table[5] != todo or any(e.amax is None for e in todo):
+                    todo = [e for e in todo if e.wref() is not None and e.amax is not None]
+                    self._build_table(todo)
+                descs, block_desc, first, nd, nblocks, elist = self.table
+                if all(e.wref() is not None for e in elist):
+                    _call("az_pack_f16_multi", _p(descs), _p(block_desc), _p(first), nd, nblocks, _stream())
+                    self.launches += 1
+                    for e in elist:
+                        e.version = e.wref()._version
+
+
+_PLANS = {}
+
+
+def pack_plan(device):
+    with _CACHE_LOCK:
+        p = _PLANS.get(device)
+        if p is None:
+            p = _PLANS[device] = PackPlan(device)
+        return p
+
+
+def prepack(weights):
+    """start of a training forward pass: all f16x3 images of these parameters in one launch (PackPlan)"""
+    ws = [w for w in weights if w is not None and w.is_cuda]
+    if _PLAN_ON and ws:
+        pack_plan(ws[0].device).prepack(ws)
+
+
+def _planned_pack(weight, w, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip, pack_now):
+    """the plan's (buffer, amax) for this image of a registered parameter, packed by `pack_now(packed, w_amax)` -- the
+    per-tensor launch -- when the plan has not brought it up to date (first step, or no prepack this step); None for tensors
+    the plan does not own"""
+    if not _PLAN_ON or not w.is_cuda:
+        return None
+    plan = pack_plan(w.device)
+    e, fresh = plan.lookup(weight, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip)
+    if e is None:
+        return None
+    if not fresh:
+        with plan.lock:
+            wkey = (weight.data_ptr(), weight._version, weight.device.index, weight.numel())
+            hit = _cache_get(_W_AMAX, wkey)
+            if hit is not None:
+                w_amax = hit[0]
+            else:
+                w_amax = absmax(w)
+                _cache_put(_W_AMAX, wkey, (w_amax, weight), 512)
+            pack_now(e.packed, w_amax)
+            e.amax, e.version = w_amax, weight._version
+            if plan.table is not None and e in plan.table[5]:
+                plan.table = None  # (this entry's amax pointer changed: the table is rebuilt with a persistent row next prepack)
+    return e.packed, e.amax
 
 
 def prime_weight_amax(weights):
@@ -368,6 +563,14 @@ def _pack_f16(weight, op_cin, op_cout, stride_out, stride_in, flip, mode, cache=
         hit = _cache_get(_PACK_CACHE, key)
         if hit is not None:
             return hit[0]
+    if not cache:
+        roll = _lib.lib().az_conv3d_f16_layout(mode, op_cin, op_cout) == PACK_3D_ROLL
+        hit = _planned_pack(weight, w, PACK_3D_ROLL if roll else PACK_3D_GATHER, op_cin, op_cout, op_cin, op_cout,
+                            stride_out, stride_in, 27, flip,
+                            lambda packed, w_amax: _call("az_conv3d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), op_cin,
+                                                         op_cout, stride_out, stride_in, int(flip), mode, _stream()))
+        if hit is not None:
+            return hit
     wkey = (weight.data_ptr(), weight._version, weight.device.index, weight.numel())
     hit = _cache_get(_W_AMAX, wkey)
     if hit is not None:
@@ -394,6 +597,12 @@ def _f16_dgrad_ok(mode, cin, cout):
     return _f16_fwd_ok(dual, cout, cin)
 
 
+def _is_split(t):
+    """the tensor holds pre-split fp16 pairs, not floats (set by _ConvBN.backward on the d(raw) it asked az_bn3d_bwd to
+    write that way; the amax attached to it is the producer's bound)"""
+    return getattr(t, "az_split", False)
+
+
 def _run_f16(x, packed, w_amax, mode, cin, cout, scale=None, shift=None, residual=None, relu=False, stats=False,
              tag="conv3d"):
     b, d, h, w, c = _dims(x)
@@ -402,7 +611,10 @@ def _run_f16(x, packed, w_amax, mode, cin, cout, scale=None, shift=None, residua
     out = x.new_empty(b, do, ho, wo, cout)
     name = f"{tag}_m{mode}_{cin}_{cout}"
     flops = _conv_flops(b, do * ho * wo, cin, cout, mode)
-    x_amax = absmax(x)
+    split = _is_split(x)
+    x_amax = _get_amax(x) if split else absmax(x)
+    if split and (stats or x_amax is None):
+        raise RuntimeError("a pre-split tensor reached a launch that cannot read it")
     if stats:
         ntiles = _lib.lib().az_conv3d_stats_tiles_f16(mode, b, cin, cout, d, h, w)
         if ntiles <= 0:
@@ -413,7 +625,7 @@ def _run_f16(x, packed, w_amax, mode, cin, cout, scale=None, shift=None, residua
                   mode, b, cin, cout, d, h, w, _stream())
         return out, part, cnt, ntiles
     with profiler.scope(name, flops=flops, peak=_PEAK_F16):
-        _call("az_conv3d_fwd_f16", _p(out), _p(x), _p(packed), _p(x_amax), _p(w_amax), _p(scale), _p(shift),
+        _call("az_conv3d_fwd_f16", _p(out), _p(x), _p(packed), _p(x_amax), _p(w_amax), int(split), _p(scale), _p(shift),
               _p(residual), int(relu), mode, b, cin, cout, d, h, w, _stream())
     return out
 
@@ -465,12 +677,17 @@ def _wgrad_f16(coarse, fine, stride, cm, cn, tag, sink=None):
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
     ws_bytes = _lib.lib().az_conv3d_wgrad_workspace(cm, cn)
     am_c, am_f = _get_amax(coarse), _get_amax(fine)
+    mask = (1 if _is_split(coarse) else 0) | (2 if _is_split(fine) else 0)
+    if (mask & 1 and am_c is None) or (mask & 2 and am_f is None):
+        raise RuntimeError("a pre-split tensor without its producer's amax")
     with overlap.scope(sink, coarse, fine, gw, am_c, am_f):
         ws = coarse.new_empty(ws_bytes // 4)
-        am_c, am_f = absmax(coarse), absmax(fine)  # (a pass over the tensor only when its producer attached none)
+        # (a pass over the tensor only when its producer attached none)
+        am_c = am_c if mask & 1 else absmax(coarse)
+        am_f = am_f if mask & 2 else absmax(fine)
         with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
                             peak=_PEAK_F16):
-            _call("az_conv3d_wgrad_f16", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), _p(am_c), _p(am_f), stride,
+            _call("az_conv3d_wgrad_f16", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), _p(am_c), _p(am_f), mask, stride,
                   b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
         if sink is not None and sink.live:
             sink.keep.extend((am_c, am_f))
@@ -523,6 +740,32 @@ def _weight_grad(x, dy, mode, cin, cout, precision, sink=None):
     if mode == DECONV_S2:
         return _wgrad(x, dy, 2, cin, cout, "deconv", precision, sink)
     return _wgrad(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", precision, sink)
+
+
+def _presplit_ok(x, raw, mode, cin, cout, need_gx, need_gw):
+    """d(raw) of this layer may be written pre-split: every kernel that will read it -- the f16x3 input gradient (a forward
+    launch of the dual map on d(raw)) and the f16x3 weight gradient -- stages such an operand by copy.  Mirrors the
+    routing of _input_grad / _weight_grad; the library answers for its own kernels (az_conv3d_*_split_ok)."""
+    lib = _lib.lib()
+    b, d, h, w, _ = raw.shape
+    if need_gx:
+        if not (_f16_dgrad_ok(mode, cin, cout) and (_fits32(raw, cin, cout) or not (mode == CONV_S1 and cin == 32)) and
+                (mode != CONV_S2 or _fits32_transposed(raw, cout, cin))):
+            return False
+        dual = {CONV_S1: CONV_S1, CONV_S2: DECONV_S2, DECONV_S2: CONV_S2}[mode]
+        if lib.az_conv3d_fwd_f16_split_ok(dual, b, cout, cin, d, h, w) != 1:
+            return False
+    if need_gw:
+        if not _f16_wgrad_ok(mode, cin, cout):
+            return False
+        _, dx_, hx, wx, _ = x.shape
+        if mode == DECONV_S2:   # coarse = x, fine = d(raw)
+            ok, bit = lib.az_conv3d_wgrad_f16_split_ok(2, b, cin, cout, dx_, hx, wx, d, h, w), 2
+        else:                   # coarse = d(raw), fine = x
+            ok, bit = lib.az_conv3d_wgrad_f16_split_ok(1 if mode == CONV_S1 else 2, b, cout, cin, d, h, w, dx_, hx, wx), 1
+        if not ok & bit:
+            return False
+    return bool(need_gx or need_gw)
 
 
 class _ConvBN(torch.autograd.Function):
@@ -620,12 +863,17 @@ class _ConvBN(torch.autograd.Function):
                 ws = gy.new_empty(ws_bytes // 4)
                 # f16x3 gradients: max |dx_raw| (the operand scale) is taken by the kernel that writes dx_raw
                 dx_amax = gy.new_empty(AMAX_SLOTS) if arith.bwd16 else None
+                # ... and dx_raw itself is written pre-split where both of its readers stage such a tensor by copy
+                split = arith.bwd16 and PRESPLIT and _presplit_ok(x, raw, mode, cin, cout, ctx.needs_input_grad[0],
+                                                                  ctx.needs_input_grad[1])
                 with profiler.scope(f"bn3d_bwd_{cout}", bytes=4.0 * raw.numel() * (7 if (relu and y is not None) else 5), bound="hbm"):
                     _call("az_bn3d_bwd", _p(dx_raw), _p(dz), _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes,
                           _p(gy), _p(y), _p(raw), _p(mean), _p(invstd), _p(gamma.detach()), _p(scale), _p(shift),
-                          int(relu), nvox, cout, _p(dx_amax), _stream())
+                          int(relu), nvox, cout, _p(dx_amax), int(split), _stream())
                 if dx_amax is not None:
                     _set_amax(dx_raw, dx_amax)
+                if split:
+                    dx_raw.az_split = True
                 g_res = (dz if relu else gy) if has_res else None
             gx = gw = None
             if ctx.needs_input_grad[0]:

@@ -16,7 +16,7 @@
 //   az_bn3d_bwd_apply: dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); optional dz out.
 #include <stdlib.h>
 
-#include "az_common.h"
+#include "az_roll_common.h"
 #include "az_options.h"
 
 // Block-wide fp64 sum in two barriers: DPP/shuffle inside each wave, one LDS slot per wave, then every thread
@@ -214,7 +214,7 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
                      const float *__restrict__ y, const float *__restrict__ x,
                      const float *__restrict__ mean, const float *__restrict__ invstd,
                      const float *__restrict__ scale, const float *__restrict__ shift, int relu,
-                     long long nvox, unsigned *__restrict__ amax_zero = nullptr) {
+                     long long nvox, unsigned *__restrict__ amax_zero = nullptr, unsigned *__restrict__ pmax = nullptr) {
     // (the apply kernel that follows in the stream takes max |dx| into this word with atomicMax: start it at zero)
     if (amax_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < AZ_AMAX_SLOTS) amax_zero[threadIdx.x * AZ_AMAX_STRIDE] = 0u;
     // thread t owns channel quad (t % C4) and voxel lane (t / C4); C4 divides 256
@@ -236,6 +236,9 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
     const float4 mu = reinterpret_cast<const float4 *>(mean)[c4];
     const float4 is = reinterpret_cast<const float4 *>(invstd)[c4];
     float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+    // `pmax` given (the apply pass will write dx PRE-SPLIT, az_roll_common.h): also the largest finite |dz| and |xhat| per
+    // channel, as bit patterns -- what the apply pass bounds max |dx| with before it writes its first element
+    uint4 mg = make_uint4(0, 0, 0, 0), mx = make_uint4(0, 0, 0, 0);
     auto body = [&](const float4 gin, const float4 xx, const float4 yin, float4 &t1, float4 &t2) {
         float4 g = gin;
         if (relu) {
@@ -244,9 +247,15 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
+        const float4 xh = make_float4((xx.x - mu.x) * is.x, (xx.y - mu.y) * is.y, (xx.z - mu.z) * is.z, (xx.w - mu.w) * is.w);
         t1.x += g.x; t1.y += g.y; t1.z += g.z; t1.w += g.w;
-        t2.x += g.x * ((xx.x - mu.x) * is.x); t2.y += g.y * ((xx.y - mu.y) * is.y);
-        t2.z += g.z * ((xx.z - mu.z) * is.z); t2.w += g.w * ((xx.w - mu.w) * is.w);
+        t2.x += g.x * xh.x; t2.y += g.y * xh.y; t2.z += g.z * xh.z; t2.w += g.w * xh.w;
+        if (pmax) {
+            mg.x = max(mg.x, az_finite_abs_bits(g.x)); mg.y = max(mg.y, az_finite_abs_bits(g.y));
+            mg.z = max(mg.z, az_finite_abs_bits(g.z)); mg.w = max(mg.w, az_finite_abs_bits(g.w));
+            mx.x = max(mx.x, az_finite_abs_bits(xh.x)); mx.y = max(mx.y, az_finite_abs_bits(xh.y));
+            mx.z = max(mx.z, az_finite_abs_bits(xh.z)); mx.w = max(mx.w, az_finite_abs_bits(xh.w));
+        }
     };
     // two voxels per thread in flight (the grid is capped so that the partials stay L2-sized: bn_bwd_apply_kernel)
     const long long stride = (long long)gridDim.x * VPB;
@@ -296,6 +305,29 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
         p[0] = s1.x; p[1] = s2.x; p[2] = s1.y; p[3] = s2.y;
         p[4] = s1.z; p[5] = s2.z; p[6] = s1.w; p[7] = s2.w;
     }
+    if (pmax) {  // the same reduction with max, rows laid out like the sums' ([block][C][2]: max |dz|, max |xhat|)
+#pragma unroll
+        for (int off = C4; off < 64; off <<= 1) {
+            mg.x = max(mg.x, (unsigned)__shfl_xor((int)mg.x, off)); mg.y = max(mg.y, (unsigned)__shfl_xor((int)mg.y, off));
+            mg.z = max(mg.z, (unsigned)__shfl_xor((int)mg.z, off)); mg.w = max(mg.w, (unsigned)__shfl_xor((int)mg.w, off));
+            mx.x = max(mx.x, (unsigned)__shfl_xor((int)mx.x, off)); mx.y = max(mx.y, (unsigned)__shfl_xor((int)mx.y, off));
+            mx.z = max(mx.z, (unsigned)__shfl_xor((int)mx.z, off)); mx.w = max(mx.w, (unsigned)__shfl_xor((int)mx.w, off));
+        }
+        __shared__ uint4 q1[4][C4], q2[4][C4];
+        if (lane < C4) { q1[wave][lane] = mg; q2[wave][lane] = mx; }
+        __syncthreads();
+        if (threadIdx.x < C4) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const uint4 a = q1[k][c4], b = q2[k][c4];
+                mg.x = max(mg.x, a.x); mg.y = max(mg.y, a.y); mg.z = max(mg.z, a.z); mg.w = max(mg.w, a.w);
+                mx.x = max(mx.x, b.x); mx.y = max(mx.y, b.y); mx.z = max(mx.z, b.z); mx.w = max(mx.w, b.w);
+            }
+            unsigned *p = pmax + ((size_t)blockIdx.y * gridDim.x * C + (size_t)blockIdx.x * C + c4 * 4) * 2;
+            p[0] = mg.x; p[1] = mx.x; p[2] = mg.y; p[3] = mx.y;
+            p[4] = mg.z; p[5] = mx.z; p[6] = mg.w; p[7] = mx.w;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -344,9 +376,14 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
                     const float *__restrict__ scale, const float *__restrict__ shift, int relu,
                     long long total4, const float *__restrict__ partial, int nblocks, const float *__restrict__ gamma,
                     float *__restrict__ dgamma, float *__restrict__ dbeta, double nvox,
-                    unsigned *__restrict__ amax = nullptr) {
+                    unsigned *__restrict__ amax = nullptr, const unsigned *__restrict__ pmax = nullptr) {
     constexpr int C4 = C / 4;
     unsigned am = 0;  // max |dx| of this thread, as a bit pattern (az_absmax.hip): the f16x3 scale of dx's consumers
+    // `pmax` given: dx is written PRE-SPLIT (az_roll_common.h) -- the two fp16 parts of dx * 2^k in place of the float.  k
+    // must be known before the first element is written: from  |dx| <= |k0| (max |dz| + |k1| + max |xhat| |k2|)  per channel,
+    // the reduce pass's maxima merged like its sums; the bound (not the true maximum) is what `amax` receives, so that the
+    // consumers derive the same k.  Every block computes the same value from the same partials.
+    float split_scale = 1.f;
     __shared__ float smu[C], sis[C], k0[C], k1[C], k2[C], ssc[C], ssh[C];
     const bool remask = relu && scale != nullptr;  // see bn_bwd_reduce_kernel
     const int grp = blockIdx.y;
@@ -408,6 +445,43 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
             }
         }
         if (writer && grp == 0 && threadIdx.x < C) { dbeta[threadIdx.x] = (float)db_tot; dgamma[threadIdx.x] = (float)dg_tot; }
+        if (pmax) {  // (one statistic group only: az_bn3d_bwd rejects the combination otherwise)
+            const uint4 *m4 = reinterpret_cast<const uint4 *>(pmax);
+            uint4 m = make_uint4(0, 0, 0, 0);
+            for (int blk = r; blk < nblocks; blk += ROWS) {
+                const uint4 v = m4[(size_t)blk * COLS + j];
+                m.x = max(m.x, v.x); m.y = max(m.y, v.y); m.z = max(m.z, v.z); m.w = max(m.w, v.w);
+            }
+#pragma unroll
+            for (int off = COLS; off < 64; off <<= 1) {
+                m.x = max(m.x, (unsigned)__shfl_xor((int)m.x, off)); m.y = max(m.y, (unsigned)__shfl_xor((int)m.y, off));
+                m.z = max(m.z, (unsigned)__shfl_xor((int)m.z, off)); m.w = max(m.w, (unsigned)__shfl_xor((int)m.w, off));
+            }
+            __syncthreads();  // (k0 / k1 / k2 of every channel written; wsum free again)
+            if ((threadIdx.x & 63) < COLS) {
+                wsum[wave][4 * j + 0] = __uint_as_float(m.x); wsum[wave][4 * j + 1] = __uint_as_float(m.y);
+                wsum[wave][4 * j + 2] = __uint_as_float(m.z); wsum[wave][4 * j + 3] = __uint_as_float(m.w);
+            }
+            __syncthreads();
+            float bnd = 0.f;
+            if (threadIdx.x < C) {
+                const int c = threadIdx.x;
+                const float gm = fmaxf(fmaxf(wsum[0][2 * c], wsum[1][2 * c]), fmaxf(wsum[2][2 * c], wsum[3][2 * c]));
+                const float xm = fmaxf(fmaxf(wsum[0][2 * c + 1], wsum[1][2 * c + 1]), fmaxf(wsum[2][2 * c + 1], wsum[3][2 * c + 1]));
+                // (1 + 2^-20: the rounding of the apply expression itself)
+                bnd = fabsf(k0[c]) * (gm + fabsf(k1[c]) + xm * fabsf(k2[c])) * 1.000001f;
+                bnd = bnd < __builtin_inff() ? bnd : 0.f;  // (a non-finite coefficient: every element of that channel is, too)
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, off));
+            __shared__ float bwave[4];
+            if ((threadIdx.x & 63) == 0) bwave[wave] = bnd;
+            __syncthreads();
+            bnd = fmaxf(fmaxf(bwave[0], bwave[1]), fmaxf(bwave[2], bwave[3]));
+            split_scale = az_pow2(az_f16_scale_exp(bnd));
+            // slot 0 of the amax array (the reduce kernel zeroed all sixteen): the bound
+            if (writer && grp == 0 && threadIdx.x == 0 && amax) amax[0] = __float_as_uint(bnd);
+        }
     }
     __syncthreads();
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total4; i += gridDim.x * 256LL) {
@@ -428,10 +502,14 @@ bn_bwd_apply_kernel(float4 *__restrict__ dx, float4 *__restrict__ dz_out,
         o.y = k0[c + 1] * (g.y - k1[c + 1] - (xx.y - smu[c + 1]) * sis[c + 1] * k2[c + 1]);
         o.z = k0[c + 2] * (g.z - k1[c + 2] - (xx.z - smu[c + 2]) * sis[c + 2] * k2[c + 2]);
         o.w = k0[c + 3] * (g.w - k1[c + 3] - (xx.w - smu[c + 3]) * sis[c + 3] * k2[c + 3]);
-        bn_st4<NT>(&dx[i], o);
-        az_amax_acc(am, o);
+        if (pmax) {
+            bn_st4<NT>(&dx[i], az_presplit_f16x4(make_float4(o.x * split_scale, o.y * split_scale, o.z * split_scale, o.w * split_scale)));
+        } else {
+            bn_st4<NT>(&dx[i], o);
+            az_amax_acc(am, o);
+        }
     }
-    if (amax) az_amax_flush(amax, am);
+    if (amax && !pmax) az_amax_flush(amax, am);
 }
 
 // y = relu?(a + b) and its masked backward, for the plain residual sums of psmnet_3.py
@@ -593,18 +671,22 @@ extern "C" int az_bn3d_apply(float *y, const float *x, const float *scale, const
     return az_launch_status();
 }
 
+static long long bn3d_bwd_blocks(long long nvox, int C) {
+    const int vpb = 256 / (C / 4);
+    return az_grid_for((nvox + vpb - 1) / vpb * 256, 256);
+}
+// (the sums' rows, then -- split_out launches -- as many rows of per-channel maxima)
 extern "C" long long az_bn3d_bwd_workspace(long long nvox, int C) {
     if (nvox <= 0 || (C != 32 && C != 64 && C != 128)) return AZ_EINVAL;
-    const int vpb = 256 / (C / 4);
-    const long long blocks = az_grid_for((nvox + vpb - 1) / vpb * 256, 256);
-    return blocks * C * 2 * (long long)sizeof(float);
+    return 2 * bn3d_bwd_blocks(nvox, C) * C * 2 * (long long)sizeof(float);
 }
 
 extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
                            float *workspace, long long workspace_bytes, const float *dy,
                            const float *y, const float *x, const float *mean,
                            const float *invstd, const float *gamma, const float *scale,
-                           const float *shift, int relu, long long nvox, int C, float *dx_amax, void *stream) {
+                           const float *shift, int relu, long long nvox, int C, float *dx_amax, int split_out,
+                           void *stream) {
     unsigned *const am = reinterpret_cast<unsigned *>(dx_amax);
     AZ_REQUIRE_PTR(dx); AZ_REQUIRE_PTR(dgamma); AZ_REQUIRE_PTR(dbeta); AZ_REQUIRE_PTR(coef);
     AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(dy); AZ_REQUIRE_PTR(x); AZ_REQUIRE_PTR(mean);
@@ -614,16 +696,18 @@ extern "C" int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta
     const long long need = az_bn3d_bwd_workspace(nvox, C);
     if (need < 0) return (int)need;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
-    int blocks = (int)(need / (C * 2 * sizeof(float)));
+    int blocks = (int)bn3d_bwd_blocks(nvox, C);
     const long long total4 = nvox * C / 4;
     hipStream_t s = az_stream(stream);
     const bool nt = total4 * 16 >= BN_NT_BYTES;
+    if (split_out && (!am || !bn_bwd_fused())) return split_out && !am ? AZ_ENULL : AZ_EUNSUPPORTED;  // (the fused two-launch form only)
     if (bn_bwd_fused()) {
         blocks = bn_bwd_fused_blocks(blocks, C);
-        BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox, am);
+        unsigned *const pmax = split_out ? reinterpret_cast<unsigned *>(workspace) + (size_t)blocks * C * 2 : nullptr;
+        BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox, am, pmax);
         BN_LAUNCH(bn_bwd_apply_kernel, C, nt, dim3(bn_bwd_apply_grid(total4)), s, (float4 *)dx, (float4 *)dz_out, (const float4 *)dy,
                   (const float4 *)y, (const float4 *)x, mean, invstd, coef, scale, shift, relu, total4,
-                  (const float *)workspace, blocks, gamma, dgamma, dbeta, (double)nvox, am);
+                  (const float *)workspace, blocks, gamma, dgamma, dbeta, (double)nvox, am, (const unsigned *)pmax);
         return az_launch_status();
     }
     BN_LAUNCH(bn_bwd_reduce_kernel, C, nt, dim3(blocks), s, workspace, dy, y, x, mean, invstd, scale, shift, relu, nvox, am);

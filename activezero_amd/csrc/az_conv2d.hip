@@ -25,7 +25,7 @@
 // Epilogue: y = acc (* scale[c] + shift[c]) (+ residual) (ReLU) -- training stores the raw sums; an
 // eval-mode caller folds BatchNorm here.  Output pixel stride is a parameter, so a producer can write
 // straight into a channel slice of a wider tensor.
-#include "az_roll_common.h"
+#include "az_pack_f16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -377,25 +377,13 @@ conv2d_pack_kernel(unsigned short *__restrict__ dst, const float *__restrict__ s
     dst[idx] = az_split3_part(x, p);  // round-to-nearest split, as the activations' (az_common.h)
 }
 
-// f16x3 image: [tap][cin/16][cout/32][part 2][64 lanes][8] fp16 of w * 2^k (k from max |w|)
+// f16x3 image: [tap][cin/16][cout/32][part 2][64 lanes][8] fp16 of w * 2^k (k from max |w|): az_pack_f16.h, AZ_PACK_2D_SAME
 __global__ void __launch_bounds__(256)
-conv2d_pack_f16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax,
-                       int cin, int cout, int ci_real, int co_real, long long s_co, long long s_ci, int taps, int flip,
-                       long long total) {
+conv2d_pack_f16_kernel(const AzPackDesc d, long long total) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const float scale = az_pow2(az_f16_scale_exp(az_amax_read(amax)));  // (before the early exit: a wave-wide read)
+    const float scale = az_pow2(az_f16_scale_exp(az_amax_read(d.amax)));  // (before the early exit: a wave-wide read)
     if (idx >= total) return;
-    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
-    long long r = idx >> 9;
-    const int p = (int)(r & 1); r >>= 1;
-    const int nt = cout / 32, nch = cin / 16;
-    const int n = (int)(r % nt); r /= nt;
-    const int cc = (int)(r % nch);
-    const int t = (int)(r / nch);
-    const int co = n * 32 + (lane & 31), ci = cc * 16 + 8 * (lane >> 5) + j;
-    float x = 0.f;
-    if (co < co_real && ci < ci_real) x = src[co * s_co + ci * s_ci + (flip ? taps - 1 - t : t)];
-    dst[idx] = az_split2_f16_part(x * scale, p);
+    reinterpret_cast<unsigned short *>(d.dst)[idx] = az_pack_f16_elem(d, idx, scale);
 }
 
 extern "C" int az_conv2d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
@@ -405,9 +393,10 @@ extern "C" int az_conv2d_pack_weights_f16(float *packed, const float *w, const f
     if (cin <= 0 || cout <= 0 || cin % 16 || cout % 32 || kh <= 0 || kw <= 0) return AZ_EUNSUPPORTED;
     AZ_REQUIRE(ci_real > 0 && ci_real <= cin && co_real > 0 && co_real <= cout);
     const long long total = (long long)kh * kw * cin * cout * 2;
-    hipLaunchKernelGGL(conv2d_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, az_stream(stream),
-                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, ci_real, co_real, stride_out,
-                       stride_in, kh * kw, flip, total);
+    AzPackDesc d{};
+    d.dst = packed; d.src = w; d.amax = w_amax; d.s_co = stride_out; d.s_ci = stride_in; d.kind = AZ_PACK_2D_SAME;
+    d.cin = cin; d.cout = cout; d.ci_real = ci_real; d.co_real = co_real; d.taps = kh * kw; d.flip = flip;
+    hipLaunchKernelGGL(conv2d_pack_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, az_stream(stream), d, total);
     return az_launch_status();
 }
 

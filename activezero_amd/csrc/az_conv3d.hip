@@ -33,6 +33,7 @@
 
 #include "az_roll_common.h"
 #include "az_options.h"
+#include "az_launch_math.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -759,6 +760,12 @@ static bool f16_on_roll(int mode, int cout) { return mode == 0 && cout == 32; }
 // the transposed 64 -> 32 layers on the depth-rolling kernel of az_conv3d_t2roll.hip (AZ_CONV_T2ROLL=0: az_conv3d_t2.hip)
 static bool f16_on_t2roll(int mode, int cin, int cout) { return mode == 2 && cin == 64 && cout == 32 && az_options().conv_t2roll != 0; }
 
+// the layout az_conv3d_pack_weights_f16 writes for (mode, cin, cout): AZ_PACK_3D_ROLL or AZ_PACK_3D_GATHER (az_pack_f16_multi's `kind`)
+extern "C" int az_conv3d_f16_layout(int mode, int cin, int cout) {
+    if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return AZ_EUNSUPPORTED;
+    return (f16_on_roll(mode, cout) || f16_on_t2roll(mode, cin, cout)) ? AZ_PACK_3D_ROLL : AZ_PACK_3D_GATHER;
+}
+
 extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
                                           long long stride_out, long long stride_in, int flip, int mode, void *stream) {
     AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
@@ -781,14 +788,26 @@ static int conv_f16_dispatch(ConvArgs &a, int mode, int cin, int cout, int epi, 
     return epi ? dispatch_mode<1>(a, mode, 3, cin, cout, 0, s) : dispatch_mode<0>(a, mode, 3, cin, cout, 0, s);
 }
 
+// 1: an az_conv3d_fwd_f16 launch of this shape may read a pre-split input (the depth-rolling kernels, which stage by copy,
+// under the size conditions of their launchers); 0: it needs the fp32 tensor
+extern "C" int az_conv3d_fwd_f16_split_ok(int mode, int B, int cin, int cout, int Di, int Hi, int Wi) {
+    if (mode < 0 || mode > 2 || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;
+    if (f16_on_roll(mode, cout)) return (cin == 32 || cin == 64) && az_fits_buffer_offset((long long)Di * Hi * Wi * cin * 4) ? 1 : 0;
+    if (f16_on_t2roll(mode, cin, cout))
+        return az_fits_buffer_offset(8LL * Di * Hi * Wi * 32 * 4) && az_fits_buffer_offset((long long)Di * Hi * Wi * 64 * 4) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int az_conv3d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
-                                 const float *w_amax, const float *scale, const float *shift, const float *residual,
-                                 int relu, int mode, int B, int cin, int cout, int Di, int Hi, int Wi, void *stream) {
+                                 const float *w_amax, int in_split, const float *scale, const float *shift,
+                                 const float *residual, int relu, int mode, int B, int cin, int cout, int Di, int Hi, int Wi,
+                                 void *stream) {
     AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w); AZ_REQUIRE_PTR(in_amax); AZ_REQUIRE_PTR(w_amax);
     ConvArgs a{};
     if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
+    if (in_split && !az_conv3d_fwd_f16_split_ok(mode, B, cin, cout, Di, Hi, Wi)) return AZ_EUNSUPPORTED;
     a.in = in; a.wp = packed_w; a.out = out; a.scale = scale; a.shift = shift; a.res = residual; a.relu = relu;
-    a.in_amax = in_amax; a.w_amax = w_amax;
+    a.in_amax = in_amax; a.w_amax = w_amax; a.in_split = in_split ? 1 : 0;
     return conv_f16_dispatch(a, mode, cin, cout, 0, az_stream(stream));
 }
 

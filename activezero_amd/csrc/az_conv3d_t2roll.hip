@@ -75,7 +75,8 @@ __host__ __device__ constexpr T2rTab t2r_make() {
 }
 
 // EPI: 0 = y = relu?(acc * scale + shift) (+ residual when given), 1 = raw output + BatchNorm partials
-template <int EPI>
+// PS: the input is a pre-split tensor (az_roll_common.h): the input gradient of hourglass conv1 from its BatchNorm backward
+template <int EPI, bool PS = false>
 __global__ void __launch_bounds__(T2R_NT, 2)
 conv3d_t2roll_kernel(const ConvArgs a) {
     constexpr T2rTab TAB = t2r_make();
@@ -360,7 +361,9 @@ int az_conv3d_t2roll_launch(ConvArgs a, int epi, hipStream_t s) {
     if (!az_fits_buffer_offset((long long)a.Do * a.Ho * a.Wo * 32 * 4) || !az_fits_buffer_offset((long long)a.Di * a.Hi * a.Wi * 64 * 4) ||
         a.ntiles * 256 >= 0xffffff00LL)
         return AZ_EUNSUPPORTED;
+    if (a.in_split && epi) return AZ_EUNSUPPORTED;  // (pre-split inputs are gradients: no BatchNorm-partials epilogue)
     if (epi) hipLaunchKernelGGL((conv3d_t2roll_kernel<1>), dim3((unsigned)blocks), dim3(T2R_NT), 0, s, a);
+    else if (a.in_split) hipLaunchKernelGGL((conv3d_t2roll_kernel<0, true>), dim3((unsigned)blocks), dim3(T2R_NT), 0, s, a);
     else hipLaunchKernelGGL((conv3d_t2roll_kernel<0>), dim3((unsigned)blocks), dim3(T2R_NT), 0, s, a);
     return az_launch_status();
 }

@@ -22,6 +22,7 @@
 
 #include "az_roll_common.h"
 #include "az_options.h"
+#include "az_launch_math.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -649,11 +650,11 @@ static int launch_wgrad(WgArgs a, hipStream_t s) {
 
 // all 27 taps per wave on 16x16x32 tiles, four waves sharing one staged set (az_conv3d_wgrad16.hip)
 int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s,
-                               const float *coarse_amax = nullptr, const float *fine_amax = nullptr);
+                               const float *coarse_amax = nullptr, const float *fine_amax = nullptr, int split_mask = 0);
 
 // stride 2, f16x3: eight waves sharing one staged set (az_conv3d_wgrad16s2.hip)
 int az_conv3d_wgrad_s2r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int Dc, int Hc, int Wc,
-                                 int Df, int Hf, int Wf, hipStream_t s, const float *coarse_amax, const float *fine_amax);
+                                 int Df, int Hf, int Wf, hipStream_t s, const float *coarse_amax, const float *fine_amax, int split_mask);
 
 extern "C" long long az_conv3d_wgrad_workspace(int cm, int cn) {
     if (cm <= 0 || cn <= 0 || cm % 32 || cn % 32) return AZ_EINVAL;
@@ -708,17 +709,32 @@ extern "C" int az_conv3d_wgrad(float *grad_w, float *workspace, long long worksp
 }
 
 // f16x3 weight gradient (include/azhip.h): the stride-1 layers with 32 / 64 channels on either side
+// which operands of an f16x3 weight-gradient launch of this shape may be pre-split tensors: the kernels that stage by copy
+// (az_conv3d_wgrad16.hip: both; az_conv3d_wgrad16s2.hip: one of the two), under the conditions their launchers check
+extern "C" int az_conv3d_wgrad_f16_split_ok(int stride, int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf) {
+    if (B <= 0 || !((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return 0;
+    if (stride == 1 && Dc == Df && Hc == Hf && Wc == Wf)
+        return az_fits_buffer_offset((long long)Dc * Hc * Wc * (cm > cn ? cm : cn) * 4) ? 3 : 0;
+    if (stride == 2 && az_options().wgrad_s2r16 && cm == 64 && az_fits_buffer_offset((long long)Df * Hf * Wf * cn * 4) &&
+        az_fits_buffer_offset((long long)Dc * Hc * Wc * cm * 4))
+        return 3;  // (either operand, not both at once: az_conv3d_wgrad_f16 returns AZ_EUNSUPPORTED for mask 3)
+    return 0;
+}
+
 extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *coarse,
-                                   const float *fine, const float *coarse_amax, const float *fine_amax, int stride,
-                                   int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream) {
+                                   const float *fine, const float *coarse_amax, const float *fine_amax, int split_mask,
+                                   int stride, int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf,
+                                   void *stream) {
     AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(coarse); AZ_REQUIRE_PTR(fine);
     AZ_REQUIRE_PTR(coarse_amax); AZ_REQUIRE_PTR(fine_amax);
     AZ_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Df > 0 && Hf > 0 && Wf > 0);
     AZ_REQUIRE(stride == 1 || stride == 2);
+    AZ_REQUIRE(split_mask >= 0 && split_mask <= 3);
     const long long need = az_conv3d_wgrad_workspace(cm, cn);
     if (need < 0) return AZ_EUNSUPPORTED;
     if (workspace_bytes < need) return AZ_EWORKSPACE;
     if (!((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return AZ_EUNSUPPORTED;
+    if (split_mask & ~az_conv3d_wgrad_f16_split_ok(stride, B, cm, cn, Dc, Hc, Wc, Df, Hf, Wf)) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
     if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
     int rc = AZ_EUNSUPPORTED;
@@ -726,9 +742,10 @@ extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long wo
     //  stride between lanes -- the V0 kernel took 1.52 instead of 1.06 ms and the stride-2 one 1.03 instead of 0.35: one cache
     //  line per lane and atomic instead of four 64-byte segments per instruction)
     if (stride == 1 && Dc == Df && Hc == Hf && Wc == Wf)  // all 27 taps per wave on 16x16x32 tiles (az_conv3d_wgrad16.hip)
-        rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s, coarse_amax, fine_amax);
+        rc = az_conv3d_wgrad_r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, s, coarse_amax, fine_amax, split_mask);
     else if (stride == 2 && az_options().wgrad_s2r16)
-        rc = az_conv3d_wgrad_s2r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, Df, Hf, Wf, s, coarse_amax, fine_amax);
+        rc = az_conv3d_wgrad_s2r16_launch(workspace, coarse, fine, B, cm, cn, Dc, Hc, Wc, Df, Hf, Wf, s, coarse_amax, fine_amax, split_mask);
+    if (rc == AZ_EUNSUPPORTED && split_mask) return rc;  // (the one-kd-per-wave kernels read fp32 tensors only: ask az_conv3d_wgrad_f16_split_ok first)
     if (rc == AZ_EUNSUPPORTED) {  // shapes / sizes those kernels do not take (e.g. a batch element beyond 32-bit offsets): one kd per wave
         WgArgs a{};
         a.coarse = coarse; a.fine = fine; a.ws = workspace; a.coarse_amax = coarse_amax; a.fine_amax = fine_amax;

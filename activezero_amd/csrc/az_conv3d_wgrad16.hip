@@ -66,7 +66,8 @@ struct Wg16Args {
 
 // AR: 0 = bf16x6 (three bf16 parts, six MFMAs per tap), 1 = f16x3 (two scaled fp16 parts, three MFMAs; az_roll_common.h).
 // The LDS images keep their three-part strides either way (the third part is unused with AR = 1).
-template <int AR>
+// PSM (AR = 1): bit 0 = the coarse operand, bit 1 = the fine operand is a pre-split tensor (az_roll_common.h).
+template <int AR, int PSM = 0>
 __global__ void __launch_bounds__(256, 2)
 conv3d_wgrad_r16_kernel(const Wg16Args a) {
     constexpr int NP = AR ? 2 : 3;
@@ -167,10 +168,8 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
             const int q = tid + 256 * it;
             uint2 hi, mid, lo;
             if (AR) {
-                float4 v = __builtin_bit_cast(float4, pre[it]);
-                const float sc_ = it == 0 ? c_scale : f_scale;
-                v.x *= sc_; v.y *= sc_; v.z *= sc_; v.w *= sc_;
-                az_split2_f16x4(v, hi, mid);
+                if (it == 0) az_stage_f16x4<(PSM & 1) != 0>(pre[it], c_scale, hi, mid);
+                else az_stage_f16x4<(PSM & 2) != 0>(pre[it], f_scale, hi, mid);
                 lo = mid;
             } else {
                 az_split3_bf16x4(__builtin_bit_cast(float4, pre[it]), hi, mid, lo);
@@ -286,7 +285,7 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
 
 // persistent workgroups: at most 512 resident (2 per CU); the count that balances the columns best
 int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s,
-                               const float *coarse_amax, const float *fine_amax) {
+                               const float *coarse_amax, const float *fine_amax, int split_mask) {
     if (!((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return AZ_EUNSUPPORTED;
     Wg16Args a{};
     a.coarse = coarse; a.fine = fine; a.ws = ws; a.coarse_amax = coarse_amax; a.fine_amax = fine_amax;
@@ -299,7 +298,14 @@ int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
     const int best = az_wgrad16_workgroups(a.ncols, slots, ntiles, az_options().wgrad_r16_wgs);
     a.wgs = best;
     a.xcd = az_options().wgrad_r16_xcd;
-    if (coarse_amax && fine_amax) hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<1>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<0>, dim3((unsigned)(a.wgs * ntiles)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)(a.wgs * ntiles));
+    if (!(coarse_amax && fine_amax)) {
+        if (split_mask) return AZ_EINVAL;
+        hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<0>, grid, dim3(256), 0, s, a);
+    } else if (split_mask == 0) hipLaunchKernelGGL((conv3d_wgrad_r16_kernel<1, 0>), grid, dim3(256), 0, s, a);
+    else if (split_mask == 1) hipLaunchKernelGGL((conv3d_wgrad_r16_kernel<1, 1>), grid, dim3(256), 0, s, a);
+    else if (split_mask == 2) hipLaunchKernelGGL((conv3d_wgrad_r16_kernel<1, 2>), grid, dim3(256), 0, s, a);
+    else if (split_mask == 3) hipLaunchKernelGGL((conv3d_wgrad_r16_kernel<1, 3>), grid, dim3(256), 0, s, a);
+    else return AZ_EINVAL;
     return az_launch_status();
 }

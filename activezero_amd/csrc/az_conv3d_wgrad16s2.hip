@@ -73,6 +73,9 @@ struct Wg16s2Args {
     const float *coarse_amax, *fine_amax;
 };
 
+// PSM: bit 0 = the coarse operand, bit 1 = the fine operand is a pre-split tensor (az_roll_common.h): a stride-2 layer's
+// coarse operand is the gradient of its raw output, a transposed layer's fine one.
+template <int PSM = 0>
 __global__ void __launch_bounds__(512, 2)
 conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[S2_LDS + 64];  // + a sink for the lanes of the partial piece
@@ -183,11 +186,9 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
         };
         auto commit_piece = [&](int it, int cbuf_idx, int frow0) {
             if (S2_ABL & 2) return;
-            float4 v = __builtin_bit_cast(float4, pre[it]);
-            const float sc_ = it == 0 ? c_scale : f_scale;
-            v.x *= sc_; v.y *= sc_; v.z *= sc_; v.w *= sc_;
             uint2 hi, lo;
-            az_split2_f16x4(v, hi, lo);
+            if (it == 0) az_stage_f16x4<(PSM & 1) != 0>(pre[it], c_scale, hi, lo);
+            else az_stage_f16x4<(PSM & 2) != 0>(pre[it], f_scale, hi, lo);
             unsigned d0, d1;
             if (it == 0) {
                 d0 = (unsigned)cbuf_idx * S2_CBUF + relc_l;
@@ -290,7 +291,7 @@ conv3d_wgrad_s2r16_kernel(const Wg16s2Args a) {
 // one persistent workgroup per CU over the fine-channel tiles; AZ_EUNSUPPORTED: shapes the kernel does not take (the caller
 // falls back to az_conv3d_wgrad.hip's one-kd-per-wave kernel)
 int az_conv3d_wgrad_s2r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int Dc, int Hc, int Wc,
-                                 int Df, int Hf, int Wf, hipStream_t s, const float *coarse_amax, const float *fine_amax) {
+                                 int Df, int Hf, int Wf, hipStream_t s, const float *coarse_amax, const float *fine_amax, int split_mask) {
     if (cm != 64 || !(cn == 32 || cn == 64) || !coarse_amax || !fine_amax) return AZ_EUNSUPPORTED;
     if (!az_fits_buffer_offset((long long)Df * Hf * Wf * cn * 4) || !az_fits_buffer_offset((long long)Dc * Hc * Wc * cm * 4)) return AZ_EUNSUPPORTED;
     Wg16s2Args a{};
@@ -300,6 +301,10 @@ int az_conv3d_wgrad_s2r16_launch(float *ws, const float *coarse, const float *fi
     a.nwchunk = (Wc + 7) / 8;
     a.ncols = (long long)B * Dc * a.nwchunk;
     a.wgs = az_wgrad16_workgroups(a.ncols, 256 / ntiles, ntiles, 0);
-    hipLaunchKernelGGL(conv3d_wgrad_s2r16_kernel, dim3((unsigned)(a.wgs * ntiles)), dim3(512), 0, s, a);
+    const dim3 grid((unsigned)(a.wgs * ntiles));
+    if (split_mask == 0) hipLaunchKernelGGL(conv3d_wgrad_s2r16_kernel<0>, grid, dim3(512), 0, s, a);
+    else if (split_mask == 1) hipLaunchKernelGGL(conv3d_wgrad_s2r16_kernel<1>, grid, dim3(512), 0, s, a);
+    else if (split_mask == 2) hipLaunchKernelGGL(conv3d_wgrad_s2r16_kernel<2>, grid, dim3(512), 0, s, a);
+    else return AZ_EUNSUPPORTED;  // (both operands pre-split: no producer writes a pre-split forward activation yet)
     return az_launch_status();
 }

@@ -1,6 +1,6 @@
 #include <stdlib.h>
 
-#include "az_common.h"
+#include "az_pack_f16.h"
 #include "az_options.h"
 
 extern "C" const char *az_strerror(int code) {
@@ -92,4 +92,23 @@ extern "C" int az_option(const char *name) {
         if (!*a && !*b) return e.v;
     }
     return AZ_EINVAL;
+}
+
+// ---- every f16x3 weight image of a model in one launch (include/azhip.h, az_pack_f16.h) -----------------------------------
+__global__ void __launch_bounds__(256)
+pack_f16_multi_kernel(const AzPackDesc *__restrict__ descs, const int *__restrict__ block_desc, const int *__restrict__ first_block) {
+    const int di = block_desc[blockIdx.x];
+    const AzPackDesc d = descs[di];  // (block-uniform: scalar loads)
+    const float scale = az_pow2(az_f16_scale_exp(az_amax_read(d.amax)));
+    const long long idx = (long long)(blockIdx.x - first_block[di]) * 256 + threadIdx.x;
+    if (idx >= az_pack_f16_total(d)) return;
+    reinterpret_cast<unsigned short *>(d.dst)[idx] = az_pack_f16_elem(d, idx, scale);
+}
+
+extern "C" int az_pack_f16_multi(const AzPackDesc *descs, const int *block_desc, const int *first_block, int nd, int nblocks,
+                                 void *stream) {
+    AZ_REQUIRE_PTR(descs); AZ_REQUIRE_PTR(block_desc); AZ_REQUIRE_PTR(first_block);
+    AZ_REQUIRE(nd > 0 && nblocks > 0);
+    hipLaunchKernelGGL(pack_f16_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, az_stream(stream), descs, block_desc, first_block);
+    return az_launch_status();
 }

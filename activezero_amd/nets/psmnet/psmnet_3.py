@@ -145,7 +145,10 @@ class PSMNet(nn.Module):
         if self.arith.conv == conv3d.F16X3 or self.arith.bwd16:
             # the f16x3 kernels scale their weights by max |w|: all of them in one multi-tensor pass per optimizer step.
             # (the gated aliases of a training pass share storage and version counter with the parameters)
-            conv3d.prime_weight_amax(overlap.conv_weights(self))
+            ws = overlap.conv_weights(self)
+            if torch.is_grad_enabled():
+                conv3d.prepack(ws)  # ... and every packed image the last step asked for, in one more launch (conv3d.PackPlan)
+            conv3d.prime_weight_amax(ws)
         return self.arith._replace(sink=sink)
 
     def _from_features(self, feat_l, feat_r, arith=None):

@@ -332,7 +332,7 @@ def solo_probe(args, device):
     cvec = [torch.ones(32, device=device) for _ in range(3)] + [torch.zeros(32, device=device)]
     small = [torch.empty(32, device=device), torch.empty(32, device=device), torch.empty(32, 3, device=device), torch.zeros(1024, device=device)]
     fns["bn3d_bwd_32"] = lambda: _call("az_bn3d_bwd", _p(dx), None, _p(small[0]), _p(small[1]), _p(small[2]), _p(ws), wsb, _p(dy), None,
-                                       _p(x), _p(cvec[3]), _p(cvec[0]), _p(cvec[1]), _p(cvec[2]), _p(cvec[3]), 1, nv, 32, _p(small[3]), _stream())
+                                       _p(x), _p(cvec[3]), _p(cvec[0]), _p(cvec[1]), _p(cvec[2]), _p(cvec[3]), 1, nv, 32, _p(small[3]), int(conv3d.PRESPLIT), _stream())
     with torch.no_grad():
         for _ in range(10):
             for f in fns.values():

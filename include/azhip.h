@@ -214,18 +214,50 @@ int az_conv3d_wgrad(float *grad_w, float *workspace, long long workspace_bytes,
 #define AZ_AMAX_STRIDE 64
 #define AZ_AMAX_FLOATS (AZ_AMAX_SLOTS * AZ_AMAX_STRIDE)
 int az_absmax(float *amax, const float *x, long long n, void *stream);
+/* Every f16x3 weight image of a model in ONE launch (round 5: a training step packed each weight twice -- forward image,
+ * flipped / swapped input-gradient image -- with a launch each, ~175 per step).  One descriptor per image: `kind` names
+ * the layout of the kernel that will read it (the per-tensor entry points az_conv2d_pack_weights_f16 /
+ * az_conv2d_roll_pack_f16 / az_conv3d_pack_weights_f16 write the same bytes), src / amax / dst are device pointers, the
+ * rest as in those calls (taps = kh * kw or 27; ci_real / co_real < cin / cout: zero-padded channels, 2-D "same" layout
+ * only).  descs: nd descriptors in DEVICE memory; block_desc: for each of the nblocks workgroups (256 elements each) the
+ * descriptor it works on, blocks of one descriptor consecutive; first_block: per descriptor its first workgroup --
+ * both built by the caller (activezero_amd/conv3d.py: PackPlan) once per set of weights. */
+#define AZ_PACK_2D_SAME 0
+#define AZ_PACK_2D_ROLL 1
+#define AZ_PACK_3D_GATHER 2
+#define AZ_PACK_3D_ROLL 3
+typedef struct AzPackDesc {
+    void *dst;           /* packed image (fp16 pairs) */
+    const float *src;    /* the weight tensor in PyTorch's layout */
+    const float *amax;   /* its amax array */
+    long long s_co, s_ci;
+    int kind, cin, cout, ci_real, co_real, taps, flip, pad_;
+} AzPackDesc;
+int az_pack_f16_multi(const AzPackDesc *descs, const int *block_desc, const int *first_block, int nd, int nblocks,
+                      void *stream);
 long long az_conv3d_packed_floats_f16(int cin, int cout);
 /* as az_conv3d_pack_weights, for the f16x3 launches below: w * 2^k (k from w_amax[0]) split into two fp16 parts.
  * `mode` = the mode the buffer will be launched with: mode 0 with cout = 32 runs on the depth-rolling kernel
  * ([tap][cin/32][cout/16][2][64][8 fp16]), everything else on the gather kernel ([tap][cin/32][cout/32][2][2][64][8]). */
 int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
                                long long stride_out, long long stride_in, int flip, int mode, void *stream);
+/* which of the two layouts that is: AZ_PACK_3D_ROLL / AZ_PACK_3D_GATHER (the `kind` of an az_pack_f16_multi descriptor) */
+int az_conv3d_f16_layout(int mode, int cin, int cout);
 /* az_conv3d_fwd / az_conv3d_fwd_stats / az_conv3d_stats_tiles on the f16x3 arithmetic (src = 0 only).  in_amax /
  * w_amax: device scalars holding max |in| and max |w| (of the UNPACKED weights).  The input gradient of a layer is
  * this call on the gradient of its raw output with the flipped / swapped packing, no affine map.  Every mode with
  * 32 / 64 channels on either side. */
+/* "S2 format" (pre-split operands, round 5): a tensor whose only readers are f16x3 matrix kernels may be stored the way
+ * they stage it -- every aligned group of four channels (16 bytes) holds hi(c0) hi(c1) | hi(c2) hi(c3) | lo(c0) lo(c1) |
+ * lo(c2) lo(c3), the two fp16 parts of x * 2^k with k from the amax array that travels with it -- in place of the four
+ * floats: same bytes, and the consumer stages by copy.  az_bn3d_bwd(split_out = 1) writes dx that way (its amax is then
+ * an upper BOUND of max |dx| derived before the first element is written); in_split / split_mask below tell a consumer.
+ * az_conv3d_fwd_f16_split_ok / az_conv3d_wgrad_f16_split_ok: which launches take such an operand (1 / bit mask: bit 0 =
+ * coarse, bit 1 = fine; a stride-2 launch takes one of the two); the launches return AZ_EUNSUPPORTED otherwise. */
+int az_conv3d_fwd_f16_split_ok(int mode, int B, int cin, int cout, int Di, int Hi, int Wi);
+int az_conv3d_wgrad_f16_split_ok(int stride, int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf);
 int az_conv3d_fwd_f16(float *out, const float *in, const float *packed_w, const float *in_amax,
-                      const float *w_amax, const float *scale, const float *shift, const float *residual,
+                      const float *w_amax, int in_split, const float *scale, const float *shift, const float *residual,
                       int relu, int mode, int B, int cin, int cout, int Di, int Hi, int Wi, void *stream);
 long long az_conv3d_stats_tiles_f16(int mode, int B, int cin, int cout, int Di, int Hi, int Wi);
 int az_conv3d_fwd_stats_f16(float *out, float *partials, float *counts, const float *in, const float *packed_w,
@@ -234,7 +266,7 @@ int az_conv3d_fwd_stats_f16(float *out, float *partials, float *counts, const fl
 /* as az_conv3d_wgrad on the f16x3 arithmetic; coarse_amax / fine_amax: device scalars max |coarse|, max |fine|.
  * Supported: stride 1 with 32 or 64 channels on either side; everything else returns AZ_EUNSUPPORTED. */
 int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long workspace_bytes, const float *coarse,
-                        const float *fine, const float *coarse_amax, const float *fine_amax, int stride,
+                        const float *fine, const float *coarse_amax, const float *fine_amax, int split_mask, int stride,
                         int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, void *stream);
 
 /* az_conv2d_pack_weights / az_conv2d_fwd / az_conv2d_fwd_stats on the f16x3 arithmetic (psmnet_submodule_3.py:13-41,
@@ -339,13 +371,16 @@ int az_bn3d_apply(float *y, const float *x, const float *scale, const float *shi
  * forward's affine map; when given for a ReLU layer WITHOUT residual the mask is recomputed as
  * fma(x, scale, shift) > 0 and y is not read (may be NULL).
  * dx_amax (may be NULL; need NOT be zero, the first kernel clears it): receives max |dx| -- the operand scale of the
- * f16x3 input- and weight-gradient kernels that read dx next, taken while dx is written instead of by az_absmax. */
+ * f16x3 input- and weight-gradient kernels that read dx next, taken while dx is written instead of by az_absmax.
+ * split_out = 1 (dx_amax required): dx is written in the S2 format above instead of as floats, and dx_amax receives
+ * the per-tensor bound  max_c |gamma_c invstd_c| (max |dz_c| + |mean dz_c| + max |xhat_c| |mean dz_c xhat_c|)  >= max |dx|
+ * that fixed its scale (the reduce pass takes the two per-channel maxima next to its sums); dz_out stays fp32. */
 long long az_bn3d_bwd_workspace(long long nvox, int C);
 int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *coef,
                 float *workspace, long long workspace_bytes, const float *dy, const float *y,
                 const float *x, const float *mean, const float *invstd, const float *gamma,
                 const float *scale, const float *shift, int relu, long long nvox, int C,
-                float *dx_amax, void *stream);
+                float *dx_amax, int split_out, void *stream);
 /* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175; y_amax as above */
 int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, float *y_amax, void *stream);
 /* y = a + b (+ c) (+ d), n floats (n % 4 == 0; c, d may be NULL): the gradient of a tensor with up to

@@ -271,3 +271,87 @@ def test_weight_grad_stride2_vs_torch(kind, cin, cout, fine_dims, prec):
     ref = w.grad
     err = (got.detach().cpu().double() - ref).abs().max().item()
     assert err <= 2e-6 * ref.abs().max().item() + 1e-6, err
+
+
+# ---- round 5: the BatchNorm-backward apply pass writes d(raw) pre-split (include/azhip.h "S2 format") --------------------
+def _decode_split(t, amax):
+    """a pre-split tensor -> fp64 values: every 16 bytes = hi(c0) hi(c1) | hi(c2) hi(c3) | lo(c0) lo(c1) | lo(c2) lo(c3)"""
+    a = float(amax[::64].max())  # (the slots of an amax array: every 64th float; the words between are not defined)
+    e = int(np.floor(np.log2(a))) if a > 0 else -127
+    k = min(max(14 - e, -126), 127)
+    h = t.contiguous().view(torch.int16).view(-1, 8).cpu()  # 8 halves per group of four channels
+    f = h.view(torch.float16).double()
+    vals = f[:, :4] + f[:, 4:]
+    return (vals * 2.0 ** (-k)).view(t.shape)
+
+
+@pytest.mark.parametrize("c,shape", [(32, (2, 5, 9, 20)), (64, (1, 4, 7, 12)), (32, (1, 24, 40, 96))])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bn_backward_presplit_output_is_the_split_of_the_fp32_one(c, shape, relu, capsys):
+    from activezero_amd import _lib
+    from activezero_amd.ops import _call, _p, _stream
+    b, d, h, w = shape
+    raw = cl(seeded((b, c, d, h, w), 61) * 3.0 + 0.5)
+    gy = cl(seeded((b, c, d, h, w), 62) * 1e-3)
+    gy[0, 1, 2, 3, :] *= 300.0  # a few spikes: the bound must follow the channel that has them
+    mean = raw.mean(dim=(0, 1, 2, 3)).contiguous()
+    invstd = (raw.var(dim=(0, 1, 2, 3), unbiased=False) + 1e-5).rsqrt().contiguous()
+    gamma = (seeded((c,), 63) * 0.5 + 1.0).to(DEV)
+    beta = (seeded((c,), 64) * 0.3).to(DEV)
+    scale, shift = (gamma * invstd).contiguous(), (beta - mean * gamma * invstd).contiguous()
+    nvox = raw.numel() // c
+    lib = _lib.lib()
+    wsb = lib.az_bn3d_bwd_workspace(nvox, c)
+    out = {}
+    for split in (0, 1):
+        ws = torch.empty(wsb // 4, device=DEV)
+        dx = torch.empty_like(raw)
+        dg, db, coef = torch.empty(c, device=DEV), torch.empty(c, device=DEV), torch.empty(c, 3, device=DEV)
+        am = torch.full((conv3d.AMAX_SLOTS,), 7.0, device=DEV)  # (need not be zero: the first kernel clears it)
+        _call("az_bn3d_bwd", _p(dx), None, _p(dg), _p(db), _p(coef), _p(ws), wsb, _p(gy), None, _p(raw), _p(mean), _p(invstd),
+              _p(gamma), _p(scale) if relu else None, _p(shift) if relu else None, int(relu), nvox, c, _p(am), split, _stream())
+        out[split] = (dx, am, dg, db)
+    ref, am0 = out[0][0].double().cpu(), float(out[0][1][::64].max())
+    got = _decode_split(out[1][0], out[1][1])
+    bound = float(out[1][1][::64].max())
+    assert abs(am0 - float(ref.abs().max())) == 0.0
+    assert bound >= am0, (bound, am0)
+    with capsys.disabled():
+        print(f"\npre-split dx C={c} {shape} relu={relu}: bound / max|dx| = {bound / am0:.3f}")
+    assert bound <= 4.0 * am0  # (a loose bound costs dynamic range, include/azhip.h: log2 of this ratio in bits)
+    # hi + lo = x up to 2^-22 |x|, and the fp16 subnormal spacing 2^-25 on the scaled value = 2^-39 of the bound (x2: margin)
+    err = (got - ref).abs()
+    assert float((err - (2.0 ** -21 * ref.abs() + 2.0 ** -38 * bound)).max()) <= 0.0
+    # the parameter gradients do not depend on the output format
+    torch.testing.assert_close(out[1][2], out[0][2], rtol=0, atol=0)
+    torch.testing.assert_close(out[1][3], out[0][3], rtol=0, atol=0)
+    # ... and the consumers multiply exactly these bits: input gradient from the pre-split tensor == from its decoded floats
+    if c == 32:
+        wt = (seeded((c, c, 3, 3, 3), 65) * 0.1).to(DEV)
+        dxs = out[1][0]
+        conv3d._set_amax(dxs, out[1][1])
+        dxs.az_split = True
+        dec = got.float().to(DEV)
+        conv3d._set_amax(dec, out[1][1])  # the same scale: the same two fp16 parts
+        with torch.no_grad():
+            a = conv3d._input_grad(dxs, wt, conv3d.CONV_S1, c, c, conv3d.F16X3)
+            bb = conv3d._input_grad(dec, wt, conv3d.CONV_S1, c, c, conv3d.F16X3)
+            torch.testing.assert_close(a, bb, rtol=0, atol=0)
+            xin = cl(seeded((b, c, d, h, w), 66))
+            ga = conv3d._weight_grad(xin, dxs, conv3d.CONV_S1, c, c, conv3d.F16X3)
+            gb = conv3d._weight_grad(xin, dec, conv3d.CONV_S1, c, c, conv3d.F16X3)
+            torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-6 * float(gb.abs().max()))  # (float-atomic flush order)
+
+
+def test_presplit_routing_matches_the_library_queries():
+    """which layers get a pre-split d(raw): both readers must stage it by copy (conv3d._presplit_ok)"""
+    def t(c, d, h, w):
+        return torch.empty(1, d, h, w, c, device=DEV)
+    ok = conv3d._presplit_ok
+    assert ok(t(32, 8, 16, 32), t(32, 8, 16, 32), conv3d.CONV_S1, 32, 32, True, True)      # V0 layers: roll + wgrad_r16
+    assert ok(t(32, 8, 16, 32), t(64, 4, 8, 16), conv3d.CONV_S2, 32, 64, True, True)       # conv1: t2roll + wgrad_s2r16
+    assert ok(t(64, 4, 8, 16), t(64, 4, 8, 16), conv3d.CONV_S1, 64, 64, False, True)       # weight gradient alone
+    assert ok(t(64, 4, 8, 16), t(32, 8, 16, 32), conv3d.DECONV_S2, 64, 32, False, True)    # transposed: fine operand
+    # gather-kernel input gradients read fp32 (until they move onto the rolling machinery): not pre-split
+    assert not ok(t(64, 4, 8, 16), t(64, 4, 8, 16), conv3d.CONV_S1, 64, 64, True, True)
+    assert not ok(t(64, 4, 8, 16), t(32, 8, 16, 32), conv3d.DECONV_S2, 64, 32, True, True)

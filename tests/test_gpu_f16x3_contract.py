@@ -207,4 +207,4 @@ def test_debug_amax_check_names_a_stale_attribute():
     # the kernels' own producers: BatchNorm apply writes max |y| of what it stores
     y = conv3d.add(x, x)
     conv3d.check_amax(y, conv3d._get_amax(y))
-    assert abs(float(conv3d._get_amax(y).max()) - float(y.abs().max())) == 0.0
+    assert abs(float(conv3d._get_amax(y)[::64].max()) - float(y.abs().max())) == 0.0

@@ -48,7 +48,7 @@ def run3d(shape, relu):
     am = torch.zeros(1024, device=dev)
     def f():
         _call("az_bn3d_bwd", _p(dx), None, _p(dg), _p(db), _p(coef), _p(ws), ws_bytes, _p(gy), None, _p(raw), _p(mean), _p(invstd),
-              _p(gamma), _p(scale) if relu else None, _p(shift) if relu else None, int(relu), nvox, C, _p(am), _stream())
+              _p(gamma), _p(scale) if relu else None, _p(shift) if relu else None, int(relu), nvox, C, _p(am), 0, _stream())
     ms = timeit(f)
     gb = 4.0 * raw.numel() * 5 / 1e9
     print(f"bn3d_bwd {shape} relu={relu}: {ms * 1e3:7.1f} us  {gb / ms:5.2f} TB/s over 5 passes ({gb * 1e3:.0f} MB)")

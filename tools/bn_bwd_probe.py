@@ -18,7 +18,7 @@ def run(shape, relu, n=20):
     dgamma, dbeta, coef = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, 3, device=dev)
     def bn():
         _call("az_bn3d_bwd", _p(dx), None, _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes, _p(gy), None, _p(raw), _p(mean), _p(invstd),
-              _p(gamma), _p(scale) if relu else None, _p(shift) if relu else None, int(relu), nvox, C, None, _stream())
+              _p(gamma), _p(scale) if relu else None, _p(shift) if relu else None, int(relu), nvox, C, None, 0, _stream())
     for _ in range(3): bn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

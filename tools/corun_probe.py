@@ -24,7 +24,7 @@ ws = torch.empty(ws_bytes // 4, device=dev); dx = torch.empty_like(raw)
 dgamma, dbeta, coef = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, 3, device=dev)
 def bn():
     _call("az_bn3d_bwd", _p(dx), None, _p(dgamma), _p(dbeta), _p(coef), _p(ws), ws_bytes, _p(gy), None, _p(raw), _p(mean), _p(invstd),
-          _p(gamma), _p(scale), _p(shift), 1, nvox, C, None, _stream())
+          _p(gamma), _p(scale), _p(shift), 1, nvox, C, None, 0, _stream())
 def wgrad(): conv3d._wgrad(g, x, 1, C, C, "conv", A_.wgrad)
 def dgrad(): conv3d._run_gather(g, pd, conv3d.CONV_S1, C, C, A_.conv, tag="dgrad")
 side = torch.cuda.Stream()

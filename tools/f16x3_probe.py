@@ -85,7 +85,7 @@ def timeit(fn, n=10):
 
 
 f6 = lambda: conv3d._run_gather(g, pd, conv3d.CONV_S1, C, C, conv3d.BF16X6, tag="dgrad")
-f3 = lambda: _call("az_conv3d_fwd_f16", _p(out), _p(g), _p(pk16), _p(gam), _p(wam), None, None, None, 0, 0, B, C, C, D, H, W, _stream())
+f3 = lambda: _call("az_conv3d_fwd_f16", _p(out), _p(g), _p(pk16), _p(gam), _p(wam), 0, None, None, None, 0, 0, B, C, C, D, H, W, _stream())
 fa = lambda: _call("az_absmax", _p(gam), _p(g), g.numel(), _stream())
 for _ in range(40):
     f6()

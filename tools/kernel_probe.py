@@ -47,7 +47,7 @@ def main():
         ws = torch.empty(wsb // 4, device=dev)
         dgm, dbt, coef, am = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, 3, device=dev), torch.zeros(1024, device=dev)
         _call("az_bn3d_bwd", _p(y), None, _p(dgm), _p(dbt), _p(coef), _p(ws), wsb, _p(g), None, _p(x), _p(shift), _p(scale),
-              _p(scale), _p(scale), _p(shift), 1, nv, C, _p(am), _stream())
+              _p(scale), _p(scale), _p(shift), 1, nv, C, _p(am), 0, _stream())
         # round 4, second half: the stride-2 / transposed pair of an hourglass (conv1 32 -> 64 stride 2, conv6 64 -> 32 transposed)
         if os.environ.get("AZ_PROBE_S2", "1") == "1":
             F = conv3d.F16X3
