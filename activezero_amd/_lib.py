@@ -73,6 +73,7 @@ _SIGS = {
     "az_conv3d_wgrad": [_PTR, _PTR, _LL, _PTR, _PTR] + [_INT] * 11 + [_PTR],
     "az_absmax": [_PTR, _PTR, _LL, _PTR],
     "az_pack_f16_multi": [_PTR, _PTR, _PTR, _INT, _INT, _PTR],
+    "az_wgrad_unpack_multi": [_PTR, _PTR, _PTR, _INT, _INT, _PTR],
     "az_conv3d_packed_floats_f16": [_INT, _INT],
     "az_conv3d_f16_layout": [_INT, _INT, _INT],
     "az_conv3d_pack_weights_f16": [_PTR, _PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],

@@ -232,10 +232,11 @@ def _run_stats(xr, packed, cin, cout, kh, kw, dil, stats):
     return out
 
 
-def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=None, amax=None):
+def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=None, amax=None, late_ok=True):
     """gr: [B,H,W,>=cm] grad rows, xr: [B,H,W,>=cn] input rows -> [cm_real, cn_real, kh, kw].
     sink: overlap.Sink or None -- the kernels run on its side stream (the result is valid after its join).
-    amax: None (bf16x6) or (amax array of gr or None, of xr or None): the f16x3 kernels; a missing one is taken here."""
+    amax: None (bf16x6) or (amax array of gr or None, of xr or None): the f16x3 kernels; a missing one is taken here.
+    late_ok = False: the caller reads the result on the side stream right away: no deferred epilogue (overlap.Sink)."""
     b, h, w, _ = xr.shape
     gw = xr.new_empty(cm_real, cn_real, kh, kw)
     ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cm, cn, kh, kw)
@@ -243,21 +244,26 @@ def _wgrad(gr, xr, cm, cn, cm_real, cn_real, kh, kw, dil, tag="conv2d", sink=Non
         raise RuntimeError(f"conv2d wgrad: unsupported channel counts {cm} x {cn}")
     keep = [t for t in (amax or ()) if t is not None]
     with overlap.scope(sink, gr, xr, gw, *keep):  # (gw too: the engine may drop it before the join, overlap.py)
-        ws = xr.new_empty(ws_bytes // 4)
+        # on the side stream the epilogue is deferred: zeroed workspace from the pass's arena, unpack at the join (overlap.Sink)
+        late = late_ok and sink is not None and sink.live and overlap.DEFER_UNPACK
+        ws = sink.take_workspace(ws_bytes // 4) if late else xr.new_empty(ws_bytes // 4)
+        out = None if late else _p(gw)
         if amax is None:
             with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
                                 peak=PEAK_X6):
-                _call("az_conv2d_wgrad", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w, cm, cn, cm_real, cn_real,
+                _call("az_conv2d_wgrad", out, _p(ws), ws_bytes, _p(gr), _p(xr), b, h, w, cm, cn, cm_real, cn_real,
                       gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
         else:
             am_g = amax[0] if amax[0] is not None else conv3d.absmax(gr)
             am_x = amax[1] if amax[1] is not None else conv3d.absmax(xr)
             with profiler.scope(f"{tag}_wgrad_{kh}x{kw}d{dil}_{cm}_{cn}", flops=2.0 * kh * kw * cm * cn * b * h * w,
                                 peak=PEAK_F16):
-                _call("az_conv2d_wgrad_f16", _p(gw), _p(ws), ws_bytes, _p(gr), _p(xr), _p(am_g), _p(am_x), b, h, w, cm, cn,
+                _call("az_conv2d_wgrad_f16", out, _p(ws), ws_bytes, _p(gr), _p(xr), _p(am_g), _p(am_x), b, h, w, cm, cn,
                       cm_real, cn_real, gr.shape[-1], xr.shape[-1], kh, kw, dil, _stream())
             if sink is not None and sink.live:
                 sink.keep.extend((am_g, am_x))
+        if late:
+            sink.defer_unpack(gw, ws, cm, cn, cm_real, cn_real, kh * kw)
     return gw
 
 
@@ -399,7 +405,7 @@ class _ConvS2Vol(torch.autograd.Function):
                 g2 = conv3d._input_grad(gv, w3, conv3d.CONV_S2, cin, cout, arith.conv)  # [B,2,H,W,cin]
                 gx = image(g2[:, 0, :xv.shape[2], :xv.shape[3]])
             if ctx.needs_input_grad[1]:
-                g3 = conv3d._weight_grad(xv, gv, conv3d.CONV_S2, cin, cout, arith.wgrad, ctx.sink)
+                g3 = conv3d._weight_grad(xv, gv, conv3d.CONV_S2, cin, cout, arith.wgrad, ctx.sink, late_ok=False)  # (sliced right below)
                 gw = g3.new_empty(cout, cin, 3, 3)
                 with overlap.scope(ctx.sink, g3, gw):  # the slice reads g3 on the stream that wrote it
                     gw.copy_(g3[:, :, 1])
@@ -451,7 +457,7 @@ class _ConvS2Patches(torch.autograd.Function):
                 _call("az_col2im_s2k3", _p(gxr), _p(gp), b, cin, h, w, kp, _stream())
                 gx = image(gxr)
             if ctx.needs_input_grad[1]:
-                g2 = _wgrad(gr, patches, cout, kp, cout, 9 * cin, 1, 1, 1, tag="fe2d_first", sink=ctx.sink)  # [cout, 9cin,1,1]
+                g2 = _wgrad(gr, patches, cout, kp, cout, 9 * cin, 1, 1, 1, tag="fe2d_first", sink=ctx.sink, late_ok=False)  # [cout, 9cin,1,1]; permuted right below
                 gw = g2.new_empty(cout, cin, 3, 3)
                 with overlap.scope(ctx.sink, g2, gw):
                     gw.copy_(g2.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2))

@@ -373,7 +373,8 @@ class PackPlan:
         self.entries = {}      # (data_ptr, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip) -> _PackEntry
         self.amax_rows = {}    # data_ptr -> (row tensor [AMAX_SLOTS], weakref)
         self.amax_blocks = []  # [tensor [256, AMAX_SLOTS], next row]
-        self.table = None      # (descs, block_desc, first_block, nd, nblocks, entry list) on the device
+        self.table = None      # (descs, block_desc, first_block, nd, nblocks, entry list) on the device: the last one used
+        self.tables = {}       # tuple of registered addresses -> table + the amax pointers it was built with
         self.launches = 0      # az_pack_f16_multi launches so far (tests)
 
     # -- weight amax rows: persistent, so that the descriptor table stays valid across steps
@@ -402,6 +403,7 @@ class PackPlan:
                 self.amax_rows.pop(p, None)
             self.entries = {k: e for k, e in self.entries.items() if k[0] not in dead}
             self.table = None
+            self.tables.clear()
 
     def lookup(self, weight, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip):
         """(entry, fresh): the entry of this image of a registered live parameter (created on first request), and whether its
@@ -420,6 +422,7 @@ class PackPlan:
                 e.amax, e.version = None, -1
                 self.entries[key] = e
                 self.table = None  # rebuilt at the next prepack
+                self.tables.clear()
             return e, e.version == weight._version
 
     def _build_table(self, todo):
@@ -444,18 +447,24 @@ class PackPlan:
                       torch.tensor(first, dtype=torch.int32, device=dev), nd, nblocks, list(todo))
 
     def prepack(self, weights):
-        """register `weights` (nn.Parameters) and bring every recorded image of theirs up to their current version in one
-        launch; the amax arrays of all of them in three (prime_weight_amax)"""
+        """register `weights` (nn.Parameters) and bring every recorded image of THEIRS up to their current version in one
+        launch (a table per set of weights: another live model's images are not this call's business); the amax arrays of
+        all of them in three launches (as prime_weight_amax)"""
         with self.lock:
             self.purge()
             import weakref
+            mine = []
             for w in weights:
                 if w is None or not w.is_cuda or w.dtype != torch.float32 or w.device != self.device:
                     continue
                 r = self.registered.get(w.data_ptr())
                 if r is None or r() is not w:
                     self.registered[w.data_ptr()] = weakref.ref(w)
-            stale = [e for e in self.entries.values() if e.wref() is not None and e.version != e.wref()._version]
+                mine.append(w.data_ptr())
+            setkey = tuple(sorted(set(mine)))
+            owned = set(setkey)
+            todo = [e for k, e in self.entries.items() if k[0] in owned and e.wref() is not None]
+            stale = [e for e in todo if e.version != e.wref()._version]
             if not stale:
                 return
             with torch.no_grad(), torch.cuda.device(self.device):
@@ -476,16 +485,20 @@ class PackPlan:
                     _cache_put(_W_AMAX, (w.data_ptr(), w._version, w.device.index, w.numel()), (row, w), 512)
                 for e in stale:
                     e.amax = self.amax_rows[e.wref().data_ptr()][0]
-                todo = list(self.entries.values())
-                if self.table is None or self.table[5] != todo or any(e.amax is None for e in todo):
-                    todo = [e for e in todo if e.wref() is not None and e.amax is not None]
+                todo = [e for e in todo if e.amax is not None]
+                tab = self.tables.get(setkey)
+                if tab is None or tab[5] != todo or any(e.amax.data_ptr() != p for e, p in zip(todo, tab[6])):
                     self._build_table(todo)
-                descs, block_desc, first, nd, nblocks, elist = self.table
-                if all(e.wref() is not None for e in elist):
-                    _call("az_pack_f16_multi", _p(descs), _p(block_desc), _p(first), nd, nblocks, _stream())
-                    self.launches += 1
-                    for e in elist:
-                        e.version = e.wref()._version
+                    tab = self.table + ([e.amax.data_ptr() for e in todo],)
+                    if len(self.tables) > 8:
+                        self.tables.clear()
+                    self.tables[setkey] = tab
+                descs, block_desc, first, nd, nblocks, elist, _ = tab
+                _call("az_pack_f16_multi", _p(descs), _p(block_desc), _p(first), nd, nblocks, _stream())
+                self.launches += 1
+                for e in elist:
+                    e.version = e.wref()._version
+                self.table = tab[:6]  # (the last table used: tests read it)
 
 
 _PLANS = {}
@@ -527,8 +540,7 @@ def _planned_pack(weight, w, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps
                 _cache_put(_W_AMAX, wkey, (w_amax, weight), 512)
             pack_now(e.packed, w_amax)
             e.amax, e.version = w_amax, weight._version
-            if plan.table is not None and e in plan.table[5]:
-                plan.table = None  # (this entry's amax pointer changed: the table is rebuilt with a persistent row next prepack)
+            # (this entry's amax pointer may have changed: prepack compares the pointers its table was built with)
     return e.packed, e.amax
 
 
@@ -671,7 +683,9 @@ def _f16_wgrad_ok(mode, cin, cout):
     return cin in (32, 64) and cout in (32, 64)
 
 
-def _wgrad_f16(coarse, fine, stride, cm, cn, tag, sink=None):
+def _wgrad_f16(coarse, fine, stride, cm, cn, tag, sink=None, late_ok=True):
+    """late_ok = False: the caller reads the result on the side stream right away (a slice / permute of it is the real
+    gradient): no deferred epilogue"""
     b, dc, hc, wc, _ = _dims(coarse)
     _, df, hf, wf, _ = _dims(fine)
     gw = coarse.new_empty(cm, cn, 3, 3, 3)
@@ -681,23 +695,27 @@ def _wgrad_f16(coarse, fine, stride, cm, cn, tag, sink=None):
     if (mask & 1 and am_c is None) or (mask & 2 and am_f is None):
         raise RuntimeError("a pre-split tensor without its producer's amax")
     with overlap.scope(sink, coarse, fine, gw, am_c, am_f):
-        ws = coarse.new_empty(ws_bytes // 4)
+        # on the side stream the epilogue is deferred: zeroed workspace from the pass's arena, unpack at the join (overlap.Sink)
+        late = late_ok and sink is not None and sink.live and overlap.DEFER_UNPACK
+        ws = sink.take_workspace(ws_bytes // 4) if late else coarse.new_empty(ws_bytes // 4)
         # (a pass over the tensor only when its producer attached none)
         am_c = am_c if mask & 1 else absmax(coarse)
         am_f = am_f if mask & 2 else absmax(fine)
         with profiler.scope(f"{tag}_wgrad_s{stride}_{cm}_{cn}", flops=2.0 * 27 * cm * cn * b * dc * hc * wc,
                             peak=_PEAK_F16):
-            _call("az_conv3d_wgrad_f16", _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), _p(am_c), _p(am_f), mask, stride,
-                  b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
+            _call("az_conv3d_wgrad_f16", None if late else _p(gw), _p(ws), ws_bytes, _p(coarse), _p(fine), _p(am_c), _p(am_f),
+                  mask, stride, b, cm, cn, dc, hc, wc, df, hf, wf, _stream())
+        if late:
+            sink.defer_unpack(gw, ws, cm, cn, cm, cn, 27)
         if sink is not None and sink.live:
             sink.keep.extend((am_c, am_f))
     return gw
 
 
-def _weight_grad_f16(x, dy, mode, cin, cout, sink=None):
+def _weight_grad_f16(x, dy, mode, cin, cout, sink=None, late_ok=True):
     if mode == DECONV_S2:
-        return _wgrad_f16(x, dy, 2, cin, cout, "deconv", sink)
-    return _wgrad_f16(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", sink)
+        return _wgrad_f16(x, dy, 2, cin, cout, "deconv", sink, late_ok)
+    return _wgrad_f16(dy, x, 1 if mode == CONV_S1 else 2, cout, cin, "conv", sink, late_ok)
 
 
 def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
@@ -732,10 +750,10 @@ def _input_grad(dy, weight, mode, cin, cout, precision):
     return _run_gather(dy, pk, CONV_S2, cout, cin, precision, tag="dgrad")
 
 
-def _weight_grad(x, dy, mode, cin, cout, precision, sink=None):
+def _weight_grad(x, dy, mode, cin, cout, precision, sink=None, late_ok=True):
     if precision == F16X3:
         if _f16_wgrad_ok(mode, cin, cout):
-            return _weight_grad_f16(x, dy, mode, cin, cout, sink)
+            return _weight_grad_f16(x, dy, mode, cin, cout, sink, late_ok)
         precision = BF16X6
     if mode == DECONV_S2:
         return _wgrad(x, dy, 2, cin, cout, "deconv", precision, sink)
@@ -747,6 +765,8 @@ def _presplit_ok(x, raw, mode, cin, cout, need_gx, need_gw):
     launch of the dual map on d(raw)) and the f16x3 weight gradient -- stages such an operand by copy.  Mirrors the
     routing of _input_grad / _weight_grad; the library answers for its own kernels (az_conv3d_*_split_ok)."""
     lib = _lib.lib()
+    if lib.az_option(b"AZ_BN_BWD_FUSED") == 0:  # (the three-launch BatchNorm backward of that A/B switch writes floats only)
+        return False
     b, d, h, w, _ = raw.shape
     if need_gx:
         if not (_f16_dgrad_ok(mode, cin, cout) and (_fits32(raw, cin, cout) or not (mode == CONV_S1 and cin == 32)) and

@@ -317,7 +317,8 @@ static int conv2d_wgrad_impl(float *grad_w, float *workspace, long long workspac
                              const float *in, const float *go_amax, const float *in_amax, int B, int H, int W, int cm,
                              int cn, int cm_real, int cn_real, int go_cstride, int in_cstride, int kh, int kw,
                              int dilation, void *stream, int plain_bf16 = 0) {
-    AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(grad_out); AZ_REQUIRE_PTR(in);
+    // grad_w == NULL: accumulate-only into an ALREADY ZERO workspace, which keeps the tap-major result (az_conv3d_wgrad_f16)
+    AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(grad_out); AZ_REQUIRE_PTR(in);
     AZ_REQUIRE(B > 0 && H > 0 && W > 0);
     const long long need = az_conv2d_wgrad_workspace(cm, cn, kh, kw);
     if (need < 0) return AZ_EUNSUPPORTED;
@@ -326,7 +327,7 @@ static int conv2d_wgrad_impl(float *grad_w, float *workspace, long long workspac
     AZ_REQUIRE(go_cstride >= cm && in_cstride >= cn && go_cstride % 4 == 0 && in_cstride % 4 == 0);
     if ((long long)H * W * (go_cstride > in_cstride ? go_cstride : in_cstride) > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
-    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
+    if (grad_w && hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
     W2Args a{};
     a.coarse = grad_out; a.fine = in; a.ws = workspace; a.coarse_amax = go_amax; a.fine_amax = in_amax;
     a.plain_bf16 = plain_bf16;
@@ -347,6 +348,7 @@ static int conv2d_wgrad_impl(float *grad_w, float *workspace, long long workspac
         }
     }
     if (rc != AZ_OK) return rc;
+    if (!grad_w) return az_launch_status();
     const int total = cm_real * cn_real * kh * kw;
     hipLaunchKernelGGL(wgrad2d_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm,
                        cn, cm_real, cn_real, kh * kw);

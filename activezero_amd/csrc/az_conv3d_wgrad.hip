@@ -725,7 +725,10 @@ extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long wo
                                    const float *fine, const float *coarse_amax, const float *fine_amax, int split_mask,
                                    int stride, int B, int cm, int cn, int Dc, int Hc, int Wc, int Df, int Hf, int Wf,
                                    void *stream) {
-    AZ_REQUIRE_PTR(grad_w); AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(coarse); AZ_REQUIRE_PTR(fine);
+    // grad_w == NULL: accumulate-only -- the workspace is ALREADY ZERO (one arena memset per backward pass instead of one per
+    // layer) and keeps the tap-major result [27][cm][cn]; az_wgrad_unpack_multi turns a whole pass's workspaces into
+    // PyTorch-layout gradients in one launch
+    AZ_REQUIRE_PTR(workspace); AZ_REQUIRE_PTR(coarse); AZ_REQUIRE_PTR(fine);
     AZ_REQUIRE_PTR(coarse_amax); AZ_REQUIRE_PTR(fine_amax);
     AZ_REQUIRE(B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && Df > 0 && Hf > 0 && Wf > 0);
     AZ_REQUIRE(stride == 1 || stride == 2);
@@ -736,7 +739,7 @@ extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long wo
     if (!((cm == 32 || cm == 64) && (cn == 32 || cn == 64))) return AZ_EUNSUPPORTED;
     if (split_mask & ~az_conv3d_wgrad_f16_split_ok(stride, B, cm, cn, Dc, Hc, Wc, Df, Hf, Wf)) return AZ_EUNSUPPORTED;
     hipStream_t s = az_stream(stream);
-    if (hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
+    if (grad_w && hipMemsetAsync(workspace, 0, (size_t)need, s) != hipSuccess) return AZ_ELAUNCH;
     int rc = AZ_EUNSUPPORTED;
     // (the flush stays tap-major + one unpack launch: with the atomics going straight into PyTorch's [m][n][27] layout -- 27-float
     //  stride between lanes -- the V0 kernel took 1.52 instead of 1.06 ms and the stride-2 one 1.03 instead of 0.35: one cache
@@ -755,6 +758,7 @@ extern "C" int az_conv3d_wgrad_f16(float *grad_w, float *workspace, long long wo
 #undef WG16_CASE
     }
     if (rc != AZ_OK) return rc;
+    if (!grad_w) return az_launch_status();
     const int total = cm * cn * 27;
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, grad_w, workspace, cm, cn);
     return az_launch_status();

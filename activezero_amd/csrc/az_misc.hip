@@ -112,3 +112,24 @@ extern "C" int az_pack_f16_multi(const AzPackDesc *descs, const int *block_desc,
     hipLaunchKernelGGL(pack_f16_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, az_stream(stream), descs, block_desc, first_block);
     return az_launch_status();
 }
+
+// ---- the weight-gradient workspaces of a whole backward pass -> PyTorch-layout gradients, one launch (include/azhip.h) ------
+// ws [taps][cm][cn] -> dst[(co * cn_real + ci) * taps + t], co < cm_real, ci < cn_real (wgrad_unpack_kernel / wgrad2d_unpack_kernel)
+__global__ void __launch_bounds__(256)
+wgrad_unpack_multi_kernel(const AzUnpackDesc *__restrict__ descs, const int *__restrict__ block_desc, const int *__restrict__ first_block) {
+    const int di = block_desc[blockIdx.x];
+    const AzUnpackDesc d = descs[di];
+    const int idx = (blockIdx.x - first_block[di]) * 256 + threadIdx.x;
+    if (idx >= d.cm_real * d.cn_real * d.taps) return;
+    const int t = idx % d.taps, mn = idx / d.taps;
+    const int ci = mn % d.cn_real, co = mn / d.cn_real;
+    d.dst[idx] = d.ws[((size_t)t * d.cm + co) * d.cn + ci];
+}
+
+extern "C" int az_wgrad_unpack_multi(const AzUnpackDesc *descs, const int *block_desc, const int *first_block, int nd, int nblocks,
+                                     void *stream) {
+    AZ_REQUIRE_PTR(descs); AZ_REQUIRE_PTR(block_desc); AZ_REQUIRE_PTR(first_block);
+    AZ_REQUIRE(nd > 0 && nblocks > 0);
+    hipLaunchKernelGGL(wgrad_unpack_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, az_stream(stream), descs, block_desc, first_block);
+    return az_launch_status();
+}

@@ -71,6 +71,8 @@ _SIDE_PRIORITY = int(os.environ.get("AZ_SIDE_PRIORITY", "0"))
 # (A third form -- references dropped when an event behind the kernel has completed, polled at every later launch -- behaves as
 #  "join": at enqueue time the GPU is far behind, nothing has completed yet.)
 _RELEASE = os.environ.get("AZ_SIDE_RELEASE", "join")
+# AZ_WGRAD_DEFER=0 (read once): every side-stream weight gradient zeroes its own workspace and unpacks at once (round 4)
+DEFER_UNPACK = os.environ.get("AZ_WGRAD_DEFER", "1") != "0"
 if _RELEASE not in ("record", "join"):
     _RELEASE = "join"
 
@@ -84,6 +86,9 @@ def side_stream(device):
         if s is None:
             s = _STREAMS[idx] = torch.cuda.Stream(device=idx, priority=_SIDE_PRIORITY)
     return s
+
+
+_ARENA_HINT = {}   # device index -> floats of weight-gradient workspace the last pass used
 
 
 class Sink:
@@ -101,6 +106,11 @@ class Sink:
         self.uses = {}       # id(weight) -> times requested in this pass
         self.disarmed = False
         self.callback_set = False
+        # round 5: one zeroed arena for all weight-gradient workspaces of the pass and one unpack launch at the join
+        self.arena = None    # flat fp32 tensor, allocated and zeroed on the side stream by the first weight gradient
+        self.arena_used = 0
+        self.arena_need = 0  # floats this pass asked for (the next pass's arena size)
+        self.pending = []    # (grad_w, workspace view, cm, cn, cm_real, cn_real, taps): unpacked at the join
 
     def weight(self, w):
         """The tensor a layer of this pass must use for parameter w."""
@@ -122,13 +132,68 @@ class Sink:
         """True when t is one of this pass's gated weights: only their gradients may be produced late."""
         return id(t) in self.owned
 
+    # ---- deferred weight-gradient epilogues (call both INSIDE `scope`, i.e. with the side stream current) -------------------
+    def take_workspace(self, nfloats):
+        """a ZEROED tap-major workspace for a weight-gradient kernel launched with grad_w = NULL (include/azhip.h): a slice of
+        the pass's arena -- one fill per backward pass instead of a memset per layer"""
+        n = (nfloats + 63) & ~63
+        self.arena_need += n
+        if self.arena is None:
+            dev = self.stream.device
+            self.arena = torch.zeros(max(_ARENA_HINT.get(dev.index, 0), n), dtype=torch.float32, device=dev)
+            self.arena_used = 0
+        if self.arena_used + n > self.arena.numel():  # (first pass, or a pass larger than the last one)
+            return torch.zeros(n, dtype=torch.float32, device=self.arena.device)
+        ws = self.arena[self.arena_used:self.arena_used + n]
+        self.arena_used += n
+        return ws
+
+    def defer_unpack(self, grad_w, ws, cm, cn, cm_real, cn_real, taps):
+        """grad_w (PyTorch layout, still unwritten) <- ws at the join; both are kept alive until then"""
+        self.pending.append((grad_w, ws, cm, cn, cm_real, cn_real, taps))
+
+    def _flush_pending(self):
+        import numpy as np
+        from .ops import _call, _p
+        pend, self.pending = self.pending, []
+        nd = len(pend)
+        raw = np.zeros(nd * 40, dtype=np.uint8)  # sizeof(AzUnpackDesc): 2 pointers, 6 ints
+        q, ints = raw.view(np.int64).reshape(nd, 5), raw.view(np.int32).reshape(nd, 10)
+        block_desc, first, nblocks = [], [], 0
+        for i, (gw, ws, cm, cn, cmr, cnr, taps) in enumerate(pend):
+            q[i, 0], q[i, 1] = gw.data_ptr(), ws.data_ptr()
+            ints[i, 4:9] = (cm, cn, cmr, cnr, taps)
+            nb = (cmr * cnr * taps + 255) // 256
+            first.append(nblocks)
+            block_desc.append(np.full(nb, i, dtype=np.int32))
+            nblocks += nb
+        tables = np.concatenate([raw.view(np.int32), np.concatenate(block_desc), np.asarray(first, dtype=np.int32)])
+        dev = self.stream.device
+        # a FRESH pinned tensor per join, from torch's caching host allocator: the asynchronous copy below executes when the side
+        # stream reaches it -- tens of milliseconds after this line, and the host may be several steps ahead of the GPU by then
+        # -- and that allocator does not recycle a block before the copies recorded on it have completed.  (A hand-kept pair of
+        # staging buffers was overwritten by the join of step k + 2 before step k's copy had run: gradients unpacked into the
+        # wrong tensors, invisible in tests that synchronise every step, 11.6 -> 14.3 in the bench's loss after 13 steps.)
+        stage = torch.from_numpy(tables).pin_memory()
+        with torch.cuda.stream(self.stream):
+            t = stage.to(dev, non_blocking=True)
+            o1, o2 = nd * 10, nd * 10 + nblocks
+            with torch.cuda.device(dev):
+                _call("az_wgrad_unpack_multi", _p(t), _p(t[o1:o2]), _p(t[o2:]), nd, nblocks, self.stream.cuda_stream)
+        self.keep.append(t)
+
     def join(self):
         if self.joined:
             return
+        if self.pending:
+            self._flush_pending()
+        if self.arena is not None:
+            _ARENA_HINT[self.stream.device.index] = self.arena_need
         # (the model's device, not the calling thread's current one: the end-of-backward callback runs outside the
         #  engine's per-node device guard)
         torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
         self.keep.clear()
+        self.arena = None
         self.joined = True
         profiler.joined()
 

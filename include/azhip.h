@@ -235,6 +235,18 @@ typedef struct AzPackDesc {
 } AzPackDesc;
 int az_pack_f16_multi(const AzPackDesc *descs, const int *block_desc, const int *first_block, int nd, int nblocks,
                       void *stream);
+/* The other end of a step: az_conv3d_wgrad_f16 / az_conv2d_wgrad(_f16) called with grad_w = NULL only ACCUMULATE into
+ * their tap-major workspace [taps][cm][cn], which the caller has zeroed (one memset of an arena per backward pass instead
+ * of one per layer); this call unpacks all of a pass's workspaces into PyTorch's [cm_real][cn_real][taps] layout in one
+ * launch (descriptor / block tables as above; activezero_amd/overlap.py: Sink.join).  Round 4: 105 memsets and 88 unpack
+ * launches per step. */
+typedef struct AzUnpackDesc {
+    float *dst;
+    const float *ws;
+    int cm, cn, cm_real, cn_real, taps, pad_;
+} AzUnpackDesc;
+int az_wgrad_unpack_multi(const AzUnpackDesc *descs, const int *block_desc, const int *first_block, int nd, int nblocks,
+                          void *stream);
 long long az_conv3d_packed_floats_f16(int cin, int cout);
 /* as az_conv3d_pack_weights, for the f16x3 launches below: w * 2^k (k from w_amax[0]) split into two fp16 parts.
  * `mode` = the mode the buffer will be launched with: mode 0 with cout = 32 runs on the depth-rolling kernel
