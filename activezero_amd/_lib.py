@@ -35,6 +35,8 @@ _SIGS = {
     "az_patch_reproj_vis": [_PTR] * 3 + [_INT] * 5 + [_C.c_float, _PTR],
     "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
     "az_sum4": [_PTR] * 5 + [_LL, _PTR],
+    "az_spp_upsample_fwd": [_PTR, _PTR] + [_INT] * 7 + [_PTR],
+    "az_spp_upsample_bwd": [_PTR, _PTR] + [_INT] * 7 + [_PTR],
     "az_costconv_edge_width": [_INT, _INT],
     "az_costconv_num_classes": [_INT],
     "az_costconv_assemble_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],

@@ -140,6 +140,60 @@ def upsample_bilinear_ac(x, size):
     return torch.matmul(wy, torch.matmul(x, wx.t())).contiguous(memory_format=torch.channels_last)
 
 
+class _SppConcat(torch.autograd.Function):
+    """torch.cat([raw, skip] + [F.upsample(branch_i, (H, W), mode="bilinear")], 1) of psmnet_submodule_3.py:198-211 as one node:
+    the four pooled branch maps are interpolated straight into their channel slots of the concat buffer by az_spp_upsample_fwd
+    (a 2 x 2-tap stencil; rounds 1-4: two rocBLAS GEMMs and a layout copy per branch, forward and backward), raw and skip are
+    copied into theirs.  Channels-last throughout: out is [B, 64 + 128 + 4 * 32, H, W] in channels_last memory."""
+
+    @staticmethod
+    def forward(ctx, raw, skip, *branches):
+        from activezero_amd.ops import _call, _chk, _p, _stream
+        b, _, h, w = skip.shape
+        parts = [raw, skip]
+        ctot = raw.shape[1] + skip.shape[1] + sum(t.shape[1] for t in branches)
+        out = skip.new_empty(b, h, w, ctot)  # rows
+        at = 0
+        for t in parts:
+            out[..., at:at + t.shape[1]] = t.permute(0, 2, 3, 1)
+            at += t.shape[1]
+        ctx.slots, ctx.shapes = [], []
+        with torch.cuda.device(skip.device):
+            for t in branches:
+                r = _chk(conv2d.rows(t), "spp branch")
+                c = r.shape[-1]
+                _call("az_spp_upsample_fwd", _p(out[..., at:]), _p(r), b, r.shape[1], r.shape[2], h, w, c, ctot, _stream())
+                ctx.slots.append((at, c))
+                ctx.shapes.append(tuple(r.shape))
+                at += c
+        ctx.c_raw, ctx.c_skip = raw.shape[1], skip.shape[1]
+        return conv2d.image(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        from activezero_amd.ops import _call, _chk, _p, _stream
+        gr = _chk(conv2d.rows(g), "grad")
+        b, h, w, ctot = gr.shape
+        need = ctx.needs_input_grad
+        g_raw = conv2d.image(gr[..., :ctx.c_raw]) if need[0] else None
+        g_skip = conv2d.image(gr[..., ctx.c_raw:ctx.c_raw + ctx.c_skip]) if need[1] else None
+        outs = []
+        with torch.cuda.device(g.device):
+            for k, ((at, c), shp) in enumerate(zip(ctx.slots, ctx.shapes)):
+                if not need[2 + k]:
+                    outs.append(None)
+                    continue
+                gi = gr.new_empty(shp)
+                _call("az_spp_upsample_bwd", _p(gi), _p(gr[..., at:]), b, shp[1], shp[2], h, w, c, ctot, _stream())
+                outs.append(conv2d.image(gi))
+        return (g_raw, g_skip, *outs)
+
+
+def spp_concat(raw, skip, branches):
+    """[raw | skip | upsampled branches] along the channels (see _SppConcat); branches: [B,32,hs,ws] maps, any size"""
+    return _SppConcat.apply(raw, skip, *branches)
+
+
 class FeatureExtraction(nn.Module):
     IN_CHANNELS = 3
 
@@ -199,10 +253,10 @@ class FeatureExtraction(nn.Module):
             pooled[win] = p
         assert sorted(pooled) == [8, 16, 32, 64]
         win_of = dict(_SPP_WINDOWS)
-        pyramid = [upsample_bilinear_ac(
-            _convbn_unit(pooled[win_of[i]].contiguous(memory_format=torch.channels_last),
-                         getattr(self, f"branch{i}")[1], relu=True, groups=g, arith=a), size) for i in (4, 3, 2, 1)]
-        y = _convbn_unit(torch.cat([raw, skip] + pyramid, 1), self.lastconv[0], relu=True, groups=g, arith=a)
+        branches = [_convbn_unit(pooled[win_of[i]].contiguous(memory_format=torch.channels_last),
+                                 getattr(self, f"branch{i}")[1], relu=True, groups=g, arith=a) for i in (4, 3, 2, 1)]
+        # upsampling + concat in one node, the branches written straight into their slots (_SppConcat)
+        y = _convbn_unit(spp_concat(raw, skip, branches), self.lastconv[0], relu=True, groups=g, arith=a)
         return conv2d.conv(y, self.lastconv[2], a)
 
     def forward(self, x, arith=None):

@@ -393,6 +393,15 @@ int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *co
                 const float *x, const float *mean, const float *invstd, const float *gamma,
                 const float *scale, const float *shift, int relu, long long nvox, int C,
                 float *dx_amax, int split_out, void *stream);
+/* ---- SPP branch upsampling (psmnet_submodule_3.py:198-209: F.upsample(branch, (H, W), mode="bilinear") + torch.cat) ----
+ * out rows [B,H,W,out_cstride] (the pointer already offset to the branch's channel slot of the concat buffer) <- bilinear
+ * interpolation, align_corners = True, of in rows [B,hs,ws,C] (C % 4 == 0, C <= 64, C / 4 a power of two), with ATen's
+ * source positions and expression.  _bwd: grad_in [B,hs,ws,C] <- the adjoint over grad_out rows [B,H,W,gout_cstride]; one
+ * workgroup per source pixel, no atomics. */
+int az_spp_upsample_fwd(float *out, const float *in, int B, int hs, int ws, int H, int W, int C, int out_cstride,
+                        void *stream);
+int az_spp_upsample_bwd(float *grad_in, const float *grad_out, int B, int hs, int ws, int H, int W, int C,
+                        int gout_cstride, void *stream);
 /* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175; y_amax as above */
 int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, float *y_amax, void *stream);
 /* y = a + b (+ c) (+ d), n floats (n % 4 == 0; c, d may be NULL): the gradient of a tensor with up to

@@ -259,7 +259,7 @@ def test_full_model_d192_error_split(golden, arith, capsys):
         #     train-mode heads (<= 5.9e-4 px), which are what the headline workload computes
         #     (round 5: the eval ceiling per arithmetic -- profiles/r04z_gpu_tests.log measured 1.06e-3 / 1.05e-3 for the
         #     default f16x3, 1.15e-3 / 1.17e-3 for bf16x6, 1.33e-3 / 1.20e-3 for the bit-exact fp32 MFMA)
-        eval_ceiling = {"f16x3": 1.2e-3, "bf16x6": 1.3e-3}.get(arith, 1.4e-3)
+        eval_ceiling = {"f16x3": 1.2e-3}.get(arith, 1.4e-3)
         assert e_hr32.max() <= (eval_ceiling if "eval" in k else 7e-4), line
 
 
