@@ -100,8 +100,11 @@ _SIGS = {
     "az_conv2d_fwd": [_PTR] * 6 + [_INT] * 12 + [_PTR],
     "az_gru_rh": [_PTR] * 3 + [_LL, _INT, _INT, _PTR],
     "az_gru_out": [_PTR] * 4 + [_LL, _INT, _INT, _PTR],
-    "az_gru_bwd1": [_PTR] * 7 + [_LL, _INT, _INT, _PTR],
-    "az_gru_bwd2": [_PTR] * 5 + [_LL, _INT, _INT, _PTR],
+    "az_gru_bwd1": [_PTR] * 7 + [_LL, _INT, _INT, _PTR, _PTR, _PTR],
+    "az_gru_bwd2": [_PTR] * 5 + [_LL, _INT, _INT, _PTR, _PTR],
+    "az_conv2d_pack_weights_h1": [_PTR, _PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _PTR],
+    "az_conv2d_h1_fwd": [_PTR] * 9 + [_INT] * 11 + [_PTR],
+    "az_conv2d_wgrad_h1": [_PTR, _PTR, _LL] + [_PTR] * 4 + [_INT] * 9 + [_PTR],
     "az_gru_bwd3": [_PTR] * 5 + [_LL, _INT, _INT, _PTR],
     "az_conv2d_pack_weights_bf16": [_PTR, _PTR, _INT, _INT, _LL, _LL, _INT, _INT, _PTR],
     "az_conv2d_bf16_fwd": [_PTR] * 7 + [_INT] * 11 + [_PTR],

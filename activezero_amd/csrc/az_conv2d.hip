@@ -60,9 +60,14 @@ struct C2Args {
 // RAFT-Stereo GRU update (nets/raft/raft_stereo.py:98,142-172; nets/raft/update.py:19-41), same slab / weight
 // pipeline with the mid / lo parts left out.  PARTS = 2: f16x3 (az_roll_common.h) -- two scaled fp16 parts in the
 // first two parts of the same slab image, three MFMAs per block.
-template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>
+// H1 (with PARTS = 1): the ONE part is fp16 instead of bf16 -- "f16x1", the reference's real autocast arithmetic for the GRU
+// block (torch.cuda.amp.autocast is float16 on CUDA, raft_stereo.py:14): operands rounded to 11 bits once, optionally scaled
+// by a power of two from an amax array (in_amax / w_amax, either may be null = scale 1: the stand-in for GradScaler on the
+// gradient operands, train.py:303-309), one v_mfma_f32_32x32x16_f16 per block, fp32 accumulation.
+template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false, bool H1 = false>
 __global__ void __launch_bounds__(64 * NW, 2)
 conv2d_same_kernel(const C2Args a) {
+    static_assert(!H1 || PARTS == 1, "H1 is the fp16 form of the one-part arithmetic");
     constexpr int T = KH * KW;
     constexpr int HY = DIL * (KH - 1) / 2, HX = DIL * (KW - 1) / 2;
     constexpr int SY = C2_TY + 2 * HY, SX = C2_TX + 2 * HX;
@@ -103,6 +108,12 @@ conv2d_same_kernel(const C2Args a) {
     if (PARTS == 2) {  // wave-uniform power-of-two operand scales
         const int ki = az_f16_scale_exp(az_amax_read(a.in_amax));
         const int kw_ = az_f16_scale_exp(az_amax_read(a.w_amax));
+        in_scale = az_pow2(ki);
+        osc = ldexpf(1.f, -(ki + kw_));
+    }
+    if (H1) {  // (either amax may be absent: that operand is rounded as it is, the way autocast does)
+        const int ki = a.in_amax ? az_f16_scale_exp(az_amax_read(a.in_amax)) : 0;
+        const int kw_ = a.w_amax ? az_f16_scale_exp(az_amax_read(a.w_amax)) : 0;
         in_scale = az_pow2(ki);
         osc = ldexpf(1.f, -(ki + kw_));
     }
@@ -149,6 +160,9 @@ conv2d_same_kernel(const C2Args a) {
                     az_split2_f16x4(make_float4(pre[it].x * in_scale, pre[it].y * in_scale, pre[it].z * in_scale, pre[it].w * in_scale), hi, lo);
                     *reinterpret_cast<uint2 *>(dst) = hi;
                     *reinterpret_cast<uint2 *>(dst + 8) = lo;
+                } else if (H1) {
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(az_pk_f16(pre[it].x * in_scale, pre[it].y * in_scale),
+                                                                 az_pk_f16(pre[it].z * in_scale, pre[it].w * in_scale));
                 } else {
                     *reinterpret_cast<uint2 *>(dst) = make_uint2(az_pk_bf16(pre[it].x, pre[it].y), az_pk_bf16(pre[it].z, pre[it].w));
                 }
@@ -182,7 +196,10 @@ conv2d_same_kernel(const C2Args a) {
     auto step = [&](int cur, f32x16 &tn, const f32x16 &tp, const float4 (&aq)[3], const float4 (&bq)[3]) {
         // (price of the temporaries, measured against the plain six-MFMA chain into acc: +2.4 % on the
         //  extractor's forward, 10.09 vs 9.85 ms; profiles/r02_conv2d_layers_hip.txt)
-        if (PARTS == 1)
+        if (PARTS == 1 && H1)
+            acc[cur] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, aq[0]),
+                                                              __builtin_bit_cast(az_f16x8, bq[0]), acc[cur], 0, 0, 0);
+        else if (PARTS == 1)
             acc[cur] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(az_bf16x8, aq[0]),
                                                                __builtin_bit_cast(az_bf16x8, bq[0]), acc[cur], 0, 0, 0);
         else if (PARTS == 2 && PIPE) az_mfma3_step(tn, aq, bq, acc[(cur + 3) & 3], tp);
@@ -276,7 +293,7 @@ conv2d_same_kernel(const C2Args a) {
     }
 
     if (PIPE && PARTS != 1) acc[3] += t1;  // the last block's temporary
-    if (PARTS == 2) {  // undo the operand scales once, on the finished sums
+    if (PARTS == 2 || H1) {  // undo the operand scales once, on the finished sums
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m] *= osc;
     }
@@ -429,6 +446,33 @@ static int pack_bf16(float *packed, const float *w, int cin, int cout, long long
                        kh * kw, flip, 1, total);
     return az_launch_status();
 }
+// f16x1 image: [tap][cin/16][cout/32][lane 64][8] fp16 of w * 2^k (k from w's amax array, 0 without one)
+__global__ void __launch_bounds__(256)
+conv2d_pack_h1_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax, int cin,
+                      int cout, long long s_co, long long s_ci, int taps, int flip, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float scale = amax ? az_pow2(az_f16_scale_exp(az_amax_read(amax))) : 1.f;  // (before the early exit: a wave-wide read)
+    if (idx >= total) return;
+    const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    long long r = idx >> 9;
+    const int nt = cout / 32, nch = cin / 16;
+    const int n = (int)(r % nt); r /= nt;
+    const int cc = (int)(r % nch);
+    const int t = (int)(r / nch);
+    const int co = n * 32 + (lane & 31), ci = cc * 16 + 8 * (lane >> 5) + j;
+    dst[idx] = __builtin_bit_cast(unsigned short, (_Float16)(src[co * s_co + ci * s_ci + (flip ? taps - 1 - t : t)] * scale));
+}
+/* one-part fp16 image of a 3x3 weight (az_conv2d_h1_fwd); flip = 1 with (cin, cout, stride_out, stride_in) swapped: the
+ * image of the layer's input gradient.  w_amax may be NULL (no scaling). */
+extern "C" int az_conv2d_pack_weights_h1(float *packed, const float *w, const float *w_amax, int cin, int cout,
+                                         long long stride_out, long long stride_in, int flip, void *stream) {
+    AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w);
+    if (az_conv2d_packed_floats(cin, cout, 3, 3) < 0) return AZ_EUNSUPPORTED;
+    const long long total = 9LL * cin * cout;
+    hipLaunchKernelGGL(conv2d_pack_h1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, az_stream(stream),
+                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, stride_out, stride_in, 9, flip, total);
+    return az_launch_status();
+}
 extern "C" int az_conv2d_pack_weights_bf16(float *packed, const float *w, int cin, int cout, long long stride_out,
                                            long long stride_in, int kh, int kw, void *stream) {
     return pack_bf16(packed, w, cin, cout, stride_out, stride_in, kh, kw, 0, stream);
@@ -440,22 +484,22 @@ extern "C" int az_conv2d_pack_weights_bf16_flipped(float *packed, const float *w
     return pack_bf16(packed, w, cin, cout, stride_out, stride_in, kh, kw, 1, stream);
 }
 
-template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>
+template <int NW, int KH, int KW, int DIL, int PARTS = 3, bool STATS = false, bool H1 = false>
 static int launch_c2(C2Args a, hipStream_t s) {
     a.ngroups = (a.cout / 32) / NW;
     const long long blocks = (long long)a.B * a.tiles_y * a.tiles_x * a.ngroups;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv2d_same_kernel<NW, KH, KW, DIL, PARTS, STATS>), dim3((unsigned)blocks), dim3(64 * NW), 0, s, a);
+    hipLaunchKernelGGL((conv2d_same_kernel<NW, KH, KW, DIL, PARTS, STATS, H1>), dim3((unsigned)blocks), dim3(64 * NW), 0, s, a);
     return az_launch_status();
 }
 
-template <int KH, int KW, int DIL, int PARTS = 3, bool STATS = false>
+template <int KH, int KW, int DIL, int PARTS = 3, bool STATS = false, bool H1 = false>
 static int dispatch_nw(const C2Args &a, hipStream_t s) {
     const int nt = a.cout / 32;
-    if (nt % 4 == 0) return launch_c2<4, KH, KW, DIL, PARTS, STATS>(a, s);
-    if (nt % 3 == 0) return launch_c2<3, KH, KW, DIL, PARTS, STATS>(a, s);
-    if (nt % 2 == 0) return launch_c2<2, KH, KW, DIL, PARTS, STATS>(a, s);
-    return launch_c2<1, KH, KW, DIL, PARTS, STATS>(a, s);
+    if (nt % 4 == 0) return launch_c2<4, KH, KW, DIL, PARTS, STATS, H1>(a, s);
+    if (nt % 3 == 0) return launch_c2<3, KH, KW, DIL, PARTS, STATS, H1>(a, s);
+    if (nt % 2 == 0) return launch_c2<2, KH, KW, DIL, PARTS, STATS, H1>(a, s);
+    return launch_c2<1, KH, KW, DIL, PARTS, STATS, H1>(a, s);
 }
 
 extern "C" int az_conv2d_fwd(float *out, const float *in, const float *packed_w, const float *scale,
@@ -517,10 +561,10 @@ extern "C" int az_conv2d_fwd_stats(float *out, float *partials, float *counts, c
 /* 3x3 stride-1 "same" convolution with plain bf16 operands (one MFMA per block, fp32 accumulation, fp32 in / out):
  * out = act(conv(in) + bias[co] + residual); act 0 none, 1 ReLU, 2 sigmoid, 3 tanh, 4 = the GRU state update
  * (1 - z) * h + z * tanh(.) with gate z and previous state h read at gate_z / gate_h. */
-extern "C" int az_conv2d_bf16_fwd(float *out, const float *in, const float *packed_w, const float *bias,
-                                  const float *residual, const float *gate_z, const float *gate_h, int act, int B,
-                                  int H, int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
-                                  int z_cstride, int h_cstride, void *stream) {
+static int conv2d_onepart_fwd(float *out, const float *in, const float *packed_w, const float *bias,
+                              const float *residual, const float *gate_z, const float *gate_h, int act, int B,
+                              int H, int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
+                              int z_cstride, int h_cstride, void *stream, bool h1, const float *in_amax, const float *w_amax) {
     AZ_REQUIRE_PTR(out); AZ_REQUIRE_PTR(in); AZ_REQUIRE_PTR(packed_w);
     AZ_REQUIRE(B > 0 && H > 0 && W > 0 && cin > 0 && cout > 0 && act >= 0 && act <= 4);
     if (cin % 16 || cout % 32) return AZ_EUNSUPPORTED;
@@ -538,7 +582,26 @@ extern "C" int az_conv2d_bf16_fwd(float *out, const float *in, const float *pack
     a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout;
     a.in_cs = in_cstride; a.out_cs = out_cstride; a.res_cs = res_cstride;
     a.tiles_y = (H + C2_TY - 1) / C2_TY; a.tiles_x = (W + C2_TX - 1) / C2_TX;
+    a.in_amax = in_amax; a.w_amax = w_amax;
+    if (h1) return dispatch_nw<3, 3, 1, 1, false, true>(a, az_stream(stream));
     return dispatch_nw<3, 3, 1, 1>(a, az_stream(stream));
+}
+extern "C" int az_conv2d_bf16_fwd(float *out, const float *in, const float *packed_w, const float *bias,
+                                  const float *residual, const float *gate_z, const float *gate_h, int act, int B,
+                                  int H, int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
+                                  int z_cstride, int h_cstride, void *stream) {
+    return conv2d_onepart_fwd(out, in, packed_w, bias, residual, gate_z, gate_h, act, B, H, W, cin, cout, in_cstride, out_cstride,
+                              res_cstride, z_cstride, h_cstride, stream, false, nullptr, nullptr);
+}
+/* the same with ONE FP16 part per operand ("f16x1": what torch.cuda.amp.autocast computes on CUDA, raft_stereo.py:14): weights
+ * packed by az_conv2d_pack_weights_h1; in_amax / w_amax (either may be NULL = scale 1): amax arrays for a power-of-two operand
+ * scale -- the gradient operands of the backward launches get one, in place of the reference's GradScaler */
+extern "C" int az_conv2d_h1_fwd(float *out, const float *in, const float *packed_w, const float *in_amax, const float *w_amax,
+                                const float *bias, const float *residual, const float *gate_z, const float *gate_h, int act, int B,
+                                int H, int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
+                                int z_cstride, int h_cstride, void *stream) {
+    return conv2d_onepart_fwd(out, in, packed_w, bias, residual, gate_z, gate_h, act, B, H, W, cin, cout, in_cstride, out_cstride,
+                              res_cstride, z_cstride, h_cstride, stream, true, in_amax, w_amax);
 }
 
 /* az_conv2d_fwd / az_conv2d_fwd_stats on the f16x3 arithmetic (include/azhip.h): in_amax / w_amax = device scalars

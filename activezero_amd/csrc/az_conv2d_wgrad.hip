@@ -39,7 +39,7 @@ struct W2Args {
     int fine_dy;  // extra row offset of the fine rows (single-row launches of a multi-row kernel)
     int tap0;     // first workspace tap of this launch
     const float *coarse_amax, *fine_amax;  // AR 1 (f16x3): amax arrays of dy and x
-    int plain_bf16;                        // AR 2
+    int plain_bf16;                        // 1: AR 2 (one bf16 part), 2: AR 3 (one fp16 part, amax arrays optional)
 };
 
 // AR: 0 = bf16x6, 1 = f16x3 (az_roll_common.h; the LDS images keep their three-part strides), 2 = plain bf16 operands
@@ -49,10 +49,18 @@ template <int MT, int NT, int KH, int KW, int DIL, int AR = 0>
 __global__ void __launch_bounds__(64 * MT * NT, 2)
 conv2d_wgrad_kernel(const W2Args a) {
     constexpr int T = KH * KW;
-    constexpr int NP = AR == 2 ? 1 : AR ? 2 : 3;
+    // AR 3 = "f16x1": ONE fp16 part per operand (what the reference's autocast computes on CUDA), each optionally scaled by a
+    // power of two from an amax array (null = scale 1)
+    constexpr int NP = (AR == 2 || AR == 3) ? 1 : AR ? 2 : 3;
     float c_scale = 1.f, f_scale = 1.f, o_scale = 1.f;
     if (AR == 1) {
         const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax)), kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
+        c_scale = az_pow2(kc); f_scale = az_pow2(kf);
+        o_scale = ldexpf(1.f, -(kc + kf));
+    }
+    if (AR == 3) {
+        const int kc = a.coarse_amax ? az_f16_scale_exp(az_amax_read(a.coarse_amax)) : 0;
+        const int kf = a.fine_amax ? az_f16_scale_exp(az_amax_read(a.fine_amax)) : 0;
         c_scale = az_pow2(kc); f_scale = az_pow2(kf);
         o_scale = ldexpf(1.f, -(kc + kf));
     }
@@ -96,6 +104,10 @@ conv2d_wgrad_kernel(const W2Args a) {
         uint2 hi, mid, lo;
         if (AR == 2) {
             *reinterpret_cast<uint2 *>(dst_part0) = make_uint2(az_pk_bf16(v.x, v.y), az_pk_bf16(v.z, v.w));
+            return;
+        }
+        if (AR == 3) {
+            *reinterpret_cast<uint2 *>(dst_part0) = make_uint2(az_pk_f16(v.x * scale_, v.y * scale_), az_pk_f16(v.z * scale_, v.w * scale_));
             return;
         }
         if (AR) {
@@ -204,6 +216,10 @@ conv2d_wgrad_kernel(const W2Args a) {
                         acc[kh * KW + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
                         continue;
                     }
+                    if constexpr (AR == 3) {
+                        acc[kh * KW + kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bfr[0]), c, 0, 0, 0);
+                        continue;
+                    }
                     if constexpr (AR == 1) {
                         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[1]), __builtin_bit_cast(az_f16x8, bfr[0]), c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(az_f16x8, af[0]), __builtin_bit_cast(az_f16x8, bfr[1]), c, 0, 0, 0);
@@ -228,7 +244,7 @@ conv2d_wgrad_kernel(const W2Args a) {
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
             const int m = co0 + mt * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-            atomicAdd(&a.ws[((size_t)(a.tap0 + t) * a.CM + m) * a.CN + ci0 + nt * 32 + row], AR == 1 ? acc[t][rg] * o_scale : acc[t][rg]);
+            atomicAdd(&a.ws[((size_t)(a.tap0 + t) * a.CM + m) * a.CN + ci0 + nt * 32 + row], (AR == 1 || AR == 3) ? acc[t][rg] * o_scale : acc[t][rg]);
         }
     }
 }
@@ -279,10 +295,14 @@ static int launch_w2(W2Args a, hipStream_t s) {
     a.nitems = base_items * a.nhseg;
     if (a.nitems < a.blocks_per_combo) a.blocks_per_combo = (int)((a.nitems + 7) & ~7LL);
     if (plain) {
-        if constexpr (KH == 3 && KW == 3 && DIL == 1)  // (the GRU's convolutions: the only users)
-            hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 2>), dim3(a.blocks_per_combo * ncombo),
-                               dim3(64 * MT * NT), 0, s, a);
-        else
+        if constexpr (KH == 3 && KW == 3 && DIL == 1) {  // (the GRU's convolutions: the only users)
+            if (a.plain_bf16 == 2)
+                hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 3>), dim3(a.blocks_per_combo * ncombo),
+                                   dim3(64 * MT * NT), 0, s, a);
+            else
+                hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 2>), dim3(a.blocks_per_combo * ncombo),
+                                   dim3(64 * MT * NT), 0, s, a);
+        } else
             return AZ_EUNSUPPORTED;
     } else if (f16)
         hipLaunchKernelGGL((conv2d_wgrad_kernel<MT, NT, KH, KW, DIL, 1>), dim3(a.blocks_per_combo * ncombo),
@@ -370,6 +390,14 @@ extern "C" int az_conv2d_wgrad_f16(float *grad_w, float *workspace, long long wo
     AZ_REQUIRE_PTR(go_amax); AZ_REQUIRE_PTR(in_amax);
     return conv2d_wgrad_impl(grad_w, workspace, workspace_bytes, grad_out, in, go_amax, in_amax, B, H, W, cm, cn, cm_real,
                              cn_real, go_cstride, in_cstride, kh, kw, dilation, stream);
+}
+
+/* az_conv2d_wgrad_bf16 with ONE FP16 part per operand ("f16x1", az_conv2d_h1_fwd): go_amax / in_amax may each be NULL */
+extern "C" int az_conv2d_wgrad_h1(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out,
+                                  const float *in, const float *go_amax, const float *in_amax, int B, int H, int W, int cm, int cn,
+                                  int cm_real, int cn_real, int go_cstride, int in_cstride, void *stream) {
+    return conv2d_wgrad_impl(grad_w, workspace, workspace_bytes, grad_out, in, go_amax, in_amax, B, H, W, cm, cn, cm_real,
+                             cn_real, go_cstride, in_cstride, 3, 3, 1, stream, 2);
 }
 
 /* az_conv2d_wgrad with plain bf16 operands (round-to-nearest, one MFMA per 16-deep block, fp32 accumulation, fp32 in / out):

@@ -83,6 +83,12 @@ __device__ __forceinline__ void az_split2_f16_pair(float x0, float x1, unsigned 
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+// two values -> one packed fp16 pair, round-to-nearest (the one-part "f16x1" operands of the RAFT-Stereo GRU convolutions)
+__device__ __forceinline__ unsigned az_pk_f16(float a, float b) {
+    az_f16x2 p;
+    p[0] = (_Float16)a; p[1] = (_Float16)b;
+    return __builtin_bit_cast(unsigned, p);
+}
 // four values (already scaled) -> two 8-byte pieces
 __device__ __forceinline__ void az_split2_f16x4(const float4 &v, uint2 &hi, uint2 &lo) {
     az_split2_f16_pair(v.x, v.y, hi.x, lo.x);

@@ -26,7 +26,7 @@ import weakref
 import torch
 import torch.nn as nn
 
-from activezero_amd import _lib, conv2d, profiler
+from activezero_amd import _lib, conv2d, conv3d, profiler
 from activezero_amd.conv3d import _CACHE_LOCK, _cache_get, _cache_key, _cache_put
 from activezero_amd.ops import _call, _chk, _p, _stream
 
@@ -78,16 +78,43 @@ def _pack_bf16(weights, cache):
     return packed
 
 
-def conv3x3_bf16(xr, packed, cin, cout, bias=None, residual=None, act=ACT_NONE, gate_z=None, gate_h=None):
-    """xr [B,H,W,>=cin] fp32 rows -> act(conv3x3(xr[..., :cin]) + bias + residual) as [B,H,W,cout] rows."""
+def conv3x3_bf16(xr, packed, cin, cout, bias=None, residual=None, act=ACT_NONE, gate_z=None, gate_h=None, h1=False,
+                 in_amax=None):
+    """xr [B,H,W,>=cin] fp32 rows -> act(conv3x3(xr[..., :cin]) + bias + residual) as [B,H,W,cout] rows.
+    h1: one FP16 part per operand (az_conv2d_h1_fwd; `packed` from az_conv2d_pack_weights_h1) instead of one bf16 part;
+    in_amax: amax array of xr for a power-of-two operand scale (gradient operands), None = rounded as it is."""
     b, h, w, cx = xr.shape
     out = xr.new_empty(b, h, w, cout)
-    with profiler.scope(f"gru_conv3x3_bf16_{cin}_{cout}", flops=18.0 * cin * cout * b * h * w, peak=PEAK_BF16):
-        _call("az_conv2d_bf16_fwd", _p(out), _p(xr), _p(packed), _p(bias), _p(residual), _p(gate_z), _p(gate_h),
-              act, b, h, w, cin, cout, cx, cout, residual.shape[-1] if residual is not None else 0,
-              gate_z.shape[-1] if gate_z is not None else 0, gate_h.shape[-1] if gate_h is not None else 0,
-              _stream())
+    tail = (act, b, h, w, cin, cout, cx, cout, residual.shape[-1] if residual is not None else 0,
+            gate_z.shape[-1] if gate_z is not None else 0, gate_h.shape[-1] if gate_h is not None else 0, _stream())
+    with profiler.scope(f"gru_conv3x3_{'f16x1' if h1 else 'bf16'}_{cin}_{cout}", flops=18.0 * cin * cout * b * h * w, peak=PEAK_BF16):
+        if h1:
+            _call("az_conv2d_h1_fwd", _p(out), _p(xr), _p(packed), _p(in_amax), None, _p(bias), _p(residual), _p(gate_z),
+                  _p(gate_h), *tail)
+        else:
+            _call("az_conv2d_bf16_fwd", _p(out), _p(xr), _p(packed), _p(bias), _p(residual), _p(gate_z), _p(gate_h), *tail)
     return out
+
+
+def _pack_h1(weights, flipped, cache=True):
+    """one-part FP16 image (forward, or the input gradient's with flipped = True) of [Cout_i, Cin, 3, 3] weights
+    concatenated along Cout; unscaled, as autocast casts them"""
+    key = None
+    if cache:
+        key = ("h1", bool(flipped)) + _cache_key(*weights)
+        hit = _cache_get(_PACK_CACHE, key)
+        if hit is not None:
+            return hit[0]
+    w = torch.cat([x.detach().float() for x in weights], 0).contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    packed = torch.empty(9 * cin * cout // 2, dtype=torch.float32, device=w.device)
+    if flipped:
+        _call("az_conv2d_pack_weights_h1", _p(packed), _p(w), None, cout, cin, 9, cin * 9, 1, _stream())
+    else:
+        _call("az_conv2d_pack_weights_h1", _p(packed), _p(w), None, cin, cout, cin * 9, 9, 0, _stream())
+    if key is not None:
+        _cache_put(_PACK_CACHE, key, (packed, weights), 64)
+    return packed
 
 
 def _rows(t):
@@ -160,8 +187,11 @@ class _GRUStepBf16(torch.autograd.Function):
     operator-by-operator form ("bf16_ops"), a quarter of its launches and tensor passes."""
 
     @staticmethod
-    def forward(ctx, h, cz, cr, cq, czr, cqr, wz, wr, wq, bz, br, bq, *xs):
-        """czr / cqr: the fp32 rows of the context terms (`_context_rows`; cz / cr / cq themselves only receive gradients)"""
+    def forward(ctx, h1, h, cz, cr, cq, czr, cqr, wz, wr, wq, bz, br, bq, *xs):
+        """h1: True = "f16x1" (one fp16 part per operand: the reference's float16 autocast), False = "bf16".
+        czr / cqr: the fp32 rows of the context terms (`_context_rows`; cz / cr / cq themselves only receive gradients)"""
+        ctx.h1 = h1
+        pk = (lambda ws: _pack_h1(ws, False)) if h1 else (lambda ws: _pack_bf16(ws, True))
         c, ci = h.shape[1], sum(t.shape[1] for t in xs)
         with torch.cuda.device(h.device):
             b, _, hh, ww = h.shape
@@ -173,10 +203,10 @@ class _GRUStepBf16(torch.autograd.Function):
                 hx[..., at:at + t.shape[1]] = t.permute(0, 2, 3, 1)
                 at += t.shape[1]
             bzr = torch.cat([bz, br]).detach().float().contiguous()
-            zr = conv3x3_bf16(hx, _pack_bf16((wz, wr), True), c + ci, 2 * c, bzr, czr, ACT_SIGMOID)
+            zr = conv3x3_bf16(hx, pk((wz, wr)), c + ci, 2 * c, bzr, czr, ACT_SIGMOID, h1=h1)
             rhx = torch.empty_like(hx)
             _call("az_gru_rh", _p(rhx), _p(zr), _p(hx), npix, c, ci, _stream())
-            q = conv3x3_bf16(rhx, _pack_bf16((wq,), True), c + ci, c, bq.detach().float().contiguous(), cqr, ACT_TANH)
+            q = conv3x3_bf16(rhx, pk((wq,)), c + ci, c, bq.detach().float().contiguous(), cqr, ACT_TANH, h1=h1)
             hn = torch.empty_like(q)
             _call("az_gru_out", _p(hn), _p(zr), _p(q), _p(hx), npix, c, ci, _stream())
         ctx.save_for_backward(hx, rhx, zr, q, wz, wr, wq)
@@ -195,47 +225,62 @@ class _GRUStepBf16(torch.autograd.Function):
             dq = torch.empty_like(q)
             dzr = torch.empty_like(zr)
             dh_acc = torch.empty_like(q)
-            _call("az_gru_bwd1", _p(dq), _p(dzr), _p(dh_acc), _p(g), _p(zr), _p(q), _p(hx), npix, c, ci, _stream())
-            d_rhx = conv3x3_bf16(dq, _pack_bf16_flipped((wq,), True), c, ct)
-            _call("az_gru_bwd2", _p(dzr), _p(dh_acc), _p(d_rhx), _p(zr), _p(hx), npix, c, ci, _stream())
-            d_hx = conv3x3_bf16(dzr, _pack_bf16_flipped((wz, wr), True), 2 * c, ct)
+            h1 = ctx.h1
+            # f16x1: the gradient operands are scaled by a power of two from their amax (taken by the gate kernels that write
+            # them) before the fp16 rounding -- the job GradScaler does for the reference (train.py:303-309)
+            am_q = conv3d._ZEROS.take(q) if h1 else None
+            am_z = conv3d._ZEROS.take(q) if h1 else None
+            pkf = (lambda ws: _pack_h1(ws, True)) if h1 else (lambda ws: _pack_bf16_flipped(ws, True))
+            _call("az_gru_bwd1", _p(dq), _p(dzr), _p(dh_acc), _p(g), _p(zr), _p(q), _p(hx), npix, c, ci, _p(am_q), _p(am_z), _stream())
+            d_rhx = conv3x3_bf16(dq, pkf((wq,)), c, ct, h1=h1, in_amax=am_q)
+            _call("az_gru_bwd2", _p(dzr), _p(dh_acc), _p(d_rhx), _p(zr), _p(hx), npix, c, ci, _p(am_z), _stream())
+            d_hx = conv3x3_bf16(dzr, pkf((wz, wr)), 2 * c, ct, h1=h1, in_amax=am_z)
             dh = torch.empty_like(q)
             dx = hx.new_empty(b, hh, ww, ci)
             _call("az_gru_bwd3", _p(dh), _p(dx), _p(dh_acc), _p(d_rhx), _p(d_hx), npix, c, ci, _stream())
 
-            def wgrad(go, xin, cout):
+            def wgrad(go, xin, cout, go_amax):
                 gw = hx.new_empty(cout, ct, 3, 3)
                 ws_bytes = _lib.lib().az_conv2d_wgrad_workspace(cout, ct, 3, 3)
                 ws = hx.new_empty(ws_bytes // 4)
-                with profiler.scope(f"gru_wgrad_bf16_{cout}_{ct}", flops=18.0 * ct * cout * npix, peak=PEAK_BF16):
-                    _call("az_conv2d_wgrad_bf16", _p(gw), _p(ws), ws_bytes, _p(go), _p(xin), b, hh, ww, cout, ct, cout, ct,
-                          go.shape[-1], xin.shape[-1], _stream())
+                with profiler.scope(f"gru_wgrad_{'f16x1' if h1 else 'bf16'}_{cout}_{ct}", flops=18.0 * ct * cout * npix, peak=PEAK_BF16):
+                    if h1:
+                        _call("az_conv2d_wgrad_h1", _p(gw), _p(ws), ws_bytes, _p(go), _p(xin), _p(go_amax), None, b, hh, ww, cout, ct,
+                              cout, ct, go.shape[-1], xin.shape[-1], _stream())
+                    else:
+                        _call("az_conv2d_wgrad_bf16", _p(gw), _p(ws), ws_bytes, _p(go), _p(xin), b, hh, ww, cout, ct, cout, ct,
+                              go.shape[-1], xin.shape[-1], _stream())
                 return gw
 
             gwz = gwr = gwq = gbz = gbr = gbq = None
-            if need[6] or need[7]:
-                gwzr = wgrad(dzr, hx, 2 * c)
+            if need[7] or need[8]:
+                gwzr = wgrad(dzr, hx, 2 * c, am_z)
                 gwz, gwr = gwzr[:c], gwzr[c:]
-            if need[8]:
-                gwq = wgrad(dq, rhx, c)
-            if need[9] or need[10]:
+            if need[9]:
+                gwq = wgrad(dq, rhx, c, am_q)
+            if need[10] or need[11]:
                 gbzr = dzr.sum(dim=(0, 1, 2))
                 gbz, gbr = gbzr[:c], gbzr[c:]
-            if need[11]:
+            if need[12]:
                 gbq = dq.sum(dim=(0, 1, 2))
             img = lambda t: t.permute(0, 3, 1, 2)
             gxs, at = [], 0
             for i, n in enumerate(xsplit):
-                gxs.append(img(dx[..., at:at + n]) if need[12 + i] else None)
+                gxs.append(img(dx[..., at:at + n]) if need[13 + i] else None)
                 at += n
-            return (img(dh) if need[0] else None, img(dzr[..., :c]) if need[1] else None, img(dzr[..., c:]) if need[2] else None,
-                    img(dq) if need[3] else None, None, None, gwz, gwr, gwq, gbz, gbr, gbq, *gxs)
+            return (None, img(dh) if need[1] else None, img(dzr[..., :c]) if need[2] else None, img(dzr[..., c:]) if need[3] else None,
+                    img(dq) if need[4] else None, None, None, gwz, gwr, gwq, gbz, gbr, gbq, *gxs)
 
 
 class ConvGRU(nn.Module):
-    # "bf16": the reference's autocast arithmetic, one fused autograd node per update; "bf16_ops": the same arithmetic
-    # operator by operator (first round-4 form); "bf16x6": fp32-class convolutions (round 3)
-    train_arithmetic = "bf16"
+    # Arithmetic of the convolutions under autograd (the gates are fp32 in every mode):
+    #   "f16x1"    one FP16 part per operand, fp32 accumulation: what the reference's torch.cuda.amp.autocast computes on CUDA
+    #              (raft_stereo.py:14; GradScaler's job done by a power-of-two scale from each gradient operand's amax); one fused
+    #              autograd node per update.  Default since round 5.
+    #   "bf16"     one BF16 part (round 4's default): the same node, operands rounded 8x COARSER than the reference does --
+    #              its gradients sit 1.2-2.8e-3 from the fp64 ones where the reference's fp16 autocast sits 3-7e-4 (G12).
+    #   "bf16_ops" the bf16 arithmetic operator by operator (first round-4 form); "bf16x6": fp32-class convolutions (round 3)
+    train_arithmetic = "f16x1"
 
     def __init__(self, hidden_dim, input_dim, kernel_size=3):
         super().__init__()
@@ -278,24 +323,24 @@ class ConvGRU(nn.Module):
         with torch.autocast("cuda", enabled=False):
             # (the fused node's convolutions need hidden % 32 == 0 and (hidden + input) % 32 == 0: the reference's 128 + 256;
             #  every input part a multiple of 4 channels for the float4 kernels -- RAFT's 36 correlation + 220 context do)
-            if self.train_arithmetic == "bf16" and h.shape[1] % 32 == 0 and (h.shape[1] + self.input_dim) % 32 == 0:
+            if self.train_arithmetic in ("bf16", "f16x1") and h.shape[1] % 32 == 0 and (h.shape[1] + self.input_dim) % 32 == 0:
                 with torch.cuda.device(h.device):
                     czr, cqr = _context_rows(cz, cr, cq)  # looked up on the caller's tensors, BEFORE any cast
-                return _GRUStepBf16.apply(h.float(), cz, cr, cq, czr, cqr, self.convz.weight, self.convr.weight,
+                return _GRUStepBf16.apply(self.train_arithmetic == "f16x1", h.float(), cz, cr, cq, czr, cqr, self.convz.weight, self.convr.weight,
                                           self.convq.weight, self.convz.bias, self.convr.bias, self.convq.bias,
                                           *[t.float() for t in x_list])
             h, cz, cr, cq = h.float(), cz.float(), cr.float(), cq.float()
             x = torch.cat([t.float() for t in x_list], 1)
             hx = torch.cat([h, x], 1).contiguous(memory_format=torch.channels_last)
 
-            if self.train_arithmetic in ("bf16", "bf16_ops"):
+            if self.train_arithmetic in ("bf16", "bf16_ops", "f16x1"):
                 def conv(m, t):
                     return _Conv3x3Bf16.apply(t, m.weight, m.bias)
             else:
                 def conv(m, t):
                     return conv2d.conv_same(t, m.weight) + m.bias.view(1, -1, 1, 1)
 
-            if self.train_arithmetic in ("bf16", "bf16_ops"):  # z and r read the same operand: one convolution with 2 x hidden outputs
+            if self.train_arithmetic in ("bf16", "bf16_ops", "f16x1"):  # z and r read the same operand: one convolution with 2 x hidden outputs
                 zr = _Conv3x3Bf16.apply(hx, torch.cat([self.convz.weight, self.convr.weight], 0),
                                         torch.cat([self.convz.bias, self.convr.bias], 0))
                 z, r = torch.sigmoid(zr[:, :self.hidden_dim] + cz), torch.sigmoid(zr[:, self.hidden_dim:] + cr)

@@ -477,16 +477,32 @@ int az_conv2d_bf16_fwd(float *out, const float *in, const float *packed_w, const
                        const float *residual, const float *gate_z, const float *gate_h, int act, int B, int H,
                        int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride,
                        int z_cstride, int h_cstride, void *stream);
+/* "f16x1" -- the same three entry points with ONE FP16 part per operand: what torch.cuda.amp.autocast computes on CUDA
+ * (raft_stereo.py:14; the bf16 form above rounds operands 8x coarser than the reference does).  in_amax / w_amax / go_amax
+ * (each may be NULL = no scaling, as autocast): amax arrays for a power-of-two operand scale -- the gradient operands of the
+ * backward launches get one (az_gru_bwd1 / az_gru_bwd2 write them), in place of the reference's GradScaler (train.py:303-309).
+ * az_conv2d_pack_weights_h1: flip = 1 with (cin, cout, stride_out, stride_in) swapped = the input-gradient image. */
+int az_conv2d_pack_weights_h1(float *packed, const float *w, const float *w_amax, int cin, int cout, long long stride_out,
+                              long long stride_in, int flip, void *stream);
+int az_conv2d_h1_fwd(float *out, const float *in, const float *packed_w, const float *in_amax, const float *w_amax,
+                     const float *bias, const float *residual, const float *gate_z, const float *gate_h, int act, int B, int H,
+                     int W, int cin, int cout, int in_cstride, int out_cstride, int res_cstride, int z_cstride,
+                     int h_cstride, void *stream);
+int az_conv2d_wgrad_h1(float *grad_w, float *workspace, long long workspace_bytes, const float *grad_out, const float *in,
+                       const float *go_amax, const float *in_amax, int B, int H, int W, int cm, int cn, int cm_real,
+                       int cn_real, int go_cstride, int in_cstride, void *stream);
 /* Gate arithmetic of the ConvGRU update under autograd (nets/raft/update.py:32-41 in training, train.py:303-309): dense
  * [npix][channels] fp32 rows; hx = [h (hid) | x (inp)], zr = [z | r] (2 hid), rhx = [r * h | x]; see az_gru_gates.hip.
  * forward: az_gru_rh (rhx from zr, hx), az_gru_out (h' = (1 - z) h + z q); backward: az_gru_bwd1 (g = dL/dh' -> dq_pre,
  * dzr[:hid], dh_acc), az_gru_bwd2 (d_rhx -> dzr[hid:], dh_acc +=), az_gru_bwd3 (dh, dx from dh_acc, d_rhx, d_hx). */
 int az_gru_rh(float *rhx, const float *zr, const float *hx, long long npix, int hid, int inp, void *stream);
 int az_gru_out(float *hn, const float *zr, const float *q, const float *hx, long long npix, int hid, int inp, void *stream);
+/* (dq_amax / dzr_amax: amax arrays, both or neither, ZERO before az_gru_bwd1: max |dq_pre| and -- completed by az_gru_bwd2 --
+ * max |dzr|, the operand scales of the f16x1 gradient convolutions) */
 int az_gru_bwd1(float *dq_pre, float *dzr, float *dh_acc, const float *g, const float *zr, const float *q, const float *hx,
-                long long npix, int hid, int inp, void *stream);
+                long long npix, int hid, int inp, float *dq_amax, float *dzr_amax, void *stream);
 int az_gru_bwd2(float *dzr, float *dh_acc, const float *d_rhx, const float *zr, const float *hx, long long npix, int hid, int inp,
-                void *stream);
+                float *dzr_amax, void *stream);
 int az_gru_bwd3(float *dh, float *dx, const float *dh_acc, const float *d_rhx, const float *d_hx, long long npix, int hid, int inp,
                 void *stream);
 /* the extractor's first layer (psmnet_submodule_3.py:97-99: 3x3, stride 2, pad 1 on a 3- or 6-channel
