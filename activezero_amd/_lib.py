@@ -36,9 +36,12 @@ _SIGS = {
     "az_lcn": [_PTR] * 3 + [_INT] * 4 + [_C.c_float, _C.c_longlong, _PTR],
     "az_sum4": [_PTR] * 5 + [_LL, _PTR],
     "az_spp_upsample_fwd": [_PTR, _PTR] + [_INT] * 7 + [_PTR],
-    "az_spp_upsample_bwd": [_PTR, _PTR] + [_INT] * 7 + [_PTR],
+    "az_spp_upsample_bwd_workspace": [_INT] * 4,
+    "az_spp_upsample_bwd": [_PTR, _PTR, _LL, _PTR] + [_INT] * 7 + [_PTR],
     "az_costconv_edge_width": [_INT, _INT],
     "az_costconv_num_classes": [_INT],
+    "az_costconv_merge_fwd": [_PTR] * 5 + [_INT, _PTR],
+    "az_costconv_merge_bwd": [_PTR] * 5 + [_INT, _PTR],
     "az_costconv_assemble_fwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_costconv_assemble_bwd": [_PTR] * 4 + [_INT] * 4 + [_PTR],
     "az_bn3d_stats_tiles": [_LL, _INT],
@@ -122,7 +125,7 @@ _SIGS = {
     "az_corr1d_lookup_bwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
 }
 _RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_stats_tiles": _LL, "az_conv2d_roll_packed_floats": _LL, "az_conv2d_roll_stats_rows": _LL, "az_conv3d_packed_floats": _LL, "az_conv3d_packed_floats_f16": _LL, "az_conv3d_stats_tiles_f16": _LL,
-            "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL,
+            "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL, "az_spp_upsample_bwd_workspace": _LL,
             "az_bn3d_stats_tiles": _LL, "az_bn2d_workspace": _LL,
             "az_conv2d_packed_floats": _LL, "az_conv2d_wgrad_workspace": _LL, "az_ir_pattern_workspace": _LL,
             "az_bn3d_finalize_scratch": _LL, "az_conv2d_stats_tiles": _LL}

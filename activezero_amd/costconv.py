@@ -67,14 +67,43 @@ def _merged_kernels(weight, ndisp):
             return hit[:3]
     cl = torch.channels_last
     ml, mr = _masks(weight.device, ndisp)
-    kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml)          # [cls, dl, o, i, 3, 3]
+    # kl = einsum("oidhw,cedw->ceoihw", weight[:, :32], ml), kr = einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr)
+    if weight.is_cuda:
+        kl, kr = _Merge.apply(weight, ml, mr, ncls)                      # [cls, dl, o, i, 3, 3], [cls, xb, o, i, 3, 5]
+    else:  # (tests/test_costconv_cpu.py checks this algebra on the host; every kernel downstream rejects CPU tensors)
+        kl = torch.einsum("oidhw,cedw->ceoihw", weight[:, :32], ml)
+        kr = torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr)
     out = (kl[:, 4].reshape(ncls * 32, 32, 3, 3).contiguous(memory_format=cl),
            kl[:, :4].reshape(ncls * 4 * 32, 32, 3, 3).contiguous(memory_format=cl),
-           torch.einsum("oidhw,cedwj->ceoihj", weight[:, 32:], mr).reshape(ncls * 2 * 32, 32, 3, 5)
-           .contiguous(memory_format=cl))
+           kr.reshape(ncls * 2 * 32, 32, 3, 5).contiguous(memory_format=cl))
     if key is not None:
         _cache_put(_MERGED_CACHE, key, out + (weight,), 16)  # (keeps the source alive: its address stays unique)
     return out
+
+
+class _Merge(torch.autograd.Function):
+    """the two masked depth sums of the Conv3d weight (module docstring) on az_costconv_merge_fwd / _bwd -- weight-space
+    einsums of 55 K elements that were the step's last rocBLAS launches"""
+
+    @staticmethod
+    def forward(ctx, weight, ml, mr, ncls):
+        w = _chk(weight.detach().contiguous(), "weight")
+        kl = w.new_empty(ncls, NDL, 32, 32, 3, 3)
+        kr = w.new_empty(ncls, 2, 32, 32, 3, 5)
+        with torch.cuda.device(w.device):
+            _call("az_costconv_merge_fwd", _p(kl), _p(kr), _p(w), _p(ml), _p(mr), ncls, _stream())
+        ctx.save_for_backward(ml, mr)
+        ctx.ncls = ncls
+        return kl, kr
+
+    @staticmethod
+    def backward(ctx, gkl, gkr):
+        ml, mr = ctx.saved_tensors
+        gkl, gkr = _chk(gkl.contiguous(), "grad K_L"), _chk(gkr.contiguous(), "grad K_R")
+        gw = gkl.new_empty(32, 64, 3, 3, 3)
+        with torch.cuda.device(gkl.device):
+            _call("az_costconv_merge_bwd", _p(gw), _p(gkl), _p(gkr), _p(ml), _p(mr), ctx.ncls, _stream())
+        return gw, None, None, None
 
 
 class _Assemble(torch.autograd.Function):

@@ -158,3 +158,87 @@ extern "C" int az_costconv_assemble_bwd(float *dF_bulk, float *dF_edge, float *d
                        (float4 *)dG, (const float4 *)grad_out, D, H, W, tg);
     return az_launch_status();
 }
+
+// ---- merged kernels (costconv.py: K_L, K_R) as own kernels ------------------------------------------------------------
+// The depth-summed kernels are 0/1-masked sums of the Conv3d weight over kd (and, for K_R, over kw into the shifted column
+// j): weight-space einsums of 55 K elements that rounds 1-4 left to torch.einsum -- two tiny rocBLAS GEMMs forward and two
+// backward, the last vendor-library kernels of the step.
+//   J = 0:  out[c][e][o][i][h][w] = sum_d      W[o][i][d][h][w] * M[c][e][d][w]          (K_L;  M = ML [nc][ne][3][3])
+//   J = 5:  out[c][e][o][i][h][j] = sum_d,w    W[o][i][d][h][w] * M[c][e][d][w][j]       (K_R;  M = MR [nc][ne][3][3][5])
+// W: 32 x 32 channel slice of the [32][64][3][3][3] weight (so = 64 * 27 floats between o, 27 between i); the adjoint gives
+// the gradient of that slice (every element written).
+template <int J>
+__global__ void __launch_bounds__(256)
+costconv_merge_fwd_kernel(float *__restrict__ out, const float *__restrict__ w, const float *__restrict__ m, int nce, long long so) {
+    constexpr int L = J ? J : 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = nce * 32 * 32 * 3 * L;
+    if (idx >= total) return;
+    const int l = idx % L;
+    int r = idx / L;
+    const int h = r % 3; r /= 3;
+    const int i = r % 32; r /= 32;
+    const int o = r % 32;
+    const int ce = r / 32;
+    const float *wp = w + o * so + i * 27 + h * 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (J) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) acc += wp[d * 9 + x] * m[((ce * 3 + d) * 3 + x) * J + l];
+        } else {
+            acc += wp[d * 9 + l] * m[(ce * 3 + d) * 3 + l];
+        }
+    }
+    out[idx] = acc;
+}
+
+template <int J>
+__global__ void __launch_bounds__(256)
+costconv_merge_bwd_kernel(float *__restrict__ gw, const float *__restrict__ gout, const float *__restrict__ m, int nce, long long so) {
+    constexpr int L = J ? J : 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // over [o][i][d][h][x] of the slice
+    if (idx >= 32 * 32 * 27) return;
+    const int x = idx % 3;
+    int r = idx / 3;
+    const int h = r % 3; r /= 3;
+    const int d = r % 3; r /= 3;
+    const int i = r % 32;
+    const int o = r / 32;
+    float acc = 0.f;
+    for (int ce = 0; ce < nce; ++ce) {
+        const float *g = gout + ((((size_t)ce * 32 + o) * 32 + i) * 3 + h) * L;
+        if (J) {
+#pragma unroll
+            for (int l = 0; l < J; ++l) acc += g[l] * m[((ce * 3 + d) * 3 + x) * J + l];
+        } else {
+            acc += g[x] * m[(ce * 3 + d) * 3 + x];
+        }
+    }
+    gw[o * so + i * 27 + d * 9 + h * 3 + x] = acc;
+}
+
+// kl [nc][5][32][32][3][3], kr [nc][2][32][32][3][5] from weight [32][64][3][3][3]; ml [nc][5][3][3], mr [nc][2][3][3][5]
+extern "C" int az_costconv_merge_fwd(float *kl, float *kr, const float *weight, const float *ml, const float *mr, int ncls,
+                                     void *stream) {
+    AZ_REQUIRE_PTR(kl); AZ_REQUIRE_PTR(kr); AZ_REQUIRE_PTR(weight); AZ_REQUIRE_PTR(ml); AZ_REQUIRE_PTR(mr);
+    AZ_REQUIRE(ncls >= 1 && ncls <= 3);
+    hipStream_t s = az_stream(stream);
+    const int tl = ncls * 5 * 32 * 32 * 9, tr = ncls * 2 * 32 * 32 * 15;
+    hipLaunchKernelGGL(costconv_merge_fwd_kernel<0>, dim3((tl + 255) / 256), dim3(256), 0, s, kl, weight, ml, ncls * 5, 64LL * 27);
+    hipLaunchKernelGGL(costconv_merge_fwd_kernel<5>, dim3((tr + 255) / 256), dim3(256), 0, s, kr, weight + 32 * 27, mr, ncls * 2, 64LL * 27);
+    return az_launch_status();
+}
+
+// grad_weight [32][64][3][3][3] (fully written) from the gradients of kl and kr
+extern "C" int az_costconv_merge_bwd(float *grad_weight, const float *gkl, const float *gkr, const float *ml, const float *mr,
+                                     int ncls, void *stream) {
+    AZ_REQUIRE_PTR(grad_weight); AZ_REQUIRE_PTR(gkl); AZ_REQUIRE_PTR(gkr); AZ_REQUIRE_PTR(ml); AZ_REQUIRE_PTR(mr);
+    AZ_REQUIRE(ncls >= 1 && ncls <= 3);
+    hipStream_t s = az_stream(stream);
+    const int t = 32 * 32 * 27;
+    hipLaunchKernelGGL(costconv_merge_bwd_kernel<0>, dim3((t + 255) / 256), dim3(256), 0, s, grad_weight, gkl, ml, ncls * 5, 64LL * 27);
+    hipLaunchKernelGGL(costconv_merge_bwd_kernel<5>, dim3((t + 255) / 256), dim3(256), 0, s, grad_weight + 32 * 27, gkr, mr, ncls * 2, 64LL * 27);
+    return az_launch_status();
+}

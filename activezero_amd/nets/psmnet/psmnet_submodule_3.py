@@ -171,6 +171,7 @@ class _SppConcat(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        from activezero_amd import _lib
         from activezero_amd.ops import _call, _chk, _p, _stream
         gr = _chk(conv2d.rows(g), "grad")
         b, h, w, ctot = gr.shape
@@ -184,7 +185,9 @@ class _SppConcat(torch.autograd.Function):
                     outs.append(None)
                     continue
                 gi = gr.new_empty(shp)
-                _call("az_spp_upsample_bwd", _p(gi), _p(gr[..., at:]), b, shp[1], shp[2], h, w, c, ctot, _stream())
+                wsb = _lib.lib().az_spp_upsample_bwd_workspace(b, shp[2], h, c)
+                wsp = gr.new_empty(wsb // 4)
+                _call("az_spp_upsample_bwd", _p(gi), _p(wsp), wsb, _p(gr[..., at:]), b, shp[1], shp[2], h, w, c, ctot, _stream())
                 outs.append(conv2d.image(gi))
         return (g_raw, g_skip, *outs)
 

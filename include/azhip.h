@@ -396,12 +396,13 @@ int az_bn3d_bwd(float *dx, float *dz_out, float *dgamma, float *dbeta, float *co
 /* ---- SPP branch upsampling (psmnet_submodule_3.py:198-209: F.upsample(branch, (H, W), mode="bilinear") + torch.cat) ----
  * out rows [B,H,W,out_cstride] (the pointer already offset to the branch's channel slot of the concat buffer) <- bilinear
  * interpolation, align_corners = True, of in rows [B,hs,ws,C] (C % 4 == 0, C <= 64, C / 4 a power of two), with ATen's
- * source positions and expression.  _bwd: grad_in [B,hs,ws,C] <- the adjoint over grad_out rows [B,H,W,gout_cstride]; one
- * workgroup per source pixel, no atomics. */
+ * source positions and expression.  _bwd: grad_in [B,hs,ws,C] <- the adjoint over grad_out rows [B,H,W,gout_cstride] in two
+ * separable passes (x then y, through `workspace`); no atomics. */
 int az_spp_upsample_fwd(float *out, const float *in, int B, int hs, int ws, int H, int W, int C, int out_cstride,
                         void *stream);
-int az_spp_upsample_bwd(float *grad_in, const float *grad_out, int B, int hs, int ws, int H, int W, int C,
-                        int gout_cstride, void *stream);
+long long az_spp_upsample_bwd_workspace(int B, int ws, int H, int C);  /* bytes: the x-pass result [B,H,ws,C] */
+int az_spp_upsample_bwd(float *grad_in, float *workspace, long long workspace_bytes, const float *grad_out, int B,
+                        int hs, int ws, int H, int W, int C, int gout_cstride, void *stream);
 /* y = relu?(a + b), n floats (n % 4 == 0): the plain residual sums of psmnet_3.py:166-175; y_amax as above */
 int az_add_relu(float *y, const float *a, const float *b, int relu, long long n, float *y_amax, void *stream);
 /* y = a + b (+ c) (+ d), n floats (n % 4 == 0; c, d may be NULL): the gradient of a tensor with up to
@@ -575,6 +576,12 @@ int az_disp_metrics(double *acc8, const float *disp_gt, const float *depth_gt,
 int az_costconv_edge_width(int D, int W); /* XE = min(W, D+1): columns on which the delta < 2 maps exist */
 int az_costconv_num_classes(int D);       /* NC = min(D, 3) depth classes: first / middle / last plane */
 /* F_bulk [B,H,W,NC*32] (x - d >= 2, per depth class), F_edge [B,H,XE,NC*128] (x - d = -2..1), G [B,H,W+2,NC*64] */
+/* the merged kernels themselves (costconv.py: 0/1-masked sums of the [32][64][3][3][3] weight over kd, and over kw into the
+ * shifted column for K_R): kl [ncls][5][32][32][3][3], kr [ncls][2][32][32][3][5]; ml [ncls][5][3][3], mr [ncls][2][3][3][5];
+ * _bwd: the adjoint, grad_weight fully written */
+int az_costconv_merge_fwd(float *kl, float *kr, const float *weight, const float *ml, const float *mr, int ncls, void *stream);
+int az_costconv_merge_bwd(float *grad_weight, const float *gkl, const float *gkr, const float *ml, const float *mr, int ncls,
+                          void *stream);
 int az_costconv_assemble_fwd(float *out, const float *F_bulk, const float *F_edge, const float *G, int B,
                              int D, int H, int W, void *stream);
 int az_costconv_assemble_bwd(float *dF_bulk, float *dF_edge, float *dG, const float *grad_out, int B, int D,

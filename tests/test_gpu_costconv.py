@@ -60,3 +60,23 @@ def test_costvol_conv_bn_equals_volume_path():
         assert torch.allclose(a, b_, rtol=1e-3, atol=2e-4 * float(b_.abs().max()))
     assert torch.allclose(unit_a[1].running_var, unit_b[1].running_var, rtol=1e-5, atol=1e-6)
     assert int(unit_a[1].num_batches_tracked) == int(unit_b[1].num_batches_tracked) == 1
+
+
+def test_merged_kernels_on_own_kernels_equal_the_einsums():
+    """az_costconv_merge_fwd / _bwd (round 5: the step's last rocBLAS launches were these two weight-space einsums) against
+    torch.einsum in fp64, values and the gradient of the Conv3d weight, for every depth-class count"""
+    from activezero_amd import costconv
+    for nd in (1, 2, 6):
+        w = seeded((32, 64, 3, 3, 3), 51 + nd, -0.3, 0.3).to(DEV).requires_grad_()
+        ml, mr = costconv._masks(w.device, nd)
+        ncls = costconv.num_classes(nd)
+        kl, kr = costconv._Merge.apply(w, ml, mr, ncls)
+        wd = w.detach().double().requires_grad_()
+        rl = torch.einsum("oidhw,cedw->ceoihw", wd[:, :32], ml.double())
+        rr = torch.einsum("oidhw,cedwj->ceoihj", wd[:, 32:], mr.double())
+        torch.testing.assert_close(kl.double(), rl, rtol=0, atol=1e-6)
+        torch.testing.assert_close(kr.double(), rr, rtol=0, atol=1e-6)
+        cl_, cr_ = seeded(tuple(kl.shape), 60).to(DEV), seeded(tuple(kr.shape), 61).to(DEV)
+        ((kl * cl_).sum() + (kr * cr_).sum()).backward()
+        ((rl * cl_.double()).sum() + (rr * cr_.double()).sum()).backward()
+        torch.testing.assert_close(w.grad.double(), wd.grad, rtol=0, atol=1e-5)

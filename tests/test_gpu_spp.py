@@ -35,7 +35,10 @@ def test_upsample_forward_and_adjoint_vs_torch_fp64(src, dst, c):
     gout = torch.zeros(b, h, w, ctot, device=DEV)
     gout[..., at:at + c] = cot.permute(0, 2, 3, 1).to(DEV)
     gin = torch.empty(b, hs, ws, c, device=DEV)
-    _call("az_spp_upsample_bwd", _p(gin), _p(gout[..., at:]), b, hs, ws, h, w, c, ctot, _stream())
+    from activezero_amd import _lib
+    wsb = _lib.lib().az_spp_upsample_bwd_workspace(b, ws, h, c)
+    wsp = torch.empty(wsb // 4, device=DEV)
+    _call("az_spp_upsample_bwd", _p(gin), _p(wsp), wsb, _p(gout[..., at:]), b, hs, ws, h, w, c, ctot, _stream())
     torch.testing.assert_close(gin.permute(0, 3, 1, 2).cpu().double(), ref_in.grad, rtol=0, atol=2e-5 * float(ref_in.grad.abs().max()))
 
 
