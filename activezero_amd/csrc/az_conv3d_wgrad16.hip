@@ -283,6 +283,219 @@ conv3d_wgrad_r16_kernel(const Wg16Args a) {
         }
 }
 
+// ---- round 5: the same kernel with TAPS, not channel blocks, split over the four waves ("wide tile") -------------------
+// Counted from the ISA of the kernel above (f16x3, one step of one wave): 81 MFMAs (16 cycles each) against 114 transposing
+// LDS reads -- every 16 x 16 block of every tap fetches its own fine fragment, and each fragment is fetched by the two waves
+// that share its channel half.  One ds_read_b64_tr_b16 moves 512 bytes, the LDS delivers 128 bytes per clock and CU: eight
+// resident waves need 8 x 114 x 4 = 3 648 LDS cycles per step for 2 x 81 x 16 = 2 592 matrix cycles per SIMD.  The kernel
+// is LDS-bandwidth bound (counter pass: matrix pipe 0.445 busy), and no scheduling inside it can change that.
+// Here a wave owns the WHOLE 32 x 32 channel tile of SEVEN taps (wave w: taps 7w .. 7w + 6; the last wave's seventh is a
+// duplicate that is not flushed) on v_mfma_f32_32x32x16_f16: a fragment read feeds 32 x 32 x 16 products instead of
+// 16 x 16 x 32 (same bytes, twice the flops), every fine fragment is read by exactly one wave, the coarse fragment of a
+// 16-position sub-block by all four.  Per wave and step: 8 + 7 x 2 x 4 = 64 reads for 42 MFMAs of 32 cycles -- 2 048 LDS
+// cycles per CU and step against 2 688 matrix cycles per SIMD.  Accumulators: 7 x 16 = 112 registers (108 before).
+// Staging, rings, buffer-instruction bounds, persistent columns and the LDS images (and their row-half swap: four
+// consecutive 64-byte rows cover the 64 banks once, whichever rows are swapped) are the kernel's above, unchanged.
+// MEASURED (profiles/r05l_wgrad_wide_vs_narrow.md), and why it is NOT the default (AZ_WGRAD_R16_WIDE=1 selects it): the
+// arithmetic above holds -- SQ_WAIT_INST_LDS 1.6e8 -> 3.9e7, SQ_LDS_IDX_ACTIVE 2.3e8 -> 1.3e8, bank conflicts 1.4e7 -> 0,
+// wave cycles 9.2e8 -> 8.0e8 (-13 %) -- and the kernel takes the SAME time, 1.12 against 1.11 ms alone, 85.6 against 85.4 ms
+// per step: the chip gives the saved cycles back as clock (the 32x32x16 shape holds a lower clock than 16x16x32 at equal
+// flops, MI355X_MICROARCH.md DVFS notes).  At this matrix rate the V0 weight gradient is bound by what the part sustains
+// under fp16 MFMA load, not by its LDS traffic.
+template <int PSM>
+__global__ void __launch_bounds__(256, 2)
+conv3d_wgrad_r16w_kernel(const Wg16Args a) {
+    constexpr int NP = 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[W16_LDS + 64];  // + a sink for the lanes of a partial piece
+    unsigned char *const cbuf = lds;                  // [2][W16_CBUF]
+    unsigned char *const fring = lds + 2 * W16_CBUF;  // [plane kd][slot][W16_FROW]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = a.CN >> 5;
+    const int tile = blockIdx.x / a.wgs, wgl = blockIdx.x - tile * a.wgs;
+    const int wg0 = (a.xcd && !(a.wgs & 7)) ? az_xcd_map(wgl, a.wgs) : wgl;
+    const int m0 = (tile / ntn) * 32, n0 = (tile % ntn) * 32;
+
+    az_f32x16h acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const int kc = az_f16_scale_exp(az_amax_read(a.coarse_amax));
+    const int kf = az_f16_scale_exp(az_amax_read(a.fine_amax));
+    const float c_scale = az_pow2(kc), f_scale = az_pow2(kf), o_scale = ldexpf(1.f, -(kc + kf));
+
+    // transposing-read geometry for the 32x32x16 operands on a [k][32 ch] fp16 image (az_conv2d_wgrad.hip): lane l holds
+    // channel 16 ((l >> 4) & 1) + (l & 15), k = 8 (l >> 5) + j; a 16-lane group reads 4 k-rows x 16 channels, lane 4q + p of
+    // it supplies the address of row q, channels 4p .. 4p + 3.  Rows with bit 3 set have their 32-byte halves swapped.
+    const int g8 = lane >> 5, half = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const unsigned chan_b = (unsigned)(16 * half + 4 * tp) * 2u;
+    // coarse: k-row 16 s + 8 g8 + tq (+ 4): bit 3 of the row = g8
+    const unsigned a_lane = (unsigned)(8 * g8 + tq) * W16_ROWB + (chan_b ^ ((unsigned)g8 << 5));
+    // fine: position row kw + 8 g8 + tq (+ 4)
+    unsigned b_off[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const unsigned rowi = (unsigned)(8 * g8 + tq + kw + 4 * h2);
+            b_off[kw][h2] = rowi * W16_ROWB + (chan_b ^ (((rowi >> 3) & 1u) << 5));
+        }
+    // this wave's taps 7 wv + i (clamped to 26): a step must stay straight-line code although wv is a run-time value, so a
+    // tap is reduced, once, to what its reads need -- a per-lane byte offset (plane kd + the two row groups of shift kw) in two
+    // vector registers, and kh in two bits of one scalar
+    unsigned boff[7][2], khpack = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int t = min(7 * wv + i, 26);
+        const int kd = t / 9, kh = (t % 9) / 3, kw = t % 3;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+            boff[i][h2] = (unsigned)kd * (W16_RING * W16_FROW) + (kw == 0 ? b_off[0][h2] : kw == 1 ? b_off[1][h2] : b_off[2][h2]);
+        khpack |= (unsigned)kh << (2 * i);
+    }
+    auto frag2 = [&](const unsigned char *lo, const unsigned char *hi) -> az_f16x8 {  // k rows 0..3 at lo, 4..7 at hi
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lo));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(hi));
+        s16x8 v;
+        v[0] = lo4[0]; v[1] = lo4[1]; v[2] = lo4[2]; v[3] = lo4[3];
+        v[4] = hi4[0]; v[5] = hi4[1]; v[6] = hi4[2]; v[7] = hi4[3];
+        return __builtin_bit_cast(az_f16x8, v);
+    };
+
+    const unsigned vb_c = (unsigned)a.CM * 4u, vb_f = (unsigned)a.CN * 4u;  // bytes per voxel
+    const unsigned plane_c = (unsigned)a.H * a.W * vb_c, plane_f = (unsigned)a.H * a.W * vb_f;
+    for (long long col = wg0; col < a.ncols; col += a.wgs) {
+        long long r_ = col;
+        const int cd = (int)(r_ % a.D); r_ /= a.D;
+        const int wc = (int)(r_ % a.nwchunk);
+        const int b = (int)(r_ / a.nwchunk);
+        const int cw0 = wc * W16_POS;
+        const unsigned vol_c = (unsigned)a.D * plane_c, vol_f = (unsigned)a.D * plane_f;
+        const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coarse) + (size_t)b * (vol_c / 4) + m0, 0, vol_c, 0x00020000);
+        const auto rs_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.fine) + (size_t)b * (vol_f / 4) + n0, 0, vol_f, 0x00020000);
+
+        // ---- staging: exactly the kernel above (pieces, validity, ring slots) -------------------------------------------------
+        u32x4 pre[W16_NLD];
+        auto issue = [&](int crow0, bool with_coarse, int frow0) {
+#pragma unroll
+            for (int it = 0; it < W16_NLD; ++it) {
+                const int q = tid + 256 * it;
+                unsigned off = W16_OOB;
+                if (it == 0) {
+                    const int k = q >> 3, row = crow0 + (k >> 4), cw = cw0 + (k & 15);
+                    if (with_coarse && row < a.H && cw < a.W)
+                        off = (unsigned)cd * plane_c + (unsigned)(row * a.W + cw) * vb_c + (unsigned)(q & 7) * 16u;
+                    pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, off, 0, 0);
+                } else {
+                    const int f = q - 256;
+                    const int kd = f / 288, g = f - kd * 288;
+                    const int j = g / 144, pp = (g - j * 144) >> 3;
+                    const int fd = cd - 1 + kd, fr = frow0 + j, fw = cw0 - 1 + pp;
+                    if (q < W16_NQ && (unsigned)fd < (unsigned)a.D && (unsigned)fr < (unsigned)a.H && (unsigned)fw < (unsigned)a.W)
+                        off = (unsigned)fd * plane_f + (unsigned)(fr * a.W + fw) * vb_f + (unsigned)(q & 7) * 16u;
+                    pre[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_f, off, 0, 0);
+                }
+            }
+        };
+        auto commit_piece = [&](int it, int cbuf_idx, int frow0) {
+            const int q = tid + 256 * it;
+            uint2 hi, lo;
+            if (it == 0) az_stage_f16x4<(PSM & 1) != 0>(pre[it], c_scale, hi, lo);
+            else az_stage_f16x4<(PSM & 2) != 0>(pre[it], f_scale, hi, lo);
+            unsigned char *dst;
+            unsigned part_stride;
+            if (it == 0) {
+                dst = cbuf + cbuf_idx * W16_CBUF + (q >> 3) * W16_ROWB + (((q & 7) * 8) ^ ((((q >> 3) >> 3) & 1) << 5));
+                part_stride = 32 * W16_ROWB;
+            } else {
+                const int f = q - 256;
+                const int kd = f / 288, g = f - kd * 288;
+                const int j = g / 144, pp = (g - j * 144) >> 3;
+                const int slot = (frow0 + j + W16_RING) % W16_RING;
+                dst = fring + (kd * W16_RING + slot) * W16_FROW + pp * W16_ROWB + (((q & 7) * 8) ^ (((pp >> 3) & 1) << 5));
+                part_stride = W16_FW * W16_ROWB;
+            }
+            if (q >= W16_NQ) { dst = lds + W16_LDS + (tid & 7) * 8; part_stride = 0; }  // (no branch: a step stays one block)
+            *reinterpret_cast<uint2 *>(dst) = hi;
+            *reinterpret_cast<uint2 *>(dst + part_stride) = lo;
+        };
+
+        __syncthreads();  // the previous column's last step no longer reads
+        issue(0, false, -1);
+#pragma unroll
+        for (int it = 0; it < W16_NLD; ++it) commit_piece(it, 0, -1);
+        issue(0, true, 1);
+#pragma unroll
+        for (int it = 0; it < W16_NLD; ++it) commit_piece(it, 0, 1);
+        issue(2, true, 3);
+        __syncthreads();
+
+        const int nsteps = (a.H + 1) / 2;
+        for (int s = 0; s < nsteps; ++s) {
+            const int ch = 2 * s;
+            const unsigned char *ca = cbuf + (s & 1) * W16_CBUF + a_lane;
+            const int slot0 = (ch - 1 + W16_RING) % W16_RING;  // ring slot of fine row ch - 1 (wave-uniform)
+            // coarse fragments of the two sub-blocks (k = the 16 positions of coarse row ch + sb), both parts
+            az_f16x8 af[2][NP];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned char *cp = ca + sb * 16 * W16_ROWB + p * 32 * W16_ROWB;
+                    af[sb][p] = frag2(cp, cp + 4 * W16_ROWB);
+                }
+            az_f16x8 bf[2][NP];
+            auto load_b = [&](az_f16x8 (&bq)[NP], int u) {  // unit u = 2 i + sb: tap i of this wave, sub-block sb
+                const int i = u >> 1, sb = u & 1;
+                int r = slot0 + (int)((khpack >> (2 * i)) & 3u) + sb;  // fine row ch - 1 + kh + sb
+                r = r >= W16_RING ? r - W16_RING : r;
+                const unsigned char *fp = fring + (unsigned)r * W16_FROW;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bq[p] = frag2(fp + boff[i][0] + p * W16_FW * W16_ROWB, fp + boff[i][1] + p * W16_FW * W16_ROWB);
+            };
+            load_b(bf[0], 0);
+#pragma unroll
+            for (int u = 0; u < 14; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < 14) load_b(bf[(u + 1) & 1], u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                az_f32x16h c = acc[u >> 1];
+                const az_f16x8(&bq)[NP] = bf[u & 1];
+                const az_f16x8(&aq)[NP] = af[u & 1];
+                // lo*hi, hi*lo, hi*hi chained into the running accumulator (smallest first, as the kernel above)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[1], bq[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0], bq[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[0], bq[0], c, 0, 0, 0);
+                acc[u >> 1] = c;
+                // the set of step s+1 (requested a step ago): one piece after each of the units 1, 3, 5, 7, 9; then the
+                // request for step s+2
+                if (u >= 1 && u <= 9 && (u & 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    commit_piece((u - 1) / 2, (s + 1) & 1, ch + 3);
+                }
+                if (u == 10) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(ch + 4, true, ch + 5);
+                }
+            }
+            __syncthreads();  // next step's rows written by all four waves; this step's no longer read
+        }
+    }
+    // D[i][j]: i = coarse channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5), j = fine channel lane & 31; the last wave's seventh
+    // tap is the duplicate of tap 26
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int t = 7 * wv + i;
+        if (t > 26) break;  // (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            atomicAdd(&a.ws[((size_t)t * a.CM + m) * a.CN + n0 + (lane & 31)], acc[i][r] * o_scale);
+        }
+    }
+}
+
 // persistent workgroups: at most 512 resident (2 per CU); the count that balances the columns best
 int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine, int B, int cm, int cn, int D, int H, int W, hipStream_t s,
                                const float *coarse_amax, const float *fine_amax, int split_mask) {
@@ -302,6 +515,12 @@ int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
     if (!(coarse_amax && fine_amax)) {
         if (split_mask) return AZ_EINVAL;
         hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<0>, grid, dim3(256), 0, s, a);
+    } else if (az_options().wgrad_r16_wide) {  // taps split over the waves, 32x32x16 tiles (AZ_WGRAD_R16_WIDE=0: the kernel above)
+        if (split_mask == 0) hipLaunchKernelGGL(conv3d_wgrad_r16w_kernel<0>, grid, dim3(256), 0, s, a);
+        else if (split_mask == 1) hipLaunchKernelGGL(conv3d_wgrad_r16w_kernel<1>, grid, dim3(256), 0, s, a);
+        else if (split_mask == 2) hipLaunchKernelGGL(conv3d_wgrad_r16w_kernel<2>, grid, dim3(256), 0, s, a);
+        else if (split_mask == 3) hipLaunchKernelGGL(conv3d_wgrad_r16w_kernel<3>, grid, dim3(256), 0, s, a);
+        else return AZ_EINVAL;
     } else if (split_mask == 0) hipLaunchKernelGGL((conv3d_wgrad_r16_kernel<1, 0>), grid, dim3(256), 0, s, a);
     else if (split_mask == 1) hipLaunchKernelGGL((conv3d_wgrad_r16_kernel<1, 1>), grid, dim3(256), 0, s, a);
     else if (split_mask == 2) hipLaunchKernelGGL((conv3d_wgrad_r16_kernel<1, 2>), grid, dim3(256), 0, s, a);
