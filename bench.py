@@ -678,8 +678,8 @@ def main():
             # hipMalloc / hipFree calls of the caching allocator INSIDE the timed steps (a steady state has none)
             "allocator_in_timed_steps": {k: int(torch.cuda.memory_stats(device).get(k, 0) - mem0.get(k, 0))
                                          for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")},
-            "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "r04_pmc_traffic_b4.json"),
-                                          os.path.join(REPO, "profiles", "r04_pmc_clock_b4.json"),
+            "roofline": profiler.roofline(prof, os.path.join(REPO, "profiles", "r05_pmc_traffic_b4.json"),
+                                          os.path.join(REPO, "profiles", "r05_pmc_clock_b4.json"),
                                           ms_per_step=1e3 * dt / args.steps, steps=args.steps,
                                           solo=solo_probe(args, device) if (world == 1 and not mixed and not args.no_solo_probe) else None),
             "cpu_baseline": None,

@@ -38,16 +38,22 @@ def main():
         _call("az_bn3d_apply", _p(y), _p(x), _p(scale), _p(shift), None, 0, x.numel() // C, C, None, _stream())
         A = conv3d.DEFAULT_ARITH  # (round 4: f16x3 forward / input gradient / weight gradient)
         conv3d._conv(x, w, conv3d.CONV_S1, A.conv, stats=True)                                  # forward + BN partials
-        conv3d._input_grad(g, w, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.conv)
-        conv3d._weight_grad(x, g, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.wgrad)
-        # BatchNorm backward of the same tensor (reduce + apply; ReLU mask recomputed from raw; max |dx| taken on the way)
+        # BatchNorm backward of the same tensor (reduce + apply; ReLU mask recomputed from raw); round 5: dx written PRE-SPLIT
+        # with its bound as amax, which is what the layer's input- and weight-gradient kernels then read
         from activezero_amd import _lib
         nv = x.numel() // C
         wsb = _lib.lib().az_bn3d_bwd_workspace(nv, C)
         ws = torch.empty(wsb // 4, device=dev)
         dgm, dbt, coef, am = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.empty(C, 3, device=dev), torch.zeros(1024, device=dev)
-        _call("az_bn3d_bwd", _p(y), None, _p(dgm), _p(dbt), _p(coef), _p(ws), wsb, _p(g), None, _p(x), _p(shift), _p(scale),
-              _p(scale), _p(scale), _p(shift), 1, nv, C, _p(am), 0, _stream())
+        split = int(conv3d.PRESPLIT and A.bwd16)
+        dx = torch.empty_like(x)
+        _call("az_bn3d_bwd", _p(dx), None, _p(dgm), _p(dbt), _p(coef), _p(ws), wsb, _p(g), None, _p(x), _p(shift), _p(scale),
+              _p(scale), _p(scale), _p(shift), 1, nv, C, _p(am), split, _stream())
+        conv3d._set_amax(dx, am)
+        if split:
+            dx.az_split = True
+        conv3d._input_grad(dx, w, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.conv)
+        conv3d._weight_grad(x, dx, conv3d.CONV_S1, C, C, conv3d.F16X3 if A.bwd16 else A.wgrad)
         # round 4, second half: the stride-2 / transposed pair of an hourglass (conv1 32 -> 64 stride 2, conv6 64 -> 32 transposed)
         if os.environ.get("AZ_PROBE_S2", "1") == "1":
             F = conv3d.F16X3
