@@ -56,6 +56,7 @@ const AzOptions &az_options() {
         v.bn_bwd_fused = az_env_int("AZ_BN_BWD_FUSED", 1);
         v.conv2d_roll_nt4 = az_env_int("AZ_CONV2D_ROLL_NT4", 1);
         v.conv2d_wgrad_r16 = az_env_int("AZ_CONV2D_WGRAD_R16", 1);
+        v.conv2d_wgrad_w64 = az_env_int("AZ_CONV2D_WGRAD_W64", 1);
         v.conv_m128 = az_env_int("AZ_CONV_M128", 1);
         v.conv_map = az_env_int("AZ_CONV_MAP", 2);
         if (v.conv_map < 0 || v.conv_map > 3) v.conv_map = 2;
@@ -82,7 +83,7 @@ extern "C" int az_option(const char *name) {
     AZ_REQUIRE_PTR(name);
     const AzOptions &o = az_options();
     struct { const char *n; int v; } t[] = {
-        {"AZ_BN_BWD_FUSED", o.bn_bwd_fused}, {"AZ_CONV2D_ROLL_NT4", o.conv2d_roll_nt4}, {"AZ_CONV2D_WGRAD_R16", o.conv2d_wgrad_r16},
+        {"AZ_BN_BWD_FUSED", o.bn_bwd_fused}, {"AZ_CONV2D_ROLL_NT4", o.conv2d_roll_nt4}, {"AZ_CONV2D_WGRAD_R16", o.conv2d_wgrad_r16}, {"AZ_CONV2D_WGRAD_W64", o.conv2d_wgrad_w64},
         {"AZ_CONV_M128", o.conv_m128}, {"AZ_CONV_MAP", o.conv_map}, {"AZ_ROLL_SEGLEN", o.roll_seglen},
         {"AZ_WGRAD_SLOTS", o.wgrad_slots}, {"AZ_WGRAD_ORDER", o.wgrad_order}, {"AZ_WGRAD_FW", o.wgrad_fw},
         {"AZ_WGRAD_R16", o.wgrad_r16}, {"AZ_WGRAD_R16_WGS", o.wgrad_r16_wgs}, {"AZ_WGRAD_S2R16", o.wgrad_s2r16}, {"AZ_WGRAD_R16_XCD", o.wgrad_r16_xcd}, {"AZ_WGRAD_R16_WIDE", o.wgrad_r16_wide}, {"AZ_CONV_T2ROLL", o.conv_t2roll}, {"AZ_CONV2D_ROLL_H", o.conv2d_roll_h}, {"AZ_CORR_FP32", o.corr_fp32},

@@ -7,6 +7,7 @@ struct AzOptions {
     int bn_bwd_fused;      // AZ_BN_BWD_FUSED      1: BatchNorm backward in two launches (reduce, apply + merge); 0: three
     int conv2d_roll_nt4;   // AZ_CONV2D_ROLL_NT4   1: 64 output channels as four N tiles per wave in az_conv2d_roll.hip
     int conv2d_wgrad_r16;  // AZ_CONV2D_WGRAD_R16  1: 3x3 32/64-channel 2-D weight gradients on az_conv2d_wgrad16.hip
+    int conv2d_wgrad_w64;  // AZ_CONV2D_WGRAD_W64  1: its f16x3 64 -> 64 layers as one 64 x 64 tile per eight-wave workgroup (round 5)
     int conv_m128;         // AZ_CONV_M128         1: bf16x6 (precision 1) stride-1 32-output layers on az_conv3d_m128.hip
     int conv_map;          // AZ_CONV_MAP          block -> tile map of the 3-D kernels: 0 linear, 1 XCD-chunked, 2 + banded
     int roll_seglen;       // AZ_ROLL_SEGLEN       > 0: depth-segment length of az_conv3d_roll.hip (0: chosen per launch)
