@@ -732,22 +732,95 @@ def _wgrad(coarse, fine, stride, cm, cn, tag, precision, sink=None):
     return gw
 
 
-def _input_grad(dy, weight, mode, cin, cout, precision):
-    """gradient of the layer's input from the gradient dy of its (raw) convolution output"""
+def _input_grad(dy, weight, mode, cin, cout, precision, residual=None):
+    """gradient of the layer's input from the gradient dy of its (raw) convolution output; `residual` (a tensor of the
+    result's shape) is added in the kernel's epilogue: another consumer's gradient of the same tensor (GradSlot)"""
     fits = _fits32(dy, cin, cout)
     if precision == F16X3:
         if _f16_dgrad_ok(mode, cin, cout) and (fits or not (mode == CONV_S1 and cin == 32)) and \
                 (mode != CONV_S2 or _fits32_transposed(dy, cout, cin)):
-            return _input_grad_f16(dy, weight, mode, cin, cout)
+            return _input_grad_f16(dy, weight, mode, cin, cout, residual)
         precision = BF16X6
     if mode == CONV_S1:    # flipped taps, channels swapped
         pk = _pack(weight, cout, cin, 27, cin * 27, True, _layout(precision, CONV_S1, cin, fits))
-        return _run_gather(dy, pk, CONV_S1, cout, cin, precision, tag="dgrad")
+        return _run_gather(dy, pk, CONV_S1, cout, cin, precision, residual=residual, tag="dgrad")
     if mode == CONV_S2:    # transposed conv of dy with W[co][ci][k]
         pk = _pack(weight, cout, cin, 27, cin * 27, False, precision)
-        return _run_gather(dy, pk, DECONV_S2, cout, cin, precision, tag="dgrad")
+        return _run_gather(dy, pk, DECONV_S2, cout, cin, precision, residual=residual, tag="dgrad")
     pk = _pack(weight, cout, cin, cout * 27, 27, False, precision)  # stride-2 conv of dy with Wt[ci][co][k]
-    return _run_gather(dy, pk, CONV_S2, cout, cin, precision, tag="dgrad")
+    return _run_gather(dy, pk, CONV_S2, cout, cin, precision, residual=residual, tag="dgrad")
+
+
+# ---- gradient hand-over between the consumers of one tensor (round 5) -----------------------------------------------------
+# A tensor with several consumers gets one gradient per consumer and the autograd engine adds them pairwise: 8 `add_` kernels
+# over V0- / V1-sized tensors per step (1.8 ms on the main stream, tools/aten_sources.py).  Every input-gradient kernel can add
+# a tensor in its epilogue, so the consumers of this module do the sum themselves: each one that is NOT the last to run keeps
+# its contribution in the tensor's GradSlot and returns None to the engine; the last one launches its input gradient with the
+# kept contribution(s) as `residual` and returns the total.  Correct for any execution order; a contribution that is a plain
+# tensor (the residual branch of a BatchNorm unit) is handed over the same way.  What the engine sees is a sum whose other terms
+# are None.  Safety net for pruned graphs (a consumer that registered in forward and never runs in backward): the producing
+# _ConvBN node adds whatever is still parked in its output's slot to the gradient it receives.
+_HANDOVER = os.environ.get("AZ_GRAD_HANDOVER", "1") != "0"  # (read once) 0: every consumer returns its own gradient
+
+
+class GradSlot:
+    __slots__ = ("expect", "left", "parts")
+
+    def __init__(self):
+        self.expect, self.left, self.parts = 0, 0, []
+
+
+def _slot_register(t):
+    """forward: one more consumer of t whose backward will call _slot_contribute"""
+    if not (_HANDOVER and torch.is_grad_enabled() and t.requires_grad):
+        return None
+    s = getattr(t, "az_gslot", None)
+    if s is None:
+        node = t.grad_fn
+        # only tensors produced by a _ConvBN node: that node is the safety net (_slot_leftover) for contributions parked by
+        # consumers whose siblings the engine pruned; everything else keeps the engine's own accumulation
+        if node is None or type(node).__name__ != "_ConvBNBackward":
+            return None
+        s = t.az_gslot = GradSlot()
+        node.az_out_slot = s
+    s.expect += 1
+    s.left = s.expect
+    return s
+
+
+def _sum_parts(parts):
+    while len(parts) > 1:
+        take, parts = parts[:4], parts[4:]
+        out = torch.empty_like(take[0])
+        ptrs = [_p(_chk(t.contiguous(), "grad")) for t in take] + [None] * (4 - len(take))
+        _call("az_sum4", _p(out), ptrs[0], ptrs[1], ptrs[2], ptrs[3], out.numel(), _stream())
+        parts = [out] + parts
+    return parts[0]
+
+
+def _slot_contribute(slot, make=None, plain=None):
+    """backward of one consumer: `make(residual)` launches its input gradient with `residual` added in the epilogue, or `plain`
+    is a gradient that already exists.  Returns what this consumer hands to the engine (None unless it is the last one)."""
+    if slot is None or slot.expect < 2:
+        return make(None) if make is not None else plain
+    slot.left -= 1
+    if slot.left > 0:
+        slot.parts.append(make(None) if make is not None else plain)
+        return None
+    parts, slot.parts, slot.left = slot.parts, [], slot.expect
+    res = _sum_parts(parts) if parts else None
+    if make is not None:
+        return make(res)
+    return plain if res is None else _sum_parts([plain, res])
+
+
+def _slot_leftover(ctx, gy):
+    """producer side: contributions parked in the output's slot by consumers whose siblings never ran (pruned graphs)"""
+    slot = getattr(ctx, "az_out_slot", None)
+    if slot is None or not slot.parts:
+        return gy
+    parts, slot.parts, slot.left = slot.parts, [], slot.expect
+    return _sum_parts([gy] + parts)
 
 
 def _weight_grad(x, dy, mode, cin, cout, precision, sink=None, late_ok=True):
@@ -792,7 +865,8 @@ class _ConvBN(torch.autograd.Function):
     """y = relu?( BN(conv(x, weight)) + residual ), one autograd node per convbn_3d unit."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, arith, defer=None):
+    def forward(ctx, x, weight, gamma, beta, residual, bn, mode, relu, arith, defer=None, x_slot=None, res_slot=None):
+        ctx.x_slot, ctx.res_slot = x_slot, res_slot  # (registered by conv_bn, where autograd is on: GradSlot)
         x = _chk(x, "x")  # (LazyCostVolume never reaches autograd: see conv_bn)
         if residual is not None:
             residual = _chk(residual, "residual")
@@ -862,6 +936,7 @@ class _ConvBN(torch.autograd.Function):
         gy = _chk(gy.contiguous(), "grad_y")
         nvox = raw.numel() // cout
         with torch.cuda.device(gy.device):
+            gy = _slot_leftover(ctx, gy)
             if not training:
                 # y = relu?(raw * s + t + res) with s = gamma * rinv, t = beta - running_mean * s (constants
                 # of the running statistics): dz = gy * [y > 0]; d raw = dz * s; d gamma = sum dz (raw - rm) rinv;
@@ -896,13 +971,17 @@ class _ConvBN(torch.autograd.Function):
                     dx_raw.az_split = True
                 g_res = (dz if relu else gy) if has_res else None
             gx = gw = None
+            # (the residual branch first: when this layer's own input is the same tensor's last consumer, it adds it)
+            if has_res:
+                g_res = _slot_contribute(ctx.res_slot, plain=g_res)
             if ctx.needs_input_grad[0]:
-                gx = _input_grad(dx_raw, weight, mode, cin, cout, F16X3 if arith.bwd16 else arith.conv)
+                gx = _slot_contribute(ctx.x_slot, make=lambda r: _input_grad(dx_raw, weight, mode, cin, cout,
+                                                                             F16X3 if arith.bwd16 else arith.conv, r))
             if ctx.needs_input_grad[1]:
                 if getattr(ctx, "x_amax", None) is not None and _get_amax(x) is None:
                     _set_amax(x, ctx.x_amax)
                 gw = _weight_grad(x, dx_raw, mode, cin, cout, F16X3 if arith.bwd16 else arith.wgrad, arith.sink)
-        return gx, gw, dgamma, dbeta, g_res, None, None, None, None, None
+        return gx, gw, dgamma, dbeta, g_res, None, None, None, None, None, None, None
 
 
 class DeferredAffine:
@@ -934,7 +1013,9 @@ def conv_bn(x, conv, bn, mode, relu=False, residual=None, arith=None, defer=None
             return _conv(x, conv.weight, mode, arith.conv, scale, shift,
                          _chk(residual, "residual") if residual is not None else None, relu, cache=True)
     w = arith.sink.weight(conv.weight) if arith.sink is not None else conv.weight
-    return _ConvBN.apply(x, w, bn.weight, bn.bias, residual, bn, mode, relu, arith, defer)
+    x_slot = _slot_register(x)
+    res_slot = _slot_register(residual) if residual is not None else None
+    return _ConvBN.apply(x, w, bn.weight, bn.bias, residual, bn, mode, relu, arith, defer, x_slot, res_slot)
 
 
 class _ConvLogits(torch.autograd.Function):

@@ -357,3 +357,43 @@ def test_presplit_routing_matches_the_library_queries():
     # gather-kernel input gradients read fp32 (until they move onto the rolling machinery): not pre-split
     assert not ok(t(64, 4, 8, 16), t(64, 4, 8, 16), conv3d.CONV_S1, 64, 64, True, True)
     assert not ok(t(64, 4, 8, 16), t(32, 8, 16, 32), conv3d.DECONV_S2, 64, 32, True, True)
+
+
+# ---- round 5: gradient hand-over between the consumers of one tensor (conv3d.GradSlot) -----------------------------------
+def _fork_net(x, units, arith):
+    """y = unit_a(t) + relu-free residual(t), t = unit0(x): t has two consumers inside one _ConvBN (x and residual of different
+    nodes) and a third one through a second branch -- the shapes of the hourglass skips"""
+    t = agg3d.conv_bn(x, units[0], relu=True, arith=arith)
+    u = agg3d.conv_bn(t, units[1], relu=True, arith=arith)           # consumer 1 of t (input)
+    v = agg3d.conv_bn(u, units[2], add=t, arith=arith)               # consumer 2 of t (residual)
+    w = agg3d.conv_bn(t, units[3], relu=True, arith=arith)           # consumer 3 of t (input)
+    return v, w, t
+
+
+@pytest.mark.parametrize("use", ["all", "first_only", "second_only"])
+def test_gradient_handover_equals_the_engines_sum(use, monkeypatch):
+    arith = conv3d.Arith.of("f16x3")
+    units = [load_procedural(psmnet_3.convbn_3d(32, 32, 3, 1, 1), f"t.ho{i}.").to(DEV).train() for i in range(4)]
+    x0 = seeded((1, 32, 4, 8, 16), 21)
+    cv, cw = cl(seeded((1, 32, 4, 8, 16), 22)), cl(seeded((1, 32, 4, 8, 16), 23))
+
+    def run(handover):
+        monkeypatch.setattr(conv3d, "_HANDOVER", handover)
+        for u in units:
+            u.zero_grad(set_to_none=True)
+        x = cl(x0).requires_grad_()
+        v, w, t = _fork_net(x, units, arith)
+        if handover:
+            slot = getattr(t, "az_gslot", None)
+            assert slot is not None and slot.expect == 3
+        # "first_only" / "second_only": one branch never reaches backward -- consumers registered in forward that the engine
+        # prunes; the producing node must add what the others parked (the safety net)
+        loss = {"all": (v * cv).sum() + (w * cw).sum(), "first_only": (v * cv).sum(), "second_only": (w * cw).sum()}[use]
+        loss.backward()
+        return [x.grad.clone()] + [p.grad.clone() for u in units for p in u.parameters() if p.grad is not None]
+
+    got, ref = run(True), run(False)
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        # same kernels, one addition moved from the engine into an epilogue: float-associativity-sized differences
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-9)

@@ -39,6 +39,7 @@ CASES = [
     ({"AZ_PACK_PLAN": "0"}, "tests/test_gpu_psmnet.py", "train and not d192 and not full_size"),           # every weight image packed by its own launch
     ({"AZ_WGRAD_R16_WIDE": "1"}, "tests/test_gpu_conv3d.py", "(residual_relu_train or convbn3d_golden or hourglass_golden or presplit) and f16x3"),  # taps split over the waves, 32x32x16 tiles
     ({"AZ_CONV2D_WGRAD_W64": "0"}, "tests/test_gpu_conv2d.py", "same"),                                    # 64 -> 64 2-D weight gradients as 2 x 2 tiles of 32 x 32
+    ({"AZ_GRAD_HANDOVER": "0"}, "tests/test_gpu_conv3d.py", "hourglass_golden or handover"),             # every consumer returns its own gradient, the engine adds
     ({"AZ_WGRAD_DEFER": "0"}, "tests/test_gpu_overlap.py", "in_order_pass or partial_backward"),            # per-layer workspace memset + unpack on the side stream
     ({"AZ_DEBUG_AMAX": "1"}, "tests/test_gpu_conv3d.py", "(convbn3d_golden or residual_relu_train) and f16x3"),  # every attached amax checked against a fresh pass
 ]
