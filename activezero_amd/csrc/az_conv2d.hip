@@ -30,6 +30,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef C2_ABL
+#define C2_ABL 0  // timing-only builds: 1 weight fragments fetched once per workgroup (no refills), 2 no slab staging after the first chunk
+#endif
 #define C2_TY 8
 #define C2_TX 16
 #define C2_PITCH 20  // LDS row pitch in pixels (== 4 mod 8: az_conv3d_m128.hip)
@@ -170,7 +173,10 @@ conv2d_same_kernel(const C2Args a) {
         }
     };
     // packed weights: [tap][chunk][ntile][part][lane] float4
+    bool abl_first = true;
     auto load_b = [&](float4 (&bq)[3], int cc, int t) {
+        if ((C2_ABL & 1) && !abl_first) return;
+        if ((C2_ABL & 1) && cc == 0 && t >= 2) abl_first = false;
         const float4 *p = wp4 + (((size_t)t * NCH + cc) * NT + ntile) * PARTS * 64 + lane;
 #pragma unroll
         for (int k = 0; k < PARTS; ++k) bq[k] = p[k * 64];
