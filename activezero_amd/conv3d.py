@@ -65,6 +65,12 @@ def _fits32_transposed(x, op_cin, op_cout):
     return d * h * w * 64 * 4 < _OFF32 and 8 * d * h * w * 32 * 4 < _OFF32
 
 
+def _on_s2roll(op_mode, op_cin, op_cout):
+    """the stride-2 32 -> 64 operation (hourglass conv1 forward, conv6 input gradient) runs on the depth-rolling kernel of
+    az_conv3d_s2roll.hip, which addresses a batch element through 32-bit offsets (AZ_CONV_S2ROLL=0: the gather kernel)"""
+    return op_mode == CONV_S2 and op_cin == 32 and op_cout == 64 and _lib.lib().az_option(b"AZ_CONV_S2ROLL") != 0
+
+
 def _layout(precision, mode, op_cout, fits32=True):
     """precision code the C ABI is called with (packing and launch must agree)"""
     if precision == BF16X6 and mode == CONV_S1 and op_cout == 32 and _ROLL and fits32:
@@ -656,6 +662,8 @@ def _conv(x, weight, mode, precision, scale=None, shift=None, residual=None, rel
         precision = BF16X6  # (a batch element >= 4 GiB: the flat-address bf16x6 kernels)
     if precision == F16X3 and mode == DECONV_S2 and not lazy and not _fits32_transposed(x, cin, cout):
         precision = BF16X6
+    if precision == F16X3 and not fits and _on_s2roll(CONV_S2 if mode == CONV_S2 else None, cin, cout):
+        precision = BF16X6
     if precision == F16X3 and not lazy and _f16_fwd_ok(mode, cin, cout):
         if mode == DECONV_S2:
             pk, w_amax = _pack_f16(weight, cin, cout, 27, cout * 27, False, mode, cache)
@@ -738,7 +746,8 @@ def _input_grad(dy, weight, mode, cin, cout, precision, residual=None):
     fits = _fits32(dy, cin, cout)
     if precision == F16X3:
         if _f16_dgrad_ok(mode, cin, cout) and (fits or not (mode == CONV_S1 and cin == 32)) and \
-                (mode != CONV_S2 or _fits32_transposed(dy, cout, cin)):
+                (mode != CONV_S2 or _fits32_transposed(dy, cout, cin)) and \
+                (fits or not _on_s2roll(CONV_S2 if mode == DECONV_S2 else None, cout, cin)):
             return _input_grad_f16(dy, weight, mode, cin, cout, residual)
         precision = BF16X6
     if mode == CONV_S1:    # flipped taps, channels swapped
@@ -843,7 +852,8 @@ def _presplit_ok(x, raw, mode, cin, cout, need_gx, need_gw):
     b, d, h, w, _ = raw.shape
     if need_gx:
         if not (_f16_dgrad_ok(mode, cin, cout) and (_fits32(raw, cin, cout) or not (mode == CONV_S1 and cin == 32)) and
-                (mode != CONV_S2 or _fits32_transposed(raw, cout, cin))):
+                (mode != CONV_S2 or _fits32_transposed(raw, cout, cin)) and
+                (_fits32(raw, cin, cout) or not _on_s2roll(CONV_S2 if mode == DECONV_S2 else None, cout, cin))):
             return False
         dual = {CONV_S1: CONV_S1, CONV_S2: DECONV_S2, DECONV_S2: CONV_S2}[mode]
         if lib.az_conv3d_fwd_f16_split_ok(dual, b, cout, cin, d, h, w) != 1:

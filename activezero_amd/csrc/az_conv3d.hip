@@ -759,18 +759,21 @@ extern "C" long long az_conv3d_packed_floats_f16(int cin, int cout) {
 static bool f16_on_roll(int mode, int cout) { return mode == 0 && cout == 32; }
 // the transposed 64 -> 32 layers on the depth-rolling kernel of az_conv3d_t2roll.hip (AZ_CONV_T2ROLL=0: az_conv3d_t2.hip)
 static bool f16_on_t2roll(int mode, int cin, int cout) { return mode == 2 && cin == 64 && cout == 32 && az_options().conv_t2roll != 0; }
+// the stride-2 32 -> 64 layers on the depth-rolling kernel of az_conv3d_s2roll.hip (AZ_CONV_S2ROLL=0: the gather kernel here)
+static bool f16_on_s2roll(int mode, int cin, int cout) { return mode == 1 && cin == 32 && cout == 64 && az_options().conv_s2roll != 0; }
+static bool f16_roll_layout(int mode, int cin, int cout) { return f16_on_roll(mode, cout) || f16_on_t2roll(mode, cin, cout) || f16_on_s2roll(mode, cin, cout); }
 
 // the layout az_conv3d_pack_weights_f16 writes for (mode, cin, cout): AZ_PACK_3D_ROLL or AZ_PACK_3D_GATHER (az_pack_f16_multi's `kind`)
 extern "C" int az_conv3d_f16_layout(int mode, int cin, int cout) {
     if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return AZ_EUNSUPPORTED;
-    return (f16_on_roll(mode, cout) || f16_on_t2roll(mode, cin, cout)) ? AZ_PACK_3D_ROLL : AZ_PACK_3D_GATHER;
+    return f16_roll_layout(mode, cin, cout) ? AZ_PACK_3D_ROLL : AZ_PACK_3D_GATHER;
 }
 
 extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
                                           long long stride_out, long long stride_in, int flip, int mode, void *stream) {
     AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
     if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return AZ_EUNSUPPORTED;
-    if (f16_on_roll(mode, cout) || f16_on_t2roll(mode, cin, cout))
+    if (f16_roll_layout(mode, cin, cout))
         return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream));
     const int total = 27 * cin * cout * 2;
     hipLaunchKernelGGL(conv3d_pack_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, az_stream(stream),
@@ -785,6 +788,7 @@ static int conv_f16_dispatch(ConvArgs &a, int mode, int cin, int cout, int epi, 
         if (rc != AZ_EUNSUPPORTED) return rc;
         return AZ_EUNSUPPORTED;  // (the weights are packed for that kernel: the caller takes the bf16x6 route)
     }
+    if (f16_on_s2roll(mode, cin, cout)) return az_conv3d_s2roll_launch(a, epi, s);  // (AZ_EUNSUPPORTED: as above)
     return epi ? dispatch_mode<1>(a, mode, 3, cin, cout, 0, s) : dispatch_mode<0>(a, mode, 3, cin, cout, 0, s);
 }
 
@@ -795,6 +799,7 @@ extern "C" int az_conv3d_fwd_f16_split_ok(int mode, int B, int cin, int cout, in
     if (f16_on_roll(mode, cout)) return (cin == 32 || cin == 64) && az_fits_buffer_offset((long long)Di * Hi * Wi * cin * 4) ? 1 : 0;
     if (f16_on_t2roll(mode, cin, cout))
         return az_fits_buffer_offset(8LL * Di * Hi * Wi * 32 * 4) && az_fits_buffer_offset((long long)Di * Hi * Wi * 64 * 4) ? 1 : 0;
+    if (f16_on_s2roll(mode, cin, cout)) return az_fits_buffer_offset((long long)Di * Hi * Wi * 32 * 4) ? 1 : 0;
     return 0;
 }
 
@@ -818,6 +823,11 @@ extern "C" long long az_conv3d_stats_tiles_f16(int mode, int B, int cin, int cou
         ConvArgs a{};
         if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
         return az_conv3d_t2roll_stats_tiles(a);
+    }
+    if (f16_on_s2roll(mode, cin, cout)) {
+        ConvArgs a{};
+        if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
+        return az_conv3d_s2roll_stats_tiles(a);
     }
     return az_conv3d_num_tiles(mode, B, Di, Hi, Wi);
 }

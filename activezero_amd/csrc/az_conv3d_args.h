@@ -43,6 +43,12 @@ int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long lo
 int az_conv3d_t2roll_launch(ConvArgs a, int epi, hipStream_t s);
 long long az_conv3d_t2roll_stats_tiles(const ConvArgs &a);
 
+// f16x3, stride 2, 32 -> 64 channels, depth-rolling workgroups of four waves walking the FINE depth (az_conv3d_s2roll.hip);
+// weights packed by az_conv3d_pack_r16_f16(cin = 32, cout = 64)
+int az_conv3d_s2roll_launch(ConvArgs a, int epi, hipStream_t s);
+long long az_conv3d_s2roll_stats_tiles(ConvArgs a);
+bool az_conv3d_s2roll_fits(const ConvArgs &a);
+
 // bf16x6, stride-2 transposed, 32 output channels: one workgroup owns all 8 output-parity phases of a coarse
 // patch (az_conv3d_t2.hip)
 int az_conv3d_t2_launch(const ConvArgs &a, int cin, int epi, hipStream_t s);

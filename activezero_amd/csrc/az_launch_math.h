@@ -52,6 +52,21 @@ inline void az_t2roll_segments(long long patches, int Di, int &nseg, int &seg_le
     }
 }
 
+// az_conv3d_s2roll.hip: coarse-depth segments of a launch with two workgroups per CU (512 slots); a workgroup of a segment
+// of len output planes stages 2 len + 1 fine planes and multiplies 27 len + 18 tap positions (nine of the first and nine
+// of the last plane are dropped); a staged plane is priced at four tap positions.  Postconditions as az_roll_segments.
+inline void az_s2roll_segments(long long patches, int Do, int &nseg, int &seg_len) {
+    long long best = -1;
+    nseg = 1; seg_len = Do;
+    for (int n = 1; n <= Do; ++n) {
+        const int len = (Do + n - 1) / n;
+        if ((Do + len - 1) / len != n) continue;
+        const long long rounds = (patches * n + 511) / 512;
+        const long long cost = rounds * (27LL * len + 18 + 4 * (2 * len + 1) + 4);
+        if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
+    }
+}
+
 // az_conv2d_roll.hip: image segments per statistic group (patches = groups * patch rows * patch columns; N images)
 inline void az_c2r_segments(long long patches, int N, int &nseg, int &seg_len) {
     long long best = -1;
