@@ -228,40 +228,42 @@ conv3d_s2roll_kernel(const ConvArgs a) {
         for (int q = 0; q < 4; ++q) c[4 * half + q] = R_MH(c[4 * half + q], w[1], x[q][0]);
     };
 
-    // ---- the taps of the plane in the slab.  ODD: kd = 2 into set 0 and kd = 0 into set 1; else kd = 1 into set 0 --------
-    auto plane = [&](auto odd_tag) __attribute__((always_inline)) {
-        constexpr bool ODD = decltype(odd_tag)::value != 0;
-        float4 wa[2][2], wb[2][2];  // [tap parity][part]: kd = 2 (ODD) or kd = 1; wb: kd = 0 (ODD)
+    // ---- the taps of the plane in the slab.  KIND 0: an even plane, kd = 1 into set 0;  1: an odd plane, kd = 2 into set 0 and
+    //      kd = 0 into set 1;  2: the first plane of a segment, kd = 0 into set 1 only (its kd = 2 products belong to the segment
+    //      before);  3: the last plane, kd = 2 into set 0 only --------------------------------------------------------------------
+    auto plane = [&](auto kind_tag) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool HAS_A = KIND != 2, HAS_B = KIND == 1 || KIND == 2;
+        constexpr int KD_A = KIND == 0 ? 1 : 2;
+        float4 wa[2][2], wb[2][2];  // [tap parity][part]: wa: kd = 1 or 2 into set 0; wb: kd = 0 into set 1
         float4 xf[2][4][2];         // [patch half][tile][part]
-        load_w(wa[0], ODD ? 2 : 1, 0);
-        if (ODD) load_w(wb[0], 0, 0);
+        if (HAS_A) load_w(wa[0], KD_A, 0);
+        if (HAS_B) load_w(wb[0], 0, 0);
         load_x(xf[0], 0, 0);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             __builtin_amdgcn_sched_barrier(0);
             load_x(xf[1], i, 1);
             if (i + 1 < 9 && !(S2R_ABL & 2)) {
-                load_w(wa[(i + 1) & 1], ODD ? 2 : 1, i + 1);
-                if (ODD) load_w(wb[(i + 1) & 1], 0, i + 1);
+                if (HAS_A) load_w(wa[(i + 1) & 1], KD_A, i + 1);
+                if (HAS_B) load_w(wb[(i + 1) & 1], 0, i + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int wp = (S2R_ABL & 2) ? 0 : (i & 1);
-            mul4(acc[0], 0, wa[wp], xf[0]);
-            if (ODD) mul4(acc[1], 0, wb[wp], xf[0]);
+            if (HAS_A) mul4(acc[0], 0, wa[wp], xf[0]);
+            if (HAS_B) mul4(acc[1], 0, wb[wp], xf[0]);
             __builtin_amdgcn_sched_barrier(0);
             if (i + 1 < 9) load_x(xf[0], i + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mul4(acc[0], 1, wa[wp], xf[1]);
-            if (ODD) mul4(acc[1], 1, wb[wp], xf[1]);
+            if (HAS_A) mul4(acc[0], 1, wa[wp], xf[1]);
+            if (HAS_B) mul4(acc[1], 1, wb[wp], xf[1]);
         }
     };
 
     // ---- the walk: fine planes 2 c0 - 1 .. 2 c1 - 1 ------------------------------------------------------------------------
-    // (the first plane's kd = 2 products belong to the segment before and the last plane's kd = 0 products to the one
-    //  after: computed and dropped -- set 0 is overwritten by finish's rotation, set 1 never stored)
     stage(2 * c0 - 1);
     __syncthreads();
-    plane(std::integral_constant<int, 1>{});
+    plane(std::integral_constant<int, 2>{});
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         acc[0][m] = acc[1][m];
@@ -275,7 +277,8 @@ conv3d_s2roll_kernel(const ConvArgs a) {
         __syncthreads();
         stage(2 * t + 1);
         __syncthreads();
-        plane(std::integral_constant<int, 1>{});
+        if (t + 1 < c1) plane(std::integral_constant<int, 1>{});
+        else plane(std::integral_constant<int, 3>{});
         finish(t);
     }
 
@@ -309,7 +312,7 @@ conv3d_s2roll_kernel(const ConvArgs a) {
 static void s2roll_geometry(ConvArgs &a) {
     a.tiles_y = (a.Ho + 7) / 8;
     a.tiles_x = (a.Wo + 15) / 16;
-    az_s2roll_segments((long long)a.B * a.tiles_y * a.tiles_x, a.Do, a.nseg, a.seg_len);  // (az_launch_math.h: swept on the CPU)
+    az_s2roll_segments((long long)a.B * a.tiles_y * a.tiles_x, a.Do, az_options().s2roll_seglen, a.nseg, a.seg_len);  // (az_launch_math.h: swept on the CPU)
 }
 
 long long az_conv3d_s2roll_stats_tiles(ConvArgs a) {

@@ -54,8 +54,13 @@ inline void az_t2roll_segments(long long patches, int Di, int &nseg, int &seg_le
 
 // az_conv3d_s2roll.hip: coarse-depth segments of a launch with two workgroups per CU (512 slots); a workgroup of a segment
 // of len output planes stages 2 len + 1 fine planes and multiplies 27 len + 18 tap positions (nine of the first and nine
-// of the last plane are dropped); a staged plane is priced at four tap positions.  Postconditions as az_roll_segments.
-inline void az_s2roll_segments(long long patches, int Do, int &nseg, int &seg_len) {
+// of the last plane are dropped); a staged plane is priced at four tap positions.  forced > 0: that segment length (AZ_S2ROLL_SEGLEN).  Postconditions as az_roll_segments.
+inline void az_s2roll_segments(long long patches, int Do, int forced, int &nseg, int &seg_len) {
+    if (forced > 0) {
+        seg_len = forced < Do ? forced : Do;
+        nseg = (Do + seg_len - 1) / seg_len;
+        return;
+    }
     long long best = -1;
     nseg = 1; seg_len = Do;
     for (int n = 1; n <= Do; ++n) {

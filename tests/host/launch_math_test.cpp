@@ -57,6 +57,27 @@ int main() {
             CHECK(c0 < c1, "t2roll empty segment %d of %d (len %d, Di %d)", seg, nseg, seg_len, Di);
         }
     }
+    // 2c. output-depth segments of the stride-2 depth-rolling kernel (8 x 16 coarse patches); its workgroups decode with the
+    //     same function, every (patch, segment, batch) once
+    for (const auto &d : dims)
+        for (int forced = 0; forced <= 7; forced += (forced ? 3 : 1)) {
+            const int B = d[0], Do = (d[1] - 1) / 2 + 1, Ho = (d[2] - 1) / 2 + 1, Wo = (d[3] - 1) / 2 + 1;
+            const int ty = (Ho + 7) / 8, tx = (Wo + 15) / 16;
+            int nseg = -1, seg_len = -1;
+            az_s2roll_segments((long long)B * ty * tx, Do, forced, nseg, seg_len);
+            CHECK(nseg >= 1 && seg_len >= 1 && seg_len <= Do && (long long)nseg * seg_len >= Do && (long long)(nseg - 1) * seg_len < Do,
+                  "s2roll B%d Do%d: nseg %d len %d", B, Do, nseg, seg_len);
+            const long long blocks = (long long)B * nseg * ty * tx;
+            std::vector<char> seen((size_t)blocks, 0);
+            for (int bid = 0; bid < (int)blocks; ++bid) {
+                int tix, tiy, seg, b;
+                az_roll_decode(az_xcd_map(bid, (int)blocks), tx, ty, nseg, tix, tiy, seg, b);
+                CHECK(tix >= 0 && tix < tx && tiy >= 0 && tiy < ty && seg >= 0 && seg < nseg && b >= 0 && b < B, "s2roll decode");
+                const long long id = (((long long)b * nseg + seg) * ty + tiy) * tx + tix;
+                if (id >= 0 && id < blocks) { CHECK(!seen[(size_t)id], "s2roll work item %lld twice", id); seen[(size_t)id] = 1; }
+                CHECK(seg * seg_len < Do, "s2roll empty segment %d", seg);
+            }
+        }
     // 3. image segments of the 2-D batch-walking kernel
     for (int N = 1; N <= 64; ++N)
         for (long long patches = 1; patches <= 4096; patches *= 3) {

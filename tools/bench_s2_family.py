@@ -87,6 +87,10 @@ if "--only-v0-wgrad" in sys.argv:
     case("V0 conv_wgrad_s1_32_32", 6, conv3d.CONV_S1, 32, 32, q, "wgrad")
     case("conv_wgrad_s1_64_64 @V1 (conv2 wgrad)", 3, conv3d.CONV_S1, 64, 64, e, "wgrad")
     sys.exit(0)
+if "--only-s2roll" in sys.argv:  # the two uses of az_conv3d_s2roll.hip
+    case("conv3d_m1_32_64      (conv1 fwd)", 3, conv3d.CONV_S2, 32, 64, q, "fwd")
+    case("dgrad_m1_32_64       (conv6 dgrad)", 3, conv3d.DECONV_S2, 64, 32, e, "dgrad")
+    sys.exit(0)
 ONLY_S2W = "--only-s2-wgrad" in sys.argv
 if ONLY_S2W:
     case("conv_wgrad_s2_64_32  (conv1 wgrad)", 3, conv3d.CONV_S2, 32, 64, q, "wgrad")
