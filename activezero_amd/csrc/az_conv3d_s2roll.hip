@@ -41,8 +41,22 @@
 #define S2R_SUB_BYTES (9 * S2R_PITCH * 128)  // 19 584
 #define S2R_LDS (4 * S2R_SUB_BYTES)        // 78 336
 #define S2R_TAPB (4 * 2 * 64 * 16)         // bytes per tap of the packed image [tap][cout/16 (4)][part (2)][lane][16 B]
+#ifndef S2R_KIND_FIRST  // (experiments: 1 = the first / last plane of a segment multiply all eighteen taps, nine of them dropped)
+#define S2R_KIND_FIRST 2
+#define S2R_KIND_LAST 3
+#endif
 #ifndef S2R_ABL
 #define S2R_ABL 0  // timing-only ablations: 1 no output stores, 2 no weight loads after the first tap, 4 no slab staging, 8 no fragment reads
+#endif
+
+// Diagnostic build only (-DS2R_STAMP): per-phase cycle sums of every wave, added to a global array nothing else reads
+// (tools/s2roll_stamp_probe.py): 0 staging loads issued -> arrived, 1 split + LDS writes, 2 barrier behind the staging,
+// 3 the taps, 4 barrier behind the taps, 5 epilogue, 6 planes, 7 whole wave.
+#ifdef S2R_STAMP
+__device__ unsigned long long s2r_stamp_sum[8];
+#define S2R_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[i] += t1_ - st_t0; st_t0 = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define S2R_T(i)
 #endif
 
 // EPI: 0 = y = relu?(acc * scale + shift) (+ residual when given), 1 = raw output + BatchNorm partials
@@ -53,6 +67,10 @@ conv3d_s2roll_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(128))) unsigned char slab[S2R_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave's sixteen output channels
+#ifdef S2R_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_k0 = st_t0;
+#endif
 
     const int lin = a.map_mode >= 1 ? az_xcd_map(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     int tix, tiy, seg, b;
@@ -111,6 +129,10 @@ conv3d_s2roll_kernel(const ConvArgs a) {
             const unsigned off = plane_off + (unsigned)((ih0 + pc) * a.Wi + iw) * 128u + (unsigned)pj * 16u;
             pre[S2R_FY] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : R_OOB, 0, 0);
         }
+#ifdef S2R_STAMP
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        S2R_T(0);
+#endif
 #pragma unroll
         for (int it = 0; it < S2R_FY; ++it) {
             // fine row 2r + 1 is an even input row (the kh = 1 sub-slabs, row r); fine row 2r an odd one (kh = 0 / 2, row r)
@@ -263,25 +285,43 @@ conv3d_s2roll_kernel(const ConvArgs a) {
     // ---- the walk: fine planes 2 c0 - 1 .. 2 c1 - 1 ------------------------------------------------------------------------
     stage(2 * c0 - 1);
     __syncthreads();
-    plane(std::integral_constant<int, 2>{});
+    plane(std::integral_constant<int, S2R_KIND_FIRST>{});
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         acc[0][m] = acc[1][m];
         acc[1][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int t = c0; t < c1; ++t) {
+        S2R_T(3);
         __syncthreads();
+        S2R_T(4);
         stage(2 * t);
+        S2R_T(1);
         __syncthreads();
+        S2R_T(2);
         plane(std::integral_constant<int, 0>{});
+        S2R_T(3);
         __syncthreads();
+        S2R_T(4);
         stage(2 * t + 1);
+        S2R_T(1);
         __syncthreads();
+        S2R_T(2);
         if (t + 1 < c1) plane(std::integral_constant<int, 1>{});
-        else plane(std::integral_constant<int, 3>{});
+        else plane(std::integral_constant<int, S2R_KIND_LAST>{});
+        S2R_T(3);
         finish(t);
+        S2R_T(5);
+#ifdef S2R_STAMP
+        st_acc[6] += 2;
+#endif
     }
 
+#ifdef S2R_STAMP
+    st_acc[7] = __builtin_amdgcn_s_memtime() - st_k0;
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&s2r_stamp_sum[i], st_acc[i]);
+#endif
     if (EPI == 1) {
         const unsigned tile_id = (unsigned)(((b * a.nseg + seg) * a.tiles_y + tiy) * a.tiles_x + tix);
         float ntot = 0.f;
@@ -308,6 +348,14 @@ conv3d_s2roll_kernel(const ConvArgs a) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ntot), rs_cnt, (lane == 0 && cg == 0) ? tile_id * 4u : R_OOB, 0, 0);
     }
 }
+
+#ifdef S2R_STAMP
+extern "C" int az_debug_s2roll_stamps(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(s2r_stamp_sum), 8 * sizeof(unsigned long long)) != hipSuccess) return AZ_ELAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(s2r_stamp_sum), z, sizeof(z)) != hipSuccess) return AZ_ELAUNCH; }
+    return AZ_OK;
+}
+#endif
 
 static void s2roll_geometry(ConvArgs &a) {
     a.tiles_y = (a.Ho + 7) / 8;

@@ -53,8 +53,8 @@ inline void az_t2roll_segments(long long patches, int Di, int &nseg, int &seg_le
 }
 
 // az_conv3d_s2roll.hip: coarse-depth segments of a launch with two workgroups per CU (512 slots); a workgroup of a segment
-// of len output planes stages 2 len + 1 fine planes and multiplies 27 len + 18 tap positions (nine of the first and nine
-// of the last plane are dropped); a staged plane is priced at four tap positions.  forced > 0: that segment length (AZ_S2ROLL_SEGLEN).  Postconditions as az_roll_segments.
+// of len output planes stages 2 len + 1 fine planes and multiplies 27 len tap positions; a staged plane is priced at four
+// tap positions (measured at B = 4, V0 -> V1, 288 patches: 0.34 ms for len 4 .. 6, 0.36 at 3, 0.38 at 1 and 12, 0.46 at 24).  forced > 0: that segment length (AZ_S2ROLL_SEGLEN).  Postconditions as az_roll_segments.
 inline void az_s2roll_segments(long long patches, int Do, int forced, int &nseg, int &seg_len) {
     if (forced > 0) {
         seg_len = forced < Do ? forced : Do;
@@ -67,7 +67,7 @@ inline void az_s2roll_segments(long long patches, int Do, int forced, int &nseg,
         const int len = (Do + n - 1) / n;
         if ((Do + len - 1) / len != n) continue;
         const long long rounds = (patches * n + 511) / 512;
-        const long long cost = rounds * (27LL * len + 18 + 4 * (2 * len + 1) + 4);
+        const long long cost = rounds * (27LL * len + 4 * (2 * len + 1) + 4);
         if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
     }
 }
