@@ -30,11 +30,15 @@ def test_multi_pack_writes_what_the_per_tensor_launches_write():
     def add(w, kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip, ref):
         cases.append((torch.nn.Parameter(w.to(DEV)), kind, cin, cout, ci_real, co_real, s_co, s_ci, taps, flip, ref))
 
-    w3 = seeded((64, 32, 3, 3, 3), 1, -0.3, 0.3)   # Conv3d 32 -> 64
+    w3 = seeded((64, 64, 3, 3, 3), 1, -0.3, 0.3)   # Conv3d 64 -> 64, stride 2
     for flip in (False, True):
-        # forward image of the stride-2 layer (gather layout) and the input-gradient image of a stride-1 32 -> 32 layer (roll)
-        add(w3, conv3d.PACK_3D_GATHER, 32, 64, 32, 64, 32 * 27, 27, 27, flip,
-            lambda pk, w, am, flip=flip: _call("az_conv3d_pack_weights_f16", _p(pk), _p(w), _p(am), 32, 64, 32 * 27, 27, int(flip), conv3d.CONV_S2, _stream()))
+        # forward image of the stride-2 64 -> 64 layer (gather layout) and the input-gradient image of a stride-1 32 -> 32 layer (roll)
+        add(w3, conv3d.PACK_3D_GATHER, 64, 64, 64, 64, 64 * 27, 27, 27, flip,
+            lambda pk, w, am, flip=flip: _call("az_conv3d_pack_weights_f16", _p(pk), _p(w), _p(am), 64, 64, 64 * 27, 27, int(flip), conv3d.CONV_S2, _stream()))
+    w3s = seeded((64, 32, 3, 3, 3), 6, -0.3, 0.3)  # Conv3d 32 -> 64, stride 2: the rolling layout of az_conv3d_s2roll.hip
+    s2_kind = _lib.lib().az_conv3d_f16_layout(conv3d.CONV_S2, 32, 64)
+    add(w3s, s2_kind, 32, 64, 32, 64, 32 * 27, 27, 27, False,
+        lambda pk, w, am: _call("az_conv3d_pack_weights_f16", _p(pk), _p(w), _p(am), 32, 64, 32 * 27, 27, 0, conv3d.CONV_S2, _stream()))
     w3b = seeded((32, 32, 3, 3, 3), 2, -0.3, 0.3)
     add(w3b, conv3d.PACK_3D_ROLL, 32, 32, 32, 32, 27, 32 * 27, 27, True,
         lambda pk, w, am: _call("az_conv3d_pack_weights_f16", _p(pk), _p(w), _p(am), 32, 32, 27, 32 * 27, 1, conv3d.CONV_S1, _stream()))
