@@ -233,7 +233,9 @@ conv3d_s2roll_kernel(const ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (S2R_ABL & 8) {
-                x[q][0] = x[q][1] = make_float4(1.f, 1.f, 1.f, 1.f);
+                // (operands that differ per tile and lane: with one constant the accumulators of the tiles are provably equal
+                //  and the compiler keeps ONE chain of MFMAs -- the first ablation run, profiles/r05v_s2roll_ablations.txt)
+                x[q][0] = x[q][1] = __builtin_bit_cast(float4, u32x4{0x3c003c00u + (unsigned)(4 * half + q), 0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u});
             } else {
                 x[q][0] = *reinterpret_cast<const float4 *>(slab + xb[0][kh == 2][kw == 2] + cst + 4 * q * 128);
                 x[q][1] = *reinterpret_cast<const float4 *>(slab + xb[1][kh == 2][kw == 2] + cst + 4 * q * 128);
