@@ -230,6 +230,13 @@ bn_bwd_reduce_kernel(float *__restrict__ partial, const float *__restrict__ dy,
         if (remask) { scale += blockIdx.y * C; shift += blockIdx.y * C; }
         partial += (size_t)blockIdx.y * gridDim.x * C * 2;
     }
+#if defined(BN_ABL) && (BN_ABL & 4)
+    // timing-only build (-DBN_ABL=4, run with AZ_PRESPLIT=0; tools/abl_bn_reduce.sh): the pass reads nothing and reports zero
+    // sums, so that the apply pass writes finite gradients of the usual size (dx = k0 dz) and every later kernel works on
+    // ordinary numbers -- what the step would gain if this pass were free (profiles/r05y_bn_reduce_ablation.txt: 4.4 ms)
+    if (threadIdx.x < 2 * C) partial[(size_t)blockIdx.x * C * 2 + threadIdx.x] = 0.f;
+    return;
+#endif
     float4 sc = make_float4(0, 0, 0, 0), sh = sc;
     if (remask) { sc = reinterpret_cast<const float4 *>(scale)[c4_of(threadIdx.x, C4)]; sh = reinterpret_cast<const float4 *>(shift)[c4_of(threadIdx.x, C4)]; }
     const int c4 = threadIdx.x % C4, vl = threadIdx.x / C4;
