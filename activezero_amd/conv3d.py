@@ -359,7 +359,7 @@ def absmax(t):
 #   * only tensors registered through prepack() -- live nn.Parameters, held by weak reference -- have entries: derived
 #     weights (the merged kernels of K3', DataParallel replicas) change address every step and keep the per-call route;
 #   * an entry is valid for one (address, version counter): optimizer steps and load_state_dict write in place and bump it.
-PACK_2D_SAME, PACK_2D_ROLL, PACK_3D_GATHER, PACK_3D_ROLL = 0, 1, 2, 3
+PACK_2D_SAME, PACK_2D_ROLL, PACK_3D_GATHER, PACK_3D_ROLL, PACK_3D_ROLL2 = 0, 1, 2, 3, 4
 _PLAN_ON = os.environ.get("AZ_PACK_PLAN", "1") != "0"  # (read once) 0: every image packed by its own launch, as in round 4
 
 
@@ -582,8 +582,10 @@ def _pack_f16(weight, op_cin, op_cout, stride_out, stride_in, flip, mode, cache=
         if hit is not None:
             return hit[0]
     if not cache:
-        roll = _lib.lib().az_conv3d_f16_layout(mode, op_cin, op_cout) == PACK_3D_ROLL
-        hit = _planned_pack(weight, w, PACK_3D_ROLL if roll else PACK_3D_GATHER, op_cin, op_cout, op_cin, op_cout,
+        kind = _lib.lib().az_conv3d_f16_layout(mode, op_cin, op_cout)
+        if kind < 0:
+            raise RuntimeError(f"az_conv3d_f16_layout({mode}, {op_cin}, {op_cout}): {kind}")
+        hit = _planned_pack(weight, w, kind, op_cin, op_cout, op_cin, op_cout,
                             stride_out, stride_in, 27, flip,
                             lambda packed, w_amax: _call("az_conv3d_pack_weights_f16", _p(packed), _p(w), _p(w_amax), op_cin,
                                                          op_cout, stride_out, stride_in, int(flip), mode, _stream()))
@@ -658,7 +660,7 @@ def _conv(x, weight, mode, precision, scale=None, shift=None, residual=None, rel
     else:
         cout, cin = weight.shape[0], weight.shape[1]
     fits = _fits32(x, cin, cout)
-    if precision == F16X3 and not fits and mode == CONV_S1 and cout == 32:
+    if precision == F16X3 and not fits and mode == CONV_S1 and (cout == 32 or cin == cout == 64):
         precision = BF16X6  # (a batch element >= 4 GiB: the flat-address bf16x6 kernels)
     if precision == F16X3 and mode == DECONV_S2 and not lazy and not _fits32_transposed(x, cin, cout):
         precision = BF16X6
@@ -745,7 +747,7 @@ def _input_grad(dy, weight, mode, cin, cout, precision, residual=None):
     result's shape) is added in the kernel's epilogue: another consumer's gradient of the same tensor (GradSlot)"""
     fits = _fits32(dy, cin, cout)
     if precision == F16X3:
-        if _f16_dgrad_ok(mode, cin, cout) and (fits or not (mode == CONV_S1 and cin == 32)) and \
+        if _f16_dgrad_ok(mode, cin, cout) and (fits or not (mode == CONV_S1 and (cin == 32 or cin == cout == 64))) and \
                 (mode != CONV_S2 or _fits32_transposed(dy, cout, cin)) and \
                 (fits or not _on_s2roll(CONV_S2 if mode == DECONV_S2 else None, cout, cin)):
             return _input_grad_f16(dy, weight, mode, cin, cout, residual)
@@ -851,7 +853,7 @@ def _presplit_ok(x, raw, mode, cin, cout, need_gx, need_gw):
         return False
     b, d, h, w, _ = raw.shape
     if need_gx:
-        if not (_f16_dgrad_ok(mode, cin, cout) and (_fits32(raw, cin, cout) or not (mode == CONV_S1 and cin == 32)) and
+        if not (_f16_dgrad_ok(mode, cin, cout) and (_fits32(raw, cin, cout) or not (mode == CONV_S1 and (cin == 32 or cin == cout == 64))) and
                 (mode != CONV_S2 or _fits32_transposed(raw, cout, cin)) and
                 (_fits32(raw, cin, cout) or not _on_s2roll(CONV_S2 if mode == DECONV_S2 else None, cout, cin))):
             return False

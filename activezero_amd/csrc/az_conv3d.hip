@@ -756,16 +756,20 @@ extern "C" long long az_conv3d_packed_floats_f16(int cin, int cout) {
 }
 
 // which kernel serves (mode, cout) in f16x3 -- the two read different packed-weight layouts
-static bool f16_on_roll(int mode, int cout) { return mode == 0 && cout == 32; }
+// the stride-1 layers with 32 output channels on the depth-rolling kernel of az_conv3d_roll.hip; since round 5 the 64 -> 64
+// ones too, as two workgroups per patch (AZ_CONV_ROLL64=0: this file's gather kernel, 0.61 ms at V1 against 0.4x)
+static bool f16_on_roll64(int mode, int cin, int cout) { return mode == 0 && cin == 64 && cout == 64 && az_options().conv_roll64 != 0; }
+static bool f16_on_roll(int mode, int cin, int cout) { return (mode == 0 && cout == 32) || f16_on_roll64(mode, cin, cout); }
 // the transposed 64 -> 32 layers on the depth-rolling kernel of az_conv3d_t2roll.hip (AZ_CONV_T2ROLL=0: az_conv3d_t2.hip)
 static bool f16_on_t2roll(int mode, int cin, int cout) { return mode == 2 && cin == 64 && cout == 32 && az_options().conv_t2roll != 0; }
 // the stride-2 32 -> 64 layers on the depth-rolling kernel of az_conv3d_s2roll.hip (AZ_CONV_S2ROLL=0: the gather kernel here)
 static bool f16_on_s2roll(int mode, int cin, int cout) { return mode == 1 && cin == 32 && cout == 64 && az_options().conv_s2roll != 0; }
-static bool f16_roll_layout(int mode, int cin, int cout) { return f16_on_roll(mode, cout) || f16_on_t2roll(mode, cin, cout) || f16_on_s2roll(mode, cin, cout); }
+static bool f16_roll_layout(int mode, int cin, int cout) { return f16_on_roll(mode, cin, cout) || f16_on_t2roll(mode, cin, cout) || f16_on_s2roll(mode, cin, cout); }
 
 // the layout az_conv3d_pack_weights_f16 writes for (mode, cin, cout): AZ_PACK_3D_ROLL or AZ_PACK_3D_GATHER (az_pack_f16_multi's `kind`)
 extern "C" int az_conv3d_f16_layout(int mode, int cin, int cout) {
     if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return AZ_EUNSUPPORTED;
+    if (f16_on_roll64(mode, cin, cout)) return AZ_PACK_3D_ROLL2;
     return f16_roll_layout(mode, cin, cout) ? AZ_PACK_3D_ROLL : AZ_PACK_3D_GATHER;
 }
 
@@ -774,7 +778,8 @@ extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const f
     AZ_REQUIRE_PTR(packed); AZ_REQUIRE_PTR(w); AZ_REQUIRE_PTR(w_amax);
     if (cin % 32 || cout % 32 || cin <= 0 || cout <= 0 || mode < 0 || mode > 2) return AZ_EUNSUPPORTED;
     if (f16_roll_layout(mode, cin, cout))
-        return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream));
+        return az_conv3d_pack_r16_f16(packed, w, w_amax, cin, cout, stride_out, stride_in, flip, az_stream(stream),
+                                      f16_on_roll64(mode, cin, cout) ? 2 : 1);
     const int total = 27 * cin * cout * 2;
     hipLaunchKernelGGL(conv3d_pack_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, az_stream(stream),
                        reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, stride_out, stride_in, flip, total);
@@ -782,7 +787,7 @@ extern "C" int az_conv3d_pack_weights_f16(float *packed, const float *w, const f
 }
 
 static int conv_f16_dispatch(ConvArgs &a, int mode, int cin, int cout, int epi, hipStream_t s) {
-    if (f16_on_roll(mode, cout)) return az_conv3d_roll_launch_f16(a, cin, epi, s);
+    if (f16_on_roll(mode, cin, cout)) return az_conv3d_roll_launch_f16(a, cin, epi, s, cout);
     if (f16_on_t2roll(mode, cin, cout)) {
         const int rc = az_conv3d_t2roll_launch(a, epi, s);
         if (rc != AZ_EUNSUPPORTED) return rc;
@@ -796,7 +801,8 @@ static int conv_f16_dispatch(ConvArgs &a, int mode, int cin, int cout, int epi, 
 // under the size conditions of their launchers); 0: it needs the fp32 tensor
 extern "C" int az_conv3d_fwd_f16_split_ok(int mode, int B, int cin, int cout, int Di, int Hi, int Wi) {
     if (mode < 0 || mode > 2 || B <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0) return 0;
-    if (f16_on_roll(mode, cout)) return (cin == 32 || cin == 64) && az_fits_buffer_offset((long long)Di * Hi * Wi * cin * 4) ? 1 : 0;
+    if (f16_on_roll(mode, cin, cout))
+        return (cin == 32 || cin == 64) && az_fits_buffer_offset((long long)Di * Hi * Wi * (cin > cout ? cin : cout) * 4) ? 1 : 0;
     if (f16_on_t2roll(mode, cin, cout))
         return az_fits_buffer_offset(8LL * Di * Hi * Wi * 32 * 4) && az_fits_buffer_offset((long long)Di * Hi * Wi * 64 * 4) ? 1 : 0;
     if (f16_on_s2roll(mode, cin, cout)) return az_fits_buffer_offset((long long)Di * Hi * Wi * 32 * 4) ? 1 : 0;
@@ -818,7 +824,12 @@ extern "C" int az_conv3d_fwd_f16(float *out, const float *in, const float *packe
 
 extern "C" long long az_conv3d_stats_tiles_f16(int mode, int B, int cin, int cout, int Di, int Hi, int Wi) {
     if (mode < 0 || mode > 2) return AZ_EINVAL;
-    if (f16_on_roll(mode, cout)) return az_conv3d_stats_tiles(mode, 2, B, cin, cout, Di, Hi, Wi);
+    if (f16_on_roll64(mode, cin, cout)) {
+        ConvArgs a{};
+        if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;
+        return az_conv3d_roll_stats_tiles(a, 64);
+    }
+    if (f16_on_roll(mode, cin, cout)) return az_conv3d_stats_tiles(mode, 2, B, cin, cout, Di, Hi, Wi);
     if (f16_on_t2roll(mode, cin, cout)) {
         ConvArgs a{};
         if (int e = conv_common(a, mode, B, cin, Di, Hi, Wi, 0)) return e;

@@ -31,10 +31,10 @@ int az_conv3d_m128_launch(const ConvArgs &a, int cin, int epi, int src, hipStrea
 int az_conv3d_roll_launch(const ConvArgs &a, int cin, int epi, hipStream_t s);
 // the same kernel on the f16x3 arithmetic (az_roll_common.h): input gradients; a.in_amax / a.w_amax set, weights packed
 // by az_conv3d_pack_r16_f16
-int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, int epi, hipStream_t s);
+int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, int epi, hipStream_t s, int cout = 32);
 int az_conv3d_pack_r16_f16(float *packed, const float *w, const float *w_amax, int cin, int cout, long long stride_out,
-                           long long stride_in, int flip, hipStream_t s);
-long long az_conv3d_roll_stats_tiles(const ConvArgs &a);  // rows of the BatchNorm partial buffers of an EPI-1 launch
+                           long long stride_in, int flip, hipStream_t s, int halves = 1);
+long long az_conv3d_roll_stats_tiles(const ConvArgs &a, int cout = 32);  // rows of the BatchNorm partial buffers of an EPI-1 launch
 int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long long stride_out, long long stride_in,
                        int flip, hipStream_t s);
 

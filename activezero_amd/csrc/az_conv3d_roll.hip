@@ -61,9 +61,15 @@ extern "C" int az_debug_roll_stamps(unsigned long long *out10, int reset) {
 // gradients only, az_roll_common.h); the slab keeps its 192-byte voxels either way (the third 64-byte part is then
 // unused), so addresses and the conflict-free swizzle are shared.
 // PS (AR = 1 only): the input is a pre-split tensor (az_roll_common.h): staging copies its two fp16 parts.
-template <int CIN, int EPI, int AR = 0, bool PS = false>
+// COUT = 64 (f16x3, round 5: the 64 -> 64 layers at V1 / V2 and their input gradients): TWO workgroups per patch and
+// segment, one per half of the output channels -- adjacent in the launch order, so the second finds the planes the first
+// fetched in L2; the packed weights hold the two halves one after the other (AZ_PACK_3D_ROLL2), each in the 32-channel
+// layout, the output / residual voxels are 256 bytes apart and every channel index carries the half's 32.
+template <int CIN, int EPI, int AR = 0, bool PS = false, int COUT = 32>
 __global__ void __launch_bounds__(256, 2)
 conv3d_roll_kernel(const ConvArgs a) {
+    static_assert(COUT == 32 || (COUT == 64 && AR == 1), "64 output channels: the f16x3 form only");
+    constexpr unsigned OVB = COUT * 4u;      // bytes per output voxel
     constexpr int NCH = CIN / 32;            // 32-channel chunks per plane
     constexpr int NP = AR ? 2 : 3;           // parts per operand
     constexpr int TAPF4 = NCH * 2 * NP * 64; // float4 per tap in the packed image: [tap][cc][n16][part][lane]
@@ -80,7 +86,9 @@ conv3d_roll_kernel(const ConvArgs a) {
 
     // ---- block -> (batch, depth segment, patch): contiguous chunk of the linear order per XCD, x fastest,
     //      so that the workgroups resident on an XCD are a compact (y, x) region walking the same depths ----
-    const int lin = a.map_mode >= 1 ? az_xcd_map(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    int lin = a.map_mode >= 1 ? az_xcd_map(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int co0 = COUT == 64 ? (lin & 1) * 32 : 0;  // first output channel of this workgroup
+    if (COUT == 64) lin >>= 1;
     const int tyb = (a.tiles_y + 1) >> 1;  // 8-row patch rows (a.tiles_y counts 4-row tiles)
     int tix, tiy, seg, b;
     az_roll_decode(lin, a.tiles_x, tyb, a.nseg, tix, tiy, seg, b);
@@ -90,13 +98,13 @@ conv3d_roll_kernel(const ConvArgs a) {
 
     // buffer resources: lane validity (zero padding of the input, patches that overhang the volume, depths
     // outside the segment) is an out-of-range offset, never a branch
-    const unsigned in_bytes = (unsigned)a.Di * a.Hi * a.Wi * CIN * 4u, out_bytes = (unsigned)a.Do * a.Ho * a.Wo * 32u * 4u;
+    const unsigned in_bytes = (unsigned)a.Di * a.Hi * a.Wi * CIN * 4u, out_bytes = (unsigned)a.Do * a.Ho * a.Wo * OVB;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in) + (size_t)b * (in_bytes / 4), 0, in_bytes, 0x00020000);
     const auto rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * (out_bytes / 4), 0, out_bytes, 0x00020000);
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(EPI == 2 ? a.res : a.out) + (size_t)b * (out_bytes / 4), 0, EPI == 2 ? out_bytes : 0u, 0x00020000);
     const auto rs_part = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.part : a.out, 0,
-                                                           EPI == 1 ? (unsigned)(a.ntiles * 32 * 2 * 4) : 0u, 0x00020000);
+                                                           EPI == 1 ? (unsigned)(a.ntiles * COUT * 2 * 4) : 0u, 0x00020000);
     const auto rs_cnt = __builtin_amdgcn_make_buffer_rsrc(EPI == 1 ? a.cnt : a.out, 0,
                                                           EPI == 1 ? (unsigned)(a.ntiles * 4) : 0u, 0x00020000);
 
@@ -179,7 +187,8 @@ conv3d_roll_kernel(const ConvArgs a) {
     // B: packed [tap][cc][n16][part][lane] float4 (conv3d_pack_r16_kernel), this wave's 16 output channels.  Read
     // through a buffer resource: one lane-offset register, the tap's byte offset travels in an SGPR / the immediate
     // (with flat addresses hipcc hoists the 27 x 64-bit tap addresses out of the walk and spills them)
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, 27u * CIN * 32u * 2u * NP, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp) + (size_t)(co0 / 32) * (27u * CIN * 32u * 2u * NP / 4u), 0,
+                                                        27u * CIN * 32u * 2u * NP, 0x00020000);
     const unsigned wlane = (unsigned)(wn * NP * 64 + lane) * 16u;
     auto load_b = [&](float4 (&bq)[NP], int tap_f4) {  // tap_f4: float4 index of the tap's first fragment (static)
 #pragma unroll
@@ -187,7 +196,7 @@ conv3d_roll_kernel(const ConvArgs a) {
             bq[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, tap_f4 * 16 + p * 1024, 0));
     };
     // per-channel epilogue constants, loaded once (four consecutive channels per lane after the quad transpose)
-    const int cq = wn * 16 + (lane & 12);
+    const int cq = co0 + wn * 16 + (lane & 12);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI != 1) {
         if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + cq);
@@ -219,13 +228,13 @@ conv3d_roll_kernel(const ConvArgs a) {
     auto finish = [&](int o, bool ok) {
         const int oh = ty0 + 4 * wm + (lane >> 4);  // row of the 4x4 tiles this lane's accumulator registers belong to
         const bool row_ok = ok && oh < a.Ho;
-        const unsigned row_off = (unsigned)((o * a.Ho + oh) * a.Wo) * 128u + (unsigned)cq * 4u;
+        const unsigned row_off = (unsigned)((o * a.Ho + oh) * a.Wo) * OVB + (unsigned)cq * 4u;
         if (EPI != 1) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int ow = tx0 + 4 * m + (lane & 3);
                 const f32x4 v = r16_quad_transpose(acc[2][m], lane);
-                const unsigned off = (row_ok && ow < a.Wo) ? row_off + (unsigned)ow * 128u : R_OOB;
+                const unsigned off = (row_ok && ow < a.Wo) ? row_off + (unsigned)ow * OVB : R_OOB;
                 float4 y = make_float4(v[0] * sc.x + sf.x, v[1] * sc.y + sf.y, v[2] * sc.z + sf.z, v[3] * sc.w + sf.w);
                 if (EPI == 2) {
                     const float4 rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, off, 0, 0));
@@ -241,7 +250,7 @@ conv3d_roll_kernel(const ConvArgs a) {
                 const f32x4 vt = r16_quad_transpose(acc[2][m], lane);
                 const int owt = tx0 + 4 * m + (lane & 3);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vt), rs_out,
-                                                       (row_ok && owt < a.Wo) ? row_off + (unsigned)owt * 128u : R_OOB, 0, 0);
+                                                       (row_ok && owt < a.Wo) ? row_off + (unsigned)owt * OVB : R_OOB, 0, 0);
             }
             st_k = (ok && st_first) ? acc[2][0][0] : st_k;  // (element (0,0) is valid whenever any of the lane's is)
             st_first = st_first && !ok;
@@ -276,11 +285,11 @@ conv3d_roll_kernel(const ConvArgs a) {
         const int tiy4 = 2 * tiy + wm;
         const bool tile_ok = tiy4 < a.tiles_y;
         const unsigned tile_id = (unsigned)(((b * a.nseg + seg) * a.tiles_y + tiy4) * a.tiles_x + tix);
-        const unsigned ch = wn * 16 + (lane & 15);
+        const unsigned ch = co0 + wn * 16 + (lane & 15);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_float2(n * mean, fmaxf(m2, 0.f))), rs_part,
                                               (tile_ok && lane < 16 && !R16_NOPART) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, n), rs_cnt,
-                                              (tile_ok && lane == 0 && wn == 0) ? tile_id * 4u : R_OOB, 0, 0);
+                                              (tile_ok && lane == 0 && wn == 0 && co0 == 0) ? tile_id * 4u : R_OOB, 0, 0);
     };
 
     auto rotate = [&]() {  // what was output p (slot 1) becomes output (p+1) - 1 of the next plane, ...
@@ -368,7 +377,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     // accumulator layout (r16_chain9): lane = voxel (row (lane >> 2) & 3, x lane & 3) of the 4x4 tile, registers = the
     // four channels 16 wn + 4 (lane >> 4) + r: no transpose.  y = acc * 2^out_exp (+ residual); no affine map, no ReLU
     // (an input gradient has neither).
-    const int cqh = wn * 16 + 4 * (lane >> 4);
+    const int cqh = co0 + wn * 16 + 4 * (lane >> 4);
     float4 sch = make_float4(1.f, 1.f, 1.f, 1.f), sfh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (AR) {
         if (EPI != 1) {
@@ -386,7 +395,7 @@ conv3d_roll_kernel(const ConvArgs a) {
     auto finish_h = [&](int o, bool ok) {
         const int oh = ty0 + 4 * wm + ((lane >> 2) & 3);
         const bool row_ok = ok && oh < a.Ho;
-        const unsigned row_off = (unsigned)((o * a.Ho + oh) * a.Wo) * 128u + (unsigned)cqh * 4u;
+        const unsigned row_off = (unsigned)((o * a.Ho + oh) * a.Wo) * OVB + (unsigned)cqh * 4u;
         if (EPI == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) hk[r] = (row_ok && h_first) ? acc[2][0][r] * sch.x : hk[r];  // (sch.x = 2^out_exp here)
@@ -396,7 +405,7 @@ conv3d_roll_kernel(const ConvArgs a) {
         for (int m = 0; m < 4; ++m) {
             const int ow = tx0 + 4 * m + (lane & 3);
             const bool vok = row_ok && ow < a.Wo;
-            const unsigned off = vok ? row_off + (unsigned)ow * 128u : R_OOB;
+            const unsigned off = vok ? row_off + (unsigned)ow * OVB : R_OOB;
             float4 y = make_float4(fmaf(acc[2][m][0], sch.x, sfh.x), fmaf(acc[2][m][1], sch.y, sfh.y),
                                    fmaf(acc[2][m][2], sch.z, sfh.z), fmaf(acc[2][m][3], sch.w, sfh.w));
             if (EPI == 2) {
@@ -443,7 +452,7 @@ conv3d_roll_kernel(const ConvArgs a) {
                                                   (tile_ok && (lane & 15) == 0 && !R16_NOPART) ? (unsigned)(((size_t)ch * a.ntiles + tile_id) * 8) : R_OOB, 0, 0);
         }
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ntot), rs_cnt,
-                                              (tile_ok && lane == 0 && wn == 0) ? tile_id * 4u : R_OOB, 0, 0);
+                                              (tile_ok && lane == 0 && wn == 0 && co0 == 0) ? tile_id * 4u : R_OOB, 0, 0);
     };
     // A stage = 36 chains of nine MFMAs (r16_chain9: K = the three kw taps of a (kd, kh) row), ordered kh, tile pair,
     // kd, tile: 144 accumulate-adds per stage (the K32-block form needs 432 and was VALU-issue bound at 0.94 ms: an
@@ -596,59 +605,71 @@ int az_conv3d_pack_r16(float *packed, const float *w, int cin, int cout, long lo
 // f16x3 packing: [tap][cc32][n16][part(2)][lane(64)][8] fp16 of w * 2^k, k from the tensor's largest magnitude
 __global__ void __launch_bounds__(256)
 conv3d_pack_r16_f16_kernel(unsigned short *__restrict__ dst, const float *__restrict__ src, const float *__restrict__ amax,
-                           int cin, int cout, long long sn, long long sk, int flip, int total) {
+                           int cin, int cout, long long sn, long long sk, int flip, int total, int halves) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const float scale = az_pow2(az_f16_scale_exp(az_amax_read(amax)));  // (before the early exit: a wave-wide read)
     if (idx >= total) return;
     const int j = idx & 7, lane = (idx >> 3) & 63;
-    int r = idx >> 9;
+    // halves = 2 (AZ_PACK_3D_ROLL2): the image of output channels 0..31, then that of 32..63, each in the 32-channel layout
+    const int half = halves == 2 ? idx / (total / 2) : 0;
+    int r = (halves == 2 ? idx % (total / 2) : idx) >> 9;
     const int p = r & 1; r >>= 1;
-    const int nn = cout / 16, nch = cin / 32;
+    const int nn = (halves == 2 ? 32 : cout) / 16, nch = cin / 32;
     const int n = r % nn; r /= nn;
     const int cc = r % nch;
     const int tap = r / nch;
-    const int co = n * 16 + (lane & 15);
+    const int co = half * 32 + n * 16 + (lane & 15);
     const int ci = cc * 32 + 8 * (lane >> 4) + j;
     dst[idx] = az_split2_f16_part(src[co * sn + ci * sk + (flip ? 26 - tap : tap)] * scale, p);
 }
 
 int az_conv3d_pack_r16_f16(float *packed, const float *w, const float *w_amax, int cin, int cout, long long stride_out,
-                           long long stride_in, int flip, hipStream_t s) {
-    if (cin % 32 || cout % 16 || cin <= 0 || cout <= 0) return AZ_EUNSUPPORTED;
+                           long long stride_in, int flip, hipStream_t s, int halves) {
+    if (cin % 32 || cout % 16 || cin <= 0 || cout <= 0 || (halves == 2 && cout != 64)) return AZ_EUNSUPPORTED;
     const int total = 27 * cin * cout * 2;
     hipLaunchKernelGGL(conv3d_pack_r16_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
-                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, stride_out, stride_in, flip, total);
+                       reinterpret_cast<unsigned short *>(packed), w, w_amax, cin, cout, stride_out, stride_in, flip, total, halves);
     return az_launch_status();
 }
 
 // depth segments: one round of workgroups over the chip's 512 slots (256 CUs x 2) if the patches allow it,
 // otherwise the split that minimises rounds x (planes walked per workgroup)
-static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len) {
-    az_roll_segments((long long)a.B * ((a.tiles_y + 1) / 2) * a.tiles_x, a.Do, az_options().roll_seglen, nseg, seg_len);
+static void roll_segments(const ConvArgs &a, int &nseg, int &seg_len, int halves = 1) {
+    az_roll_segments((long long)a.B * ((a.tiles_y + 1) / 2) * a.tiles_x * halves, a.Do, az_options().roll_seglen, nseg, seg_len);
 }
 
 // rows of the BatchNorm partial buffers of a roll launch: one per (batch, depth segment, 4x16 tile)
-long long az_conv3d_roll_stats_tiles(const ConvArgs &a) {
+long long az_conv3d_roll_stats_tiles(const ConvArgs &a, int cout) {
     int nseg, seg_len;
-    roll_segments(a, nseg, seg_len);
+    roll_segments(a, nseg, seg_len, cout / 32);
     return (long long)a.B * nseg * a.tiles_y * a.tiles_x;
 }
 
-template <int CIN, int EPI, int AR = 0, bool PS = false>
+template <int CIN, int EPI, int AR = 0, bool PS = false, int COUT = 32>
 static int launch_roll(ConvArgs a, hipStream_t s) {
-    roll_segments(a, a.nseg, a.seg_len);
+    roll_segments(a, a.nseg, a.seg_len, COUT / 32);
     if (EPI == 1) a.ntiles = (long long)a.B * a.nseg * a.tiles_y * a.tiles_x;
-    const long long blocks = (long long)a.B * a.nseg * ((a.tiles_y + 1) / 2) * a.tiles_x;
+    const long long blocks = (long long)a.B * a.nseg * ((a.tiles_y + 1) / 2) * a.tiles_x * (COUT / 32);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
     // the kernel addresses one batch element of a tensor through a 32-bit buffer offset
-    if (!az_fits_buffer_offset((long long)a.Di * a.Hi * a.Wi * CIN * 4) || a.ntiles * 256 >= 0xffffff00LL) return AZ_EUNSUPPORTED;
-    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI, AR, PS>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (!az_fits_buffer_offset((long long)a.Di * a.Hi * a.Wi * (CIN > COUT ? CIN : COUT) * 4) || a.ntiles * 2 * COUT * 4 >= 0xffffff00LL)
+        return AZ_EUNSUPPORTED;
+    hipLaunchKernelGGL((conv3d_roll_kernel<CIN, EPI, AR, PS, COUT>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     return az_launch_status();
 }
 
-int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, int epi, hipStream_t s) {
+int az_conv3d_roll_launch_f16(const ConvArgs &a, int cin, int epi, hipStream_t s, int cout) {
     if (!a.in_amax || !a.w_amax) return AZ_ENULL;
     const int e = epi ? 1 : (a.res ? 2 : 0);
+    if (cout == 64) {  // 64 -> 64: two workgroups per patch (AZ_PACK_3D_ROLL2 weights)
+        if (cin != 64) return AZ_EUNSUPPORTED;
+        if (a.in_split) {
+            if (e == 1) return AZ_EUNSUPPORTED;
+            return e == 2 ? launch_roll<64, 2, 1, true, 64>(a, s) : launch_roll<64, 0, 1, true, 64>(a, s);
+        }
+        return e == 1 ? launch_roll<64, 1, 1, false, 64>(a, s) : e == 2 ? launch_roll<64, 2, 1, false, 64>(a, s) : launch_roll<64, 0, 1, false, 64>(a, s);
+    }
+    if (cout != 32) return AZ_EUNSUPPORTED;
     if (a.in_split) {  // pre-split input: the input gradients of the 32 -> 32 / 32 -> 64 layers (no BatchNorm-partials epilogue)
         if (e == 1) return AZ_EUNSUPPORTED;
         if (cin == 32) return e == 2 ? launch_roll<32, 2, 1, true>(a, s) : launch_roll<32, 0, 1, true>(a, s);

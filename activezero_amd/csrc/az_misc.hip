@@ -71,6 +71,7 @@ const AzOptions &az_options() {
         v.wgrad_r16_wide = az_env_int("AZ_WGRAD_R16_WIDE", 0);
         v.conv_t2roll = az_env_int("AZ_CONV_T2ROLL", 1);
         v.conv_s2roll = az_env_int("AZ_CONV_S2ROLL", 1);
+        v.conv_roll64 = az_env_int("AZ_CONV_ROLL64", 1);
         v.s2roll_seglen = az_env_int("AZ_S2ROLL_SEGLEN", 0);
         v.conv2d_roll_h = az_env_int("AZ_CONV2D_ROLL_H", 1);
         v.corr_fp32 = az_env_int("AZ_CORR_FP32", 0);
@@ -88,7 +89,7 @@ extern "C" int az_option(const char *name) {
         {"AZ_BN_BWD_FUSED", o.bn_bwd_fused}, {"AZ_CONV2D_ROLL_NT4", o.conv2d_roll_nt4}, {"AZ_CONV2D_WGRAD_R16", o.conv2d_wgrad_r16}, {"AZ_CONV2D_WGRAD_W64", o.conv2d_wgrad_w64},
         {"AZ_CONV_M128", o.conv_m128}, {"AZ_CONV_MAP", o.conv_map}, {"AZ_ROLL_SEGLEN", o.roll_seglen},
         {"AZ_WGRAD_SLOTS", o.wgrad_slots}, {"AZ_WGRAD_ORDER", o.wgrad_order}, {"AZ_WGRAD_FW", o.wgrad_fw},
-        {"AZ_WGRAD_R16", o.wgrad_r16}, {"AZ_WGRAD_R16_WGS", o.wgrad_r16_wgs}, {"AZ_WGRAD_S2R16", o.wgrad_s2r16}, {"AZ_WGRAD_R16_XCD", o.wgrad_r16_xcd}, {"AZ_WGRAD_R16_WIDE", o.wgrad_r16_wide}, {"AZ_CONV_T2ROLL", o.conv_t2roll}, {"AZ_CONV_S2ROLL", o.conv_s2roll}, {"AZ_S2ROLL_SEGLEN", o.s2roll_seglen}, {"AZ_CONV2D_ROLL_H", o.conv2d_roll_h}, {"AZ_CORR_FP32", o.corr_fp32},
+        {"AZ_WGRAD_R16", o.wgrad_r16}, {"AZ_WGRAD_R16_WGS", o.wgrad_r16_wgs}, {"AZ_WGRAD_S2R16", o.wgrad_s2r16}, {"AZ_WGRAD_R16_XCD", o.wgrad_r16_xcd}, {"AZ_WGRAD_R16_WIDE", o.wgrad_r16_wide}, {"AZ_CONV_T2ROLL", o.conv_t2roll}, {"AZ_CONV_S2ROLL", o.conv_s2roll}, {"AZ_CONV_ROLL64", o.conv_roll64}, {"AZ_S2ROLL_SEGLEN", o.s2roll_seglen}, {"AZ_CONV2D_ROLL_H", o.conv2d_roll_h}, {"AZ_CORR_FP32", o.corr_fp32},
         {"AZ_PATCH_TILED", o.patch_tiled}, {"AZ_PATCH_K", o.patch_k}};
     for (const auto &e : t) {
         const char *a = e.n, *b = name;

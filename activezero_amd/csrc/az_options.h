@@ -19,6 +19,7 @@ struct AzOptions {
     int conv2d_roll_h;     // AZ_CONV2D_ROLL_H     1: f16x3 2-D layers with 64 output channels on conv2d_roll64_kernel (half channels x half patch per wave)
     int conv_t2roll;       // AZ_CONV_T2ROLL       1: f16x3 transposed 64 -> 32 layers on az_conv3d_t2roll.hip
     int s2roll_seglen;     // AZ_S2ROLL_SEGLEN     > 0: output planes per depth segment of az_conv3d_s2roll.hip (0: chosen per launch)
+    int conv_roll64;       // AZ_CONV_ROLL64       1: f16x3 stride-1 64 -> 64 layers on az_conv3d_roll.hip, two workgroups per patch (0: az_conv3d.hip's gather kernel)
     int conv_s2roll;       // AZ_CONV_S2ROLL       1: f16x3 stride-2 32 -> 64 layers on az_conv3d_s2roll.hip (0: az_conv3d.hip's gather kernel)
     int wgrad_r16_xcd;     // AZ_WGRAD_R16_XCD     1: that kernel's columns in XCD-contiguous runs
     int wgrad_r16_wide;    // AZ_WGRAD_R16_WIDE    1: its f16x3 form with the taps split over the waves on 32x32x16 tiles (round 5; default 0: not faster, az_conv3d_wgrad16.hip)

@@ -4,6 +4,7 @@
 //   AZ_PACK_2D_ROLL   az_conv2d_roll.hip   [cout/32][tap 9][cin/32][n16 2][part 2][lane 64][8]
 //   AZ_PACK_3D_GATHER az_conv3d.hip        [tap 27][cin/32][cout/32][part 2][kb 2][lane 64][8]
 //   AZ_PACK_3D_ROLL   az_conv3d_roll.hip   [tap 27][cin/32][cout/16][part 2][lane 64][8]
+//   AZ_PACK_3D_ROLL2  az_conv3d_roll.hip   [cout/32][tap 27][cin/32][n16 2][part 2][lane 64][8]   (64 output channels: one image per half)
 // every element = part p (0: hi, 1: lo) of  w[co * s_co + ci * s_ci + (flip ? taps - 1 - tap : tap)] * 2^k  as fp16,
 // k = az_f16_scale_exp(max |w|).
 #pragma once
@@ -36,6 +37,14 @@ __device__ __forceinline__ unsigned short az_pack_f16_elem(const AzPackDesc &d, 
         const int cc = (int)(r % nch);
         tap = (int)(r / nch);
         co = n * 32 + (lane & 31); ci = cc * 32 + 16 * kb + 8 * (lane >> 5) + j;
+    } else if (d.kind == AZ_PACK_3D_ROLL2) {
+        p = (int)(r & 1); r >>= 1;
+        const int n = (int)(r & 1); r >>= 1;
+        const int nch = d.cin / 32;
+        const int cc = (int)(r % nch); r /= nch;
+        tap = (int)(r % d.taps);
+        const int half = (int)(r / d.taps);
+        co = half * 32 + n * 16 + (lane & 15); ci = cc * 32 + 8 * (lane >> 4) + j;
     } else {  // AZ_PACK_3D_ROLL
         p = (int)(r & 1); r >>= 1;
         const int nn = d.cout / 16, nch = d.cin / 32;

@@ -226,6 +226,7 @@ int az_absmax(float *amax, const float *x, long long n, void *stream);
 #define AZ_PACK_2D_ROLL 1
 #define AZ_PACK_3D_GATHER 2
 #define AZ_PACK_3D_ROLL 3
+#define AZ_PACK_3D_ROLL2 4 /* 64 output channels on the depth-rolling kernel: two AZ_PACK_3D_ROLL images of 32 channels each, one after the other */
 typedef struct AzPackDesc {
     void *dst;           /* packed image (fp16 pairs) */
     const float *src;    /* the weight tensor in PyTorch's layout */
@@ -253,7 +254,7 @@ long long az_conv3d_packed_floats_f16(int cin, int cout);
  * ([tap][cin/32][cout/16][2][64][8 fp16]), everything else on the gather kernel ([tap][cin/32][cout/32][2][2][64][8]). */
 int az_conv3d_pack_weights_f16(float *packed, const float *w, const float *w_amax, int cin, int cout,
                                long long stride_out, long long stride_in, int flip, int mode, void *stream);
-/* which of the two layouts that is: AZ_PACK_3D_ROLL / AZ_PACK_3D_GATHER (the `kind` of an az_pack_f16_multi descriptor) */
+/* which of the layouts that is: AZ_PACK_3D_ROLL / AZ_PACK_3D_ROLL2 / AZ_PACK_3D_GATHER (the `kind` of an az_pack_f16_multi descriptor) */
 int az_conv3d_f16_layout(int mode, int cin, int cout);
 /* az_conv3d_fwd / az_conv3d_fwd_stats / az_conv3d_stats_tiles on the f16x3 arithmetic (src = 0 only).  in_amax /
  * w_amax: device scalars holding max |in| and max |w| (of the UNPACKED weights).  The input gradient of a layer is

@@ -354,8 +354,10 @@ def test_presplit_routing_matches_the_library_queries():
     assert ok(t(32, 8, 16, 32), t(64, 4, 8, 16), conv3d.CONV_S2, 32, 64, True, True)       # conv1: t2roll + wgrad_s2r16
     assert ok(t(64, 4, 8, 16), t(64, 4, 8, 16), conv3d.CONV_S1, 64, 64, False, True)       # weight gradient alone
     assert ok(t(64, 4, 8, 16), t(32, 8, 16, 32), conv3d.DECONV_S2, 64, 32, False, True)    # transposed: fine operand
-    # gather-kernel input gradients read fp32 (until they move onto the rolling machinery): not pre-split
-    assert not ok(t(64, 4, 8, 16), t(64, 4, 8, 16), conv3d.CONV_S1, 64, 64, True, True)
+    # gather-kernel input gradients read fp32; the stride-1 64 -> 64 ones moved onto the rolling kernel in round 5 (COUT = 64)
+    on_roll64 = conv3d._lib.lib().az_option(b"AZ_CONV_ROLL64") != 0
+    assert ok(t(64, 4, 8, 16), t(64, 4, 8, 16), conv3d.CONV_S1, 64, 64, True, True) == on_roll64
+    assert not ok(t(64, 4, 8, 16), t(64, 2, 4, 8), conv3d.CONV_S2, 64, 64, True, True)        # conv3: its input gradient is the gather kernel's
     # conv6 (transposed 64 -> 32): its input gradient is the stride-2 rolling kernel since az_conv3d_s2roll.hip
     on_s2roll = conv3d._lib.lib().az_option(b"AZ_CONV_S2ROLL") != 0
     assert ok(t(64, 4, 8, 16), t(32, 8, 16, 32), conv3d.DECONV_S2, 64, 32, True, True) == on_s2roll

@@ -39,6 +39,9 @@ def test_multi_pack_writes_what_the_per_tensor_launches_write():
     s2_kind = _lib.lib().az_conv3d_f16_layout(conv3d.CONV_S2, 32, 64)
     add(w3s, s2_kind, 32, 64, 32, 64, 32 * 27, 27, 27, False,
         lambda pk, w, am: _call("az_conv3d_pack_weights_f16", _p(pk), _p(w), _p(am), 32, 64, 32 * 27, 27, 0, conv3d.CONV_S2, _stream()))
+    r64_kind = _lib.lib().az_conv3d_f16_layout(conv3d.CONV_S1, 64, 64)  # stride-1 64 -> 64: two 32-channel images (AZ_PACK_3D_ROLL2)
+    add(w3, r64_kind, 64, 64, 64, 64, 27, 64 * 27, 27, True,
+        lambda pk, w, am: _call("az_conv3d_pack_weights_f16", _p(pk), _p(w), _p(am), 64, 64, 27, 64 * 27, 1, conv3d.CONV_S1, _stream()))
     w3b = seeded((32, 32, 3, 3, 3), 2, -0.3, 0.3)
     add(w3b, conv3d.PACK_3D_ROLL, 32, 32, 32, 32, 27, 32 * 27, 27, True,
         lambda pk, w, am: _call("az_conv3d_pack_weights_f16", _p(pk), _p(w), _p(am), 32, 32, 27, 32 * 27, 1, conv3d.CONV_S1, _stream()))
