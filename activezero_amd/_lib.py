@@ -101,6 +101,8 @@ _SIGS = {
     "az_conv2d_packed_floats": [_INT] * 4,
     "az_conv2d_pack_weights": [_PTR, _PTR] + [_INT] * 4 + [_LL, _LL] + [_INT] * 3 + [_PTR],
     "az_conv2d_fwd": [_PTR] * 6 + [_INT] * 12 + [_PTR],
+    "az_rows_concat": [_PTR, _LL, _LL, _INT, _PTR, _PTR, _PTR, _PTR],
+    "az_rows_slice_to_image": [_PTR, _PTR, _LL, _LL, _INT, _INT, _INT, _PTR],
     "az_gru_rh": [_PTR] * 3 + [_LL, _INT, _INT, _PTR],
     "az_gru_out": [_PTR] * 4 + [_LL, _INT, _INT, _PTR],
     "az_gru_bwd1": [_PTR] * 7 + [_LL, _INT, _INT, _PTR, _PTR, _PTR],

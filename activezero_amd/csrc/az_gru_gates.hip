@@ -162,3 +162,111 @@ extern "C" int az_gru_bwd3(float *dh, float *dx, const float *dh_acc, const floa
                        (const float4 *)dh_acc, (const float4 *)d_rhx, (const float4 *)d_hx, npix, hid / 4, inp / 4);
     return az_launch_status();
 }
+
+// ---- [h | x_0 | x_1 ..] rows in ONE launch (round 5) --------------------------------------------------------------------
+// hx[p][..] = the concatenation over the sources of their channels at pixel p.  A source is either dense rows [npix][c]
+// (kind 0: the previous update's state, a cached channels-last copy of the context) or an NCHW image [B][c][HW] (kind 1: the
+// correlation lookup).  torch did this with one strided copy per source -- 64 + 52 + 109 us per update on the RAFT workload
+// (transposing elementwise kernels), 22 updates per step.  A workgroup takes 64 pixels: row sources are copied 16 bytes per
+// lane (a tile's rows are ONE contiguous block of the source), image sources go through a [c][64 + 1] LDS tile (reads
+// coalesced along the pixels, writes along the channels).
+struct RowsCatArgs {
+    const float *src[4];
+    int c[4], kind[4], at[4];  // channels, layout, first destination channel
+    int nsrc, ctot;
+    long long npix, hw;
+};
+#define RC_PIX 64
+#define RC_MAXC 128  // channels of an image source (LDS tile)
+__global__ void __launch_bounds__(256)
+rows_concat_kernel(float *__restrict__ dst, const RowsCatArgs a) {
+    __shared__ float tile[RC_MAXC * (RC_PIX + 1)];
+    const long long p0 = (long long)blockIdx.x * RC_PIX;
+    const int np = (int)min((long long)RC_PIX, a.npix - p0);
+    for (int s = 0; s < a.nsrc; ++s) {
+        const int c = a.c[s], at = a.at[s];
+        if (a.kind[s] == 0) {
+            const int c4 = c >> 2;
+            const float4 *src = reinterpret_cast<const float4 *>(a.src[s]) + p0 * c4;
+            for (int i = threadIdx.x; i < np * c4; i += 256) {
+                const int p = i / c4, q = i - p * c4;
+                *reinterpret_cast<float4 *>(dst + (p0 + p) * a.ctot + at + 4 * q) = src[i];
+            }
+        } else {
+            __syncthreads();  // (the tile of the source before)
+            for (int i = threadIdx.x; i < c * RC_PIX; i += 256) {
+                const int ch = i / RC_PIX, p = i - ch * RC_PIX;
+                const long long g = p0 + p;
+                if (p < np) {
+                    const long long b = g / a.hw, r = g - b * a.hw;
+                    tile[ch * (RC_PIX + 1) + p] = a.src[s][(b * c + ch) * a.hw + r];
+                }
+            }
+            __syncthreads();
+            const int c4 = c >> 2;
+            for (int i = threadIdx.x; i < np * c4; i += 256) {
+                const int p = i / c4, q = i - p * c4;
+                const float4 v = make_float4(tile[(4 * q + 0) * (RC_PIX + 1) + p], tile[(4 * q + 1) * (RC_PIX + 1) + p],
+                                             tile[(4 * q + 2) * (RC_PIX + 1) + p], tile[(4 * q + 3) * (RC_PIX + 1) + p]);
+                *reinterpret_cast<float4 *>(dst + (p0 + p) * a.ctot + at + 4 * q) = v;
+            }
+        }
+    }
+}
+
+// dst rows [npix][ctot] <- up to four sources (channel counts multiples of 4, image sources at most 128 channels); kinds: 0 dense
+// rows [npix][c], 1 NCHW image [npix / hw][c][hw]
+extern "C" int az_rows_concat(float *dst, long long npix, long long hw, int nsrc, const float *const *srcs, const int *channels,
+                              const int *kinds, void *stream) {
+    AZ_REQUIRE_PTR(dst); AZ_REQUIRE_PTR(srcs); AZ_REQUIRE_PTR(channels); AZ_REQUIRE_PTR(kinds);
+    if (nsrc < 1 || nsrc > 4 || npix <= 0 || hw <= 0 || npix % hw) return AZ_EINVAL;
+    RowsCatArgs a{};
+    int at = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        if (srcs[s] == nullptr) return AZ_ENULL;
+        if (channels[s] <= 0 || channels[s] % 4 || (kinds[s] != 0 && kinds[s] != 1) || (kinds[s] == 1 && channels[s] > RC_MAXC)) return AZ_EUNSUPPORTED;
+        a.src[s] = srcs[s]; a.c[s] = channels[s]; a.kind[s] = kinds[s]; a.at[s] = at;
+        at += channels[s];
+    }
+    a.nsrc = nsrc; a.ctot = at; a.npix = npix; a.hw = hw;
+    const long long blocks = (npix + RC_PIX - 1) / RC_PIX;
+    if (blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
+    hipLaunchKernelGGL(rows_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, az_stream(stream), dst, a);
+    return az_launch_status();
+}
+
+// the inverse for ONE channel slice: image [B][c][hw] (NCHW, dense) <- rows[p][at .. at + c) of [npix][ctot] rows: the gradient
+// of an image source, which torch took with a transposing .contiguous() of a strided view
+__global__ void __launch_bounds__(256)
+rows_slice_to_image_kernel(float *__restrict__ img, const float *__restrict__ rows, long long npix, long long hw, int ctot, int at, int c) {
+    __shared__ float tile[RC_MAXC * (RC_PIX + 1)];
+    const long long p0 = (long long)blockIdx.x * RC_PIX;
+    const int np = (int)min((long long)RC_PIX, npix - p0);
+    const int c4 = c >> 2;
+    for (int i = threadIdx.x; i < np * c4; i += 256) {
+        const int p = i / c4, q = i - p * c4;
+        const float4 v = *reinterpret_cast<const float4 *>(rows + (p0 + p) * ctot + at + 4 * q);
+        tile[(4 * q + 0) * (RC_PIX + 1) + p] = v.x; tile[(4 * q + 1) * (RC_PIX + 1) + p] = v.y;
+        tile[(4 * q + 2) * (RC_PIX + 1) + p] = v.z; tile[(4 * q + 3) * (RC_PIX + 1) + p] = v.w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < c * RC_PIX; i += 256) {
+        const int ch = i / RC_PIX, p = i - ch * RC_PIX;
+        const long long g = p0 + p;
+        if (p < np) {
+            const long long b = g / hw, r = g - b * hw;
+            img[(b * c + ch) * hw + r] = tile[ch * (RC_PIX + 1) + p];
+        }
+    }
+}
+
+extern "C" int az_rows_slice_to_image(float *image, const float *rows, long long npix, long long hw, int ctot, int at, int c, void *stream) {
+    AZ_REQUIRE_PTR(image); AZ_REQUIRE_PTR(rows);
+    if (npix <= 0 || hw <= 0 || npix % hw || ctot <= 0 || ctot % 4 || at < 0 || at % 4 || c <= 0 || c % 4 || at + c > ctot) return AZ_EINVAL;
+    if (c > RC_MAXC) return AZ_EUNSUPPORTED;
+    const long long blocks = (npix + RC_PIX - 1) / RC_PIX;
+    if (blocks > 0x7fffffffLL) return AZ_EUNSUPPORTED;
+    hipLaunchKernelGGL(rows_slice_to_image_kernel, dim3((unsigned)blocks), dim3(256), 0, az_stream(stream), image, rows, npix, hw, ctot, at, c);
+    return az_launch_status();
+}
+

@@ -21,6 +21,8 @@ The file is deliberately not called update.py: the rest of that reference module
 multi-level block) is ordinary torch code outside this path and keeps resolving from the reference tree; the
 one-line edit there is `from nets.raft.gru import ConvGRU`.
 """
+import ctypes
+import os
 import weakref
 
 import torch
@@ -57,6 +59,72 @@ def _context_rows(cz, cr, cq):
             del _CTX_CACHE[k]
     _cache_put(_CTX_CACHE, key, ((czr, cqr), tuple(weakref.ref(t) for t in (cz, cr, cq))), 4)
     return czr, cqr
+
+
+# ---- [h | x_0 | x_1 ..] rows in one launch (az_rows_concat) -----------------------------------------------------------------
+# AZ_GRU_ASSEMBLE=0 (read once): one torch slice assignment per source, as in round 4 (A/B runs)
+ASSEMBLE = os.environ.get("AZ_GRU_ASSEMBLE", "1") != "0"
+_ROWS_CACHE = {}
+_SEEN_ONCE = {}
+ROW_CONVERSIONS = 0  # cached channels-last copies made so far (tests)
+
+
+def _cached_rows(t):
+    """a channels-last fp32 copy of an NCHW tensor that comes back update after update (the context features: the same tensor
+    in all 22 updates of a step), made once; weak-referenced like _context_rows' entries"""
+    global ROW_CONVERSIONS
+    key = _cache_key(t)
+    hit = _cache_get(_ROWS_CACHE, key)
+    if hit is not None and hit[1]() is t:
+        return hit[0]
+    with torch.no_grad():
+        r = t.detach().permute(0, 2, 3, 1).float().contiguous()
+    ROW_CONVERSIONS += 1
+    with _CACHE_LOCK:
+        for k in [k for k, v in _ROWS_CACHE.items() if v[1]() is None]:
+            del _ROWS_CACHE[k]
+    _cache_put(_ROWS_CACHE, key, (r, weakref.ref(t)), 8)
+    return r
+
+
+def _source(t):
+    """(tensor that owns the memory, kind) of one input for az_rows_concat: kind 0 = dense rows, 1 = dense NCHW image; None:
+    neither (the caller falls back to torch)"""
+    if t.dtype != torch.float32:
+        return None
+    if t.permute(0, 2, 3, 1).is_contiguous():
+        return t, 0
+    if not t.is_contiguous():
+        return None
+    if t.shape[1] <= 128:
+        # an image the kernel can transpose on the way -- unless it is the same tensor as last time: then a cached copy is cheaper
+        key = _cache_key(t)
+        seen = _cache_get(_SEEN_ONCE, key)
+        if (seen is None or seen[0]() is not t) and _cache_get(_ROWS_CACHE, key) is None:
+            _cache_put(_SEEN_ONCE, key, (weakref.ref(t),), 8)
+            return t, 1
+    return _cached_rows(t), 0
+
+
+def _assemble(h, xs):
+    """hx rows [B,H,W,C_h + sum C_x] and, per x, whether it entered as an NCHW image (its gradient leaves the same way)"""
+    b, c, hh, ww = h.shape
+    ct = c + sum(t.shape[1] for t in xs)
+    hx = h.new_empty(b, hh, ww, ct)
+    srcs = [_source(t) for t in (h, *xs)] if (ASSEMBLE and len(xs) <= 3) else [None]
+    if any(s is None for s in srcs) or any(t.shape[1] % 4 for t in (h, *xs)):
+        hx[..., :c] = h.permute(0, 2, 3, 1)
+        at = c
+        for t in xs:
+            hx[..., at:at + t.shape[1]] = t.permute(0, 2, 3, 1)
+            at += t.shape[1]
+        return hx, [False] * len(xs)
+    n = len(srcs)
+    ptrs = (ctypes.c_void_p * n)(*[s[0].data_ptr() for s in srcs])
+    chans = (ctypes.c_int * n)(*[t.shape[1] for t in (h, *xs)])
+    kinds = (ctypes.c_int * n)(*[s[1] for s in srcs])
+    _call("az_rows_concat", _p(hx), b * hh * ww, hh * ww, n, ptrs, chans, kinds, _stream())
+    return hx, [s[1] == 1 for s in srcs[1:]]
 
 
 def _pack_bf16(weights, cache):
@@ -196,12 +264,8 @@ class _GRUStepBf16(torch.autograd.Function):
         with torch.cuda.device(h.device):
             b, _, hh, ww = h.shape
             npix = b * hh * ww
-            hx = h.new_empty(b, hh, ww, c + ci)  # [h | x_0 | x_1 ..] rows, written once (no torch.cat of the inputs)
-            hx[..., :c] = h.permute(0, 2, 3, 1)
-            at = c
-            for t in xs:
-                hx[..., at:at + t.shape[1]] = t.permute(0, 2, 3, 1)
-                at += t.shape[1]
+            hx, as_image = _assemble(h, xs)  # [h | x_0 | x_1 ..] rows in one launch (az_rows_concat)
+            ctx.as_image = as_image
             bzr = torch.cat([bz, br]).detach().float().contiguous()
             zr = conv3x3_bf16(hx, pk((wz, wr)), c + ci, 2 * c, bzr, czr, ACT_SIGMOID, h1=h1)
             rhx = torch.empty_like(hx)
@@ -266,7 +330,14 @@ class _GRUStepBf16(torch.autograd.Function):
             img = lambda t: t.permute(0, 3, 1, 2)
             gxs, at = [], 0
             for i, n in enumerate(xsplit):
-                gxs.append(img(dx[..., at:at + n]) if need[13 + i] else None)
+                if need[13 + i] and ctx.as_image[i] and n <= 128:
+                    # the input came as a dense NCHW image: its consumer takes the gradient that way (the lookup's backward calls
+                    # .contiguous() on it): transposed here by one kernel instead of torch's strided copy
+                    gi = dx.new_empty(b, n, hh, ww)
+                    _call("az_rows_slice_to_image", _p(gi), _p(dx), npix, hh * ww, ci, at, n, _stream())
+                    gxs.append(gi)
+                else:
+                    gxs.append(img(dx[..., at:at + n]) if need[13 + i] else None)
                 at += n
             return (None, img(dh) if need[1] else None, img(dzr[..., :c]) if need[2] else None, img(dzr[..., c:]) if need[3] else None,
                     img(dq) if need[4] else None, None, None, gwz, gwr, gwq, gbz, gbr, gbq, *gxs)

@@ -497,6 +497,13 @@ int az_conv2d_wgrad_h1(float *grad_w, float *workspace, long long workspace_byte
  * [npix][channels] fp32 rows; hx = [h (hid) | x (inp)], zr = [z | r] (2 hid), rhx = [r * h | x]; see az_gru_gates.hip.
  * forward: az_gru_rh (rhx from zr, hx), az_gru_out (h' = (1 - z) h + z q); backward: az_gru_bwd1 (g = dL/dh' -> dq_pre,
  * dzr[:hid], dh_acc), az_gru_bwd2 (d_rhx -> dzr[hid:], dh_acc +=), az_gru_bwd3 (dh, dx from dh_acc, d_rhx, d_hx). */
+/* the GRU's input rows [h | x_0 | x_1 ..] in ONE launch (update.py:33 `hx = torch.cat([h, x], dim=1)` on channels-last rows):
+ * dst [npix][sum c_i] <- nsrc <= 4 sources, channel counts multiples of 4; kinds[i] = 0: dense rows [npix][c_i], 1: an NCHW image
+ * [npix / hw][c_i][hw] (c_i <= 128).  az_rows_slice_to_image: the inverse for one channel slice [at, at + c) of such rows -> a
+ * dense NCHW image: the gradient of an image source. */
+int az_rows_concat(float *dst, long long npix, long long hw, int nsrc, const float *const *srcs, const int *channels,
+                   const int *kinds, void *stream);
+int az_rows_slice_to_image(float *image, const float *rows, long long npix, long long hw, int ctot, int at, int c, void *stream);
 int az_gru_rh(float *rhx, const float *zr, const float *hx, long long npix, int hid, int inp, void *stream);
 int az_gru_out(float *hn, const float *zr, const float *q, const float *hx, long long npix, int hid, int inp, void *stream);
 /* (dq_amax / dzr_amax: amax arrays, both or neither, ZERO before az_gru_bwd1: max |dq_pre| and -- completed by az_gru_bwd2 --

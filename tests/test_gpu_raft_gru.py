@@ -296,3 +296,62 @@ def test_gru_fused_training_node_equals_the_operator_form():
         # (not bit-equal: a gate expression rounded differently in fp32 can move an operand of the NEXT convolution by one bf16
         #  ulp, 2^-9 relative on that element; the arithmetic's own distance from fp64 is 3-6e-3, test above)
         assert err <= 2e-4 * max(bb.abs().max().item(), 1e-3) + 1e-6, (i, err, bb.abs().max().item())
+
+
+# ---- round 5: the GRU's input rows in one launch (az_rows_concat) and image-layout gradients (az_rows_slice_to_image) ---------
+@pytest.mark.parametrize("b,h,w", [(1, 5, 7), (2, 21, 35), (1, 8, 64), (3, 3, 100)])
+def test_rows_concat_and_slice_to_image_vs_torch(b, h, w):
+    import ctypes
+    from activezero_amd.ops import _call, _p, _stream
+    g = torch.Generator().manual_seed(b * 100 + h)
+    rows_a = torch.randn(b, h, w, 32, generator=g).cuda()          # dense rows
+    img_b = torch.randn(b, 36, h, w, generator=g).cuda()           # NCHW image
+    rows_c = torch.randn(b, h, w, 220, generator=g).cuda()         # dense rows, more channels than an image source may have
+    img_d = torch.randn(b, 128, h, w, generator=g).cuda()          # the largest image source
+    want = torch.cat([rows_a, img_b.permute(0, 2, 3, 1), rows_c, img_d.permute(0, 2, 3, 1)], -1)
+    got = torch.full_like(want, float("nan"))
+    n = 4
+    ptrs = (ctypes.c_void_p * n)(rows_a.data_ptr(), img_b.data_ptr(), rows_c.data_ptr(), img_d.data_ptr())
+    chans = (ctypes.c_int * n)(32, 36, 220, 128)
+    kinds = (ctypes.c_int * n)(0, 1, 0, 1)
+    _call("az_rows_concat", _p(got), b * h * w, h * w, n, ptrs, chans, kinds, _stream())
+    assert torch.equal(got, want)
+    back = torch.full((b, 36, h, w), float("nan"), device="cuda")
+    _call("az_rows_slice_to_image", _p(back), _p(got), b * h * w, h * w, 416, 32, 36, _stream())
+    assert torch.equal(back, img_b)
+    back = torch.full((b, 128, h, w), float("nan"), device="cuda")
+    _call("az_rows_slice_to_image", _p(back), _p(got), b * h * w, h * w, 416, 288, 128, _stream())
+    assert torch.equal(back, img_d)
+
+
+def test_gru_update_with_assembled_rows_equals_the_slice_assignments(monkeypatch):
+    """the fused training node with its input rows from az_rows_concat (state in channels-last memory from the update before,
+    lookup as an NCHW image, context through the cached channels-last copy) against torch's slice assignments: the same bits
+    forward and in every gradient; the context copy is made once for the two chained updates"""
+    from activezero_amd.nets.raft import gru as G
+    torch.manual_seed(5)
+    b, c, ci, h, w = 2, 32, 256, 21, 35
+    hid, ctx, xs = _inputs(b, c, (36, 220), h, w, 78)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(G, "ASSEMBLE", on)
+        torch.manual_seed(11)
+        mod = G.ConvGRU(c, ci).cuda()
+        leaves = [hid.clone().cuda().requires_grad_(True)] + [t.clone().cuda().requires_grad_(True) for t in ctx] + \
+                 [t.clone().cuda().requires_grad_(True) for t in xs]
+        before = G.ROW_CONVERSIONS
+        s1 = mod(leaves[0], *leaves[1:4], *leaves[4:])
+        s2 = mod(s1, *leaves[1:4], *leaves[4:])
+        made = G.ROW_CONVERSIONS - before
+        # the 220-channel context once (too wide for the kernel's image tile); the 36-channel image goes through the kernel as an
+        # image in the first update and -- the SAME tensor again in the second -- gets its cached copy then
+        assert made == (2 if on else 0), made
+        cot = torch.randn(s2.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        ((s2 * cot).sum() + 0.3 * s1.square().sum()).backward()
+        res[on] = [s2.detach()] + [t.grad for t in leaves] + [p.grad for p in mod.parameters()]
+    for i, (a, bb) in enumerate(zip(res[True], res[False])):
+        # (weight gradients go through float atomics: equal to their rounding, everything else to the bit)
+        if i < 1 + 6:
+            assert torch.equal(a.contiguous(), bb.contiguous()), i
+        else:
+            torch.testing.assert_close(a, bb, rtol=1e-5, atol=1e-6 * float(bb.abs().max()))
