@@ -285,7 +285,17 @@ class _GRUStepBf16(torch.autograd.Function):
         npix = b * hh * ww
         need = ctx.needs_input_grad
         with torch.cuda.device(g_hn.device):
-            g = _chk(conv2d.rows(g_hn), "grad")
+            # the incoming gradient: channels-last memory when it comes from the next update alone (a view of its dh), a dense NCHW
+            # image as soon as a torch operator had a hand in it (the flow head, a loss term): transposed by one kernel then, and
+            # dh leaves in the layout g_hn came in, so that the engine's sum with that other gradient stays a contiguous add
+            g_is_image = ASSEMBLE and g_hn.dtype == torch.float32 and g_hn.is_contiguous() and not g_hn.permute(0, 2, 3, 1).is_contiguous() \
+                and c <= 128 and c % 4 == 0
+            if g_is_image:
+                g = g_hn.new_empty(b, hh, ww, c)
+                one = (ctypes.c_void_p * 1)(g_hn.data_ptr())
+                _call("az_rows_concat", _p(g), npix, hh * ww, 1, one, (ctypes.c_int * 1)(c), (ctypes.c_int * 1)(1), _stream())
+            else:
+                g = _chk(conv2d.rows(g_hn), "grad")
             dq = torch.empty_like(q)
             dzr = torch.empty_like(zr)
             dh_acc = torch.empty_like(q)
@@ -339,7 +349,14 @@ class _GRUStepBf16(torch.autograd.Function):
                 else:
                     gxs.append(img(dx[..., at:at + n]) if need[13 + i] else None)
                 at += n
-            return (None, img(dh) if need[1] else None, img(dzr[..., :c]) if need[2] else None, img(dzr[..., c:]) if need[3] else None,
+            g_h = None
+            if need[1]:
+                if g_is_image:
+                    g_h = dh.new_empty(b, c, hh, ww)
+                    _call("az_rows_slice_to_image", _p(g_h), _p(dh), npix, hh * ww, c, 0, c, _stream())
+                else:
+                    g_h = img(dh)
+            return (None, g_h, img(dzr[..., :c]) if need[2] else None, img(dzr[..., c:]) if need[3] else None,
                     img(dq) if need[4] else None, None, None, gwz, gwr, gwq, gbz, gbr, gbq, *gxs)
 
 
