@@ -125,6 +125,7 @@ _SIGS = {
     "az_corr1d_pool_bwd": [_PTR, _PTR, _LL, _INT, _PTR],
     "az_corr1d_lookup_fwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
     "az_corr1d_lookup_bwd": [_PTR] * 3 + [_INT] * 8 + [_PTR],
+    "az_corr1d_lookup_bwd_acc": [_PTR] * 3 + [_INT] * 8 + [_PTR],
 }
 _RESTYPE = {"az_strerror": _C.c_char_p, "az_conv3d_num_tiles": _LL, "az_conv3d_stats_tiles": _LL, "az_conv2d_roll_packed_floats": _LL, "az_conv2d_roll_stats_rows": _LL, "az_conv3d_packed_floats": _LL, "az_conv3d_packed_floats_f16": _LL, "az_conv3d_stats_tiles_f16": _LL,
             "az_conv3d_wgrad_workspace": _LL, "az_bn3d_bwd_workspace": _LL, "az_spp_upsample_bwd_workspace": _LL,

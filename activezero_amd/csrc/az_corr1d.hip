@@ -395,3 +395,18 @@ extern "C" int az_corr1d_lookup_bwd(float *grad_pyr_level, const float *grad_out
                        1.0f / (float)(1 << level), ch_offset, ch_total, total);
     return az_launch_status();
 }
+
+// the same scatter ADDED to what grad_pyr_level holds: the 22 lookups of a RAFT-Stereo step (raft_stereo.py:138-172) read ONE
+// pyramid, and the gradient of a level is the sum over them -- accumulated here by the kernel's own atomics into one buffer
+// (cleared once by the caller) instead of 22 cleared buffers and 21 tensor additions per level
+extern "C" int az_corr1d_lookup_bwd_acc(float *grad_pyr_level, const float *grad_out, const float *coords, int B, int H, int W1,
+                                        int W_level, int radius, int level, int ch_offset, int ch_total, void *stream) {
+    AZ_REQUIRE_PTR(grad_pyr_level); AZ_REQUIRE_PTR(grad_out); AZ_REQUIRE_PTR(coords);
+    AZ_REQUIRE(B > 0 && H > 0 && W1 > 0 && W_level > 1 && radius >= 0 && level >= 0 && level < 16);
+    AZ_REQUIRE(ch_offset >= 0 && ch_offset + 2 * radius + 1 <= ch_total);
+    const long long total = (long long)B * H * W1;
+    hipLaunchKernelGGL(lookup_bwd_kernel, dim3(az_grid_for(total, 256)), dim3(256), 0,
+                       az_stream(stream), grad_pyr_level, grad_out, coords, H, W1, W_level, radius,
+                       1.0f / (float)(1 << level), ch_offset, ch_total, total);
+    return az_launch_status();
+}

@@ -16,6 +16,8 @@ reference tree (`corr_sampler`, `alt_cuda_corr`) or are the numer
 different `alt` variant; they are exported as explicit "not targeted" stubs so that
 `from nets.raft.corr import ...` in raft_stereo.py keeps working.
 """
+import os
+
 import torch
 
 from activezero_amd import _lib, profiler
@@ -73,9 +75,37 @@ class _Pool(torch.autograd.Function):
         return gs
 
 
+class _LevelSums:
+    """Gradient accumulators of a pyramid's levels for ONE backward pass (round 5).  Every lookup of a step reads the same
+    pyramid, so the gradient of a level is the sum over the lookups: each _Lookup.backward scatters into the pass's buffer
+    (az_corr1d_lookup_bwd_acc: the kernel's atomics add to what is there) and only the FIRST one to run hands the buffer to
+    the engine; the others return None.  The engine runs the node that produced a level only after every lookup node that
+    reads it has run, so by then the buffer holds the whole sum -- with 22 lookups and 4 levels that replaces 88 cleared
+    buffers and 84 tensor additions per step by 4 buffers.  Keyed on the engine's graph-task id: a second backward pass
+    over a retained graph starts from fresh buffers."""
+
+    def __init__(self, n):
+        self.task, self.bufs = None, [None] * n
+
+    def take(self, i, like, shape):
+        """(buffer of level i, True if this call created it: the caller then returns it as the gradient)"""
+        task = torch._C._current_graph_task_id()
+        if task != self.task:
+            self.task, self.bufs = task, [None] * len(self.bufs)
+        fresh = self.bufs[i] is None
+        if fresh:
+            self.bufs[i] = like.new_zeros(shape)
+        return self.bufs[i], fresh
+
+
+# AZ_LOOKUP_ACC=0 (read once): one cleared gradient buffer per lookup and level, summed by the engine (A/B runs)
+LOOKUP_ACC = os.environ.get("AZ_LOOKUP_ACC", "1") != "0"
+
+
 class _Lookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, coords, radius, *levels):
+    def forward(ctx, coords, radius, sums, *levels):
+        ctx.sums = sums if LOOKUP_ACC else None
         coords = _chk(coords.detach().contiguous(), "coords")
         b, two, h, w1 = coords.shape
         if two != 2:
@@ -101,14 +131,20 @@ class _Lookup(torch.autograd.Function):
         grads = []
         with torch.cuda.device(g.device):
             for i, shp in enumerate(shapes):
-                if not ctx.needs_input_grad[2 + i]:
+                if not ctx.needs_input_grad[3 + i]:
                     grads.append(None)
+                    continue
+                if ctx.sums is not None:
+                    gl, fresh = ctx.sums.take(i, g, shp)
+                    _call("az_corr1d_lookup_bwd_acc", _p(gl), _p(g), _p(coords), b, h, w1, shp[-1], radius, i,
+                          i * taps, taps * len(shapes), _stream())
+                    grads.append(gl if fresh else None)
                     continue
                 gl = g.new_empty(shp)
                 _call("az_corr1d_lookup_bwd", _p(gl), _p(g), _p(coords), b, h, w1, shp[-1], radius, i,
                       i * taps, taps * len(shapes), _stream())
                 grads.append(gl)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class CorrBlock1D:
@@ -122,11 +158,12 @@ class CorrBlock1D:
         for _ in range(self.num_levels):
             levels.append(_Pool.apply(levels[-1]))
         self._levels = levels
+        self._sums = _LevelSums(self.num_levels)
         # the reference keeps num_levels+1 entries shaped [B*H*W1, 1, 1, W2 / 2^i]
         self.corr_pyramid = [l.view(b * h * w1, 1, 1, l.shape[-1]) for l in levels]
 
     def __call__(self, coords):
-        return _Lookup.apply(coords, self.radius, *self._levels[: self.num_levels])
+        return _Lookup.apply(coords, self.radius, self._sums, *self._levels[: self.num_levels])
 
     @staticmethod
     def corr(fmap1, fmap2):

@@ -554,6 +554,12 @@ int az_corr1d_lookup_fwd(float *out, const float *pyr_level, const float *coords
 int az_corr1d_lookup_bwd(float *grad_pyr_level, const float *grad_out, const float *coords, int B,
                          int H, int W1, int W_level, int radius, int level, int ch_offset,
                          int ch_total, void *stream);
+/* the same scatter ADDED to the buffer's contents (cleared once by the caller): the lookups of one step share a pyramid and a
+ * level's gradient is their sum -- one buffer and the kernel's own atomics instead of one cleared buffer per lookup and a
+ * tensor addition for each */
+int az_corr1d_lookup_bwd_acc(float *grad_pyr_level, const float *grad_out, const float *coords, int B,
+                         int H, int W1, int W_level, int radius, int level, int ch_offset,
+                         int ch_total, void *stream);
 
 /* ---- K12: disparity loss + error metrics (the step after the path) -------------------------
  * Replaces utils/losses.py:7-15 psmnet_disp (boolean-index compaction + three smooth_l1 means)

@@ -87,3 +87,41 @@ def test_corr1d_config5_shape_properties():
     assert out.shape == (b, 36, h, w)
     diag = (f * f).sum(1) / 16.0
     assert torch.allclose(out[:, 4], diag, rtol=1e-4, atol=1e-3)
+
+
+# ---- round 5: the lookups of a step accumulate their pyramid gradients in one buffer per level (az_corr1d_lookup_bwd_acc) -------
+@pytest.mark.parametrize("n_lookups", [1, 3, 5])
+def test_several_lookups_of_one_pyramid_sum_their_gradients_in_the_kernel(n_lookups, monkeypatch):
+    """raft_stereo.py:138-172 looks the same pyramid up once per update; the gradient of fmap1 / fmap2 is the sum over the
+    lookups.  With the accumulating kernel only the first lookup node to run hands a buffer to the engine: against the torch
+    reference, against the one-buffer-per-lookup route (AZ_LOOKUP_ACC=0), with one lookup's output left out of the loss (its
+    node never runs), and over a second backward pass through the retained graph (fresh buffers per pass)."""
+    from activezero_amd.nets.raft import corr as C
+    b, c, h, w = 2, 64, 3, 75
+    f1, f2 = seeded((b, c, h, w), 1), seeded((b, c, h, w), 2)
+    base = torch.stack(torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")[::-1], 0).float()[None].repeat(b, 1, 1, 1)
+    coords = []
+    for k in range(n_lookups + 1):
+        ck = base.clone()
+        ck[:, 0] -= seeded((b, h, w), 10 + k, -3.0, 0.6 * w)
+        coords.append(ck)
+    cots = [seeded((b, 36, h, w), 30 + k) for k in range(n_lookups + 1)]
+    a1, a2 = f1.clone().requires_grad_(), f2.clone().requires_grad_()
+    ref = sum((_torch_reference(a1, a2, coords[k])[0] * cots[k]).sum() for k in range(n_lookups))
+    r1, r2 = torch.autograd.grad(ref, (a1, a2))
+    res = {}
+    for acc in (True, False):
+        monkeypatch.setattr(C, "LOOKUP_ACC", acc)
+        x1, x2 = f1.to(DEV).requires_grad_(), f2.to(DEV).requires_grad_()
+        blk = CorrBlock1D(x1, x2)
+        outs = [blk(coords[k].to(DEV)) for k in range(n_lookups + 1)]  # the last one stays out of the loss
+        loss = sum((outs[k] * cots[k].to(DEV)).sum() for k in range(n_lookups))
+        g1, g2 = torch.autograd.grad(loss, (x1, x2), retain_graph=True)
+        close(g1, r1, 1e-3, 3e-4 * n_lookups)
+        close(g2, r2, 1e-3, 3e-4 * n_lookups)
+        h1, h2 = torch.autograd.grad(loss, (x1, x2))  # a second pass: not twice the sums
+        torch.testing.assert_close(h1, g1, rtol=1e-5, atol=1e-6 * float(g1.abs().max()))
+        torch.testing.assert_close(h2, g2, rtol=1e-5, atol=1e-6 * float(g2.abs().max()))
+        res[acc] = (g1, g2)
+    for a_, b_ in zip(res[True], res[False]):
+        torch.testing.assert_close(a_, b_, rtol=1e-5, atol=1e-6 * float(b_.abs().max()))
