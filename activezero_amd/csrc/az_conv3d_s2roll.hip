@@ -33,12 +33,18 @@
 #include "az_launch_math.h"
 
 #define S2R_NT 256
-#define S2R_FY 17                          // fine rows / columns of a patch's plane (with the halo)
+#ifndef S2R_TY
+#define S2R_TY 8                           // coarse rows of a patch: 8 (two workgroups per CU) or 4 (three; experiment)
+#endif
+#define S2R_NH (S2R_TY / 4)                // 4-row halves of the patch
+#define S2R_NTILE (4 * S2R_NH)             // 4x4 tiles of the patch = tiles per wave
+#define S2R_WGS (S2R_TY == 8 ? 2 : 3)      // workgroups per CU
+#define S2R_FY (2 * S2R_TY + 1)            // fine rows / columns of a patch's plane (with the halo)
 #define S2R_FX 33
 #define S2R_NVOX (S2R_FY * S2R_FX)         // 561
-#define S2R_NLD 18                         // 16-byte pieces per thread and plane: one per fine row + the 33rd column
+#define S2R_NLD (S2R_FY + 1)               // 16-byte pieces per thread and plane: one per fine row + the 33rd column
 #define S2R_PITCH 17                       // sub-slab row pitch in voxels
-#define S2R_SUB_BYTES (9 * S2R_PITCH * 128)  // 19 584
+#define S2R_SUB_BYTES ((S2R_TY + 1) * S2R_PITCH * 128)  // 19 584
 #define S2R_LDS (4 * S2R_SUB_BYTES)        // 78 336
 #define S2R_TAPB (4 * 2 * 64 * 16)         // bytes per tap of the packed image [tap][cout/16 (4)][part (2)][lane][16 B]
 #ifndef S2R_KIND_FIRST  // (experiments: 1 = the first / last plane of a segment multiply all eighteen taps, nine of them dropped)
@@ -62,7 +68,7 @@ __device__ unsigned long long s2r_stamp_sum[8];
 // EPI: 0 = y = relu?(acc * scale + shift) (+ residual when given), 1 = raw output + BatchNorm partials
 // PS: the input is a pre-split tensor (az_roll_common.h): the gradient a BatchNorm backward wrote
 template <int EPI, bool PS>
-__global__ void __launch_bounds__(S2R_NT, 2)
+__global__ void __launch_bounds__(S2R_NT, S2R_WGS)
 conv3d_s2roll_kernel(const ConvArgs a) {
     __shared__ __attribute__((aligned(128))) unsigned char slab[S2R_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -76,7 +82,7 @@ conv3d_s2roll_kernel(const ConvArgs a) {
     int tix, tiy, seg, b;
     az_roll_decode(lin, a.tiles_x, a.tiles_y, a.nseg, tix, tiy, seg, b);
     const int c0 = seg * a.seg_len, c1 = min(c0 + a.seg_len, a.Do);  // coarse output planes [c0, c1)
-    const int ty0 = tiy * 8, tx0 = tix * 16;                           // coarse patch origin
+    const int ty0 = tiy * S2R_TY, tx0 = tix * 16;                           // coarse patch origin
 
     const unsigned in_bytes = (unsigned)a.Di * a.Hi * a.Wi * 32u * 4u, out_bytes = (unsigned)a.Do * a.Ho * a.Wo * 64u * 4u;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in) + (size_t)b * (in_bytes / 4), 0, in_bytes, 0x00020000);
@@ -94,11 +100,11 @@ conv3d_s2roll_kernel(const ConvArgs a) {
     const int out_exp = -(ki + kw_);
 
     // accumulators: [set][tile]; set 0: output plane t (the one being completed), set 1: plane t + 1 (begun by kd = 0)
-    f32x4 acc[2][8];
+    f32x4 acc[2][S2R_NTILE];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc[s][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < S2R_NTILE; ++m) acc[s][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- staging: fine plane z, rows 2 ty0 - 1 .., columns 2 tx0 - 1 .. (17 x 33 voxels x 8 pieces of four channels).
     //      piece `it` < 17 of thread tid: fine row it, column tid >> 3, channels 4 (tid & 7) .. (a row's 32 voxels = 4 KB in one
@@ -192,7 +198,7 @@ conv3d_s2roll_kernel(const ConvArgs a) {
             h_first = false;
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < S2R_NTILE; ++m) {
             const int oy = ty0 + 4 * (m >> 2) + trow, ox = tx0 + 4 * (m & 3) + tcol;
             const bool vok = oy < a.Ho && ox < a.Wo;
             const unsigned off = vok ? (unsigned)((t * a.Ho + oy) * a.Wo + ox) * 256u + (unsigned)cqh * 4u : R_OOB;
@@ -213,7 +219,7 @@ conv3d_s2roll_kernel(const ConvArgs a) {
             }
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < S2R_NTILE; ++m) {
             acc[0][m] = acc[1][m];
             acc[1][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -243,7 +249,7 @@ conv3d_s2roll_kernel(const ConvArgs a) {
         }
     };
     // twelve MFMAs: one weight fragment pair x four tiles (the three products of a tile are four MFMAs apart)
-    auto mul4 = [&](f32x4 (&c)[8], int half, const float4 (&w)[2], const float4 (&x)[4][2]) __attribute__((always_inline)) {
+    auto mul4 = [&](f32x4 (&c)[S2R_NTILE], int half, const float4 (&w)[2], const float4 (&x)[4][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) c[4 * half + q] = R_MH(c[4 * half + q], w[0], x[q][0]);
 #pragma unroll
@@ -260,27 +266,23 @@ conv3d_s2roll_kernel(const ConvArgs a) {
         constexpr bool HAS_A = KIND != 2, HAS_B = KIND == 1 || KIND == 2;
         constexpr int KD_A = KIND == 0 ? 1 : 2;
         float4 wa[2][2], wb[2][2];  // [tap parity][part]: wa: kd = 1 or 2 into set 0; wb: kd = 0 into set 1
-        float4 xf[2][4][2];         // [patch half][tile][part]
+        float4 xf[2][4][2];         // [step parity][tile][part]: the fragments of a (tap position, patch half), one step ahead
         if (HAS_A) load_w(wa[0], KD_A, 0);
         if (HAS_B) load_w(wb[0], 0, 0);
         load_x(xf[0], 0, 0);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int st = 0; st < 9 * S2R_NH; ++st) {
+            const int i = st / S2R_NH, g = st % S2R_NH;
             __builtin_amdgcn_sched_barrier(0);
-            load_x(xf[1], i, 1);
-            if (i + 1 < 9 && !(S2R_ABL & 2)) {
+            if (st + 1 < 9 * S2R_NH) load_x(xf[(st + 1) & 1], (st + 1) / S2R_NH, (st + 1) % S2R_NH);
+            if (g == 0 && i + 1 < 9 && !(S2R_ABL & 2)) {
                 if (HAS_A) load_w(wa[(i + 1) & 1], KD_A, i + 1);
                 if (HAS_B) load_w(wb[(i + 1) & 1], 0, i + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
             const int wp = (S2R_ABL & 2) ? 0 : (i & 1);
-            if (HAS_A) mul4(acc[0], 0, wa[wp], xf[0]);
-            if (HAS_B) mul4(acc[1], 0, wb[wp], xf[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 < 9) load_x(xf[0], i + 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (HAS_A) mul4(acc[0], 1, wa[wp], xf[1]);
-            if (HAS_B) mul4(acc[1], 1, wb[wp], xf[1]);
+            if (HAS_A) mul4(acc[0], g, wa[wp], xf[st & 1]);
+            if (HAS_B) mul4(acc[1], g, wb[wp], xf[st & 1]);
         }
     };
 
@@ -289,7 +291,7 @@ conv3d_s2roll_kernel(const ConvArgs a) {
     __syncthreads();
     plane(std::integral_constant<int, S2R_KIND_FIRST>{});
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < S2R_NTILE; ++m) {
         acc[0][m] = acc[1][m];
         acc[1][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -360,9 +362,9 @@ extern "C" int az_debug_s2roll_stamps(unsigned long long *out8, int reset) {
 #endif
 
 static void s2roll_geometry(ConvArgs &a) {
-    a.tiles_y = (a.Ho + 7) / 8;
+    a.tiles_y = (a.Ho + S2R_TY - 1) / S2R_TY;
     a.tiles_x = (a.Wo + 15) / 16;
-    az_s2roll_segments((long long)a.B * a.tiles_y * a.tiles_x, a.Do, az_options().s2roll_seglen, a.nseg, a.seg_len);  // (az_launch_math.h: swept on the CPU)
+    az_s2roll_segments((long long)a.B * a.tiles_y * a.tiles_x, a.Do, az_options().s2roll_seglen, a.nseg, a.seg_len, 256 * S2R_WGS);  // (az_launch_math.h: swept on the CPU)
 }
 
 long long az_conv3d_s2roll_stats_tiles(ConvArgs a) {

@@ -55,7 +55,7 @@ inline void az_t2roll_segments(long long patches, int Di, int &nseg, int &seg_le
 // az_conv3d_s2roll.hip: coarse-depth segments of a launch with two workgroups per CU (512 slots); a workgroup of a segment
 // of len output planes stages 2 len + 1 fine planes and multiplies 27 len tap positions; a staged plane is priced at four
 // tap positions (measured at B = 4, V0 -> V1, 288 patches: 0.34 ms for len 4 .. 6, 0.36 at 3, 0.38 at 1 and 12, 0.46 at 24).  forced > 0: that segment length (AZ_S2ROLL_SEGLEN).  Postconditions as az_roll_segments.
-inline void az_s2roll_segments(long long patches, int Do, int forced, int &nseg, int &seg_len) {
+inline void az_s2roll_segments(long long patches, int Do, int forced, int &nseg, int &seg_len, int slots = 512) {
     if (forced > 0) {
         seg_len = forced < Do ? forced : Do;
         nseg = (Do + seg_len - 1) / seg_len;
@@ -66,7 +66,7 @@ inline void az_s2roll_segments(long long patches, int Do, int forced, int &nseg,
     for (int n = 1; n <= Do; ++n) {
         const int len = (Do + n - 1) / n;
         if ((Do + len - 1) / len != n) continue;
-        const long long rounds = (patches * n + 511) / 512;
+        const long long rounds = (patches * n + slots - 1) / slots;
         const long long cost = rounds * (27LL * len + 4 * (2 * len + 1) + 4);
         if (best < 0 || cost < best) { best = cost; nseg = n; seg_len = len; }
     }
