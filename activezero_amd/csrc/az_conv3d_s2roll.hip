@@ -40,8 +40,7 @@
 #define S2R_NTILE (4 * S2R_NH)             // 4x4 tiles of the patch = tiles per wave
 #define S2R_WGS (S2R_TY == 8 ? 2 : 3)      // workgroups per CU
 #define S2R_FY (2 * S2R_TY + 1)            // fine rows / columns of a patch's plane (with the halo)
-#define S2R_FX 33
-#define S2R_NVOX (S2R_FY * S2R_FX)         // 561
+#define S2R_FX 33                          // (561 voxels per staged plane at 8 patch rows)
 #define S2R_NLD (S2R_FY + 1)               // 16-byte pieces per thread and plane: one per fine row + the 33rd column
 #define S2R_PITCH 17                       // sub-slab row pitch in voxels
 #define S2R_SUB_BYTES ((S2R_TY + 1) * S2R_PITCH * 128)  // 19 584
