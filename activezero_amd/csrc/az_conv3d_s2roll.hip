@@ -25,6 +25,14 @@
 // 17 voxels = 8 mod 16: without g the four x-adjacent voxels of a tile row share two slot quads).
 // BatchNorm partials (EPI 1): per-lane shifted running sums of its four channels over everything it stores, merged once
 // after the walk: one row per workgroup.
+// Measured (B = 4, V0 -> V1, alone): 0.34 ms forward with partials, 0.37 ms input gradient from a pre-split operand (gather
+// kernel: 0.59 / 0.55); counter passes 1.01 GB read + 0.20 GB written, clock 2.03 GHz, MFMA pipe 0.42.  Timing-only builds
+// (S2R_ABL, profiles/r05v_s2roll_ablations_corrected.txt): without the staging loads 0.226, without fragment reads 0.316,
+// without weight loads 0.320, all three off 0.222 -- against 0.122 ms of matrix time.  The plane loads are the exposed term:
+// a workgroup cannot request plane z + 1 while it multiplies plane z (vmcnt is one in-order counter: the weight fragments
+// requested behind the plane would wait for it; 72 prefetch registers do not exist beside 64 accumulators and two fragment
+// sets) and the second workgroup does not fill the gap: delayed starts of the workgroups in a CU's second slot, and three
+// workgroups per CU on 4 x 16 patches (-DS2R_TY=4: 168 registers, 43.5 KB), both leave the time where it is.
 #include <type_traits>
 
 #include "az_conv3d_args.h"
