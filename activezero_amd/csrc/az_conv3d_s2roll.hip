@@ -122,7 +122,9 @@ conv3d_s2roll_kernel(const ConvArgs a) {
     const bool col_ok = (unsigned)iw_a < (unsigned)a.Wi;
     const unsigned in_col = (unsigned)iw_a * 128u + (unsigned)pj * 16u;
     // LDS: [sub-slab (row parity, column parity)][row r][column c]; octet swizzle by the row's parity, part swap by bit 1 of c
-    const unsigned dst_col = (unsigned)((pc & 1) * S2R_SUB_BYTES + (pc >> 1) * 128 + (pj & 1) * 8 + (((pc >> 2) & 1) * 64));
+    // (the sub-slabs of the ODD columns keep hi and lo the other way round: the sixteen lanes of a ds_write_b64 group are two
+    //  x-adjacent voxels, one per column parity, and would otherwise meet in the same 64-byte half of the bank row)
+    const unsigned dst_col = (unsigned)((pc & 1) * S2R_SUB_BYTES + (pc >> 1) * 128 + (pj & 1) * 8 + ((((pc >> 2) ^ pc) & 1) * 64));
     const unsigned oct_e = (unsigned)((pj >> 1) << 4), oct_o = (unsigned)(((pj >> 1) ^ 2) << 4);  // rows r even / odd
     const unsigned dst_e = dst_col + oct_e, dst_o = dst_col + oct_o, dst_e_lo = dst_e ^ 64u, dst_o_lo = dst_o ^ 64u;
     auto stage = [&](int z) __attribute__((always_inline)) {
@@ -250,8 +252,8 @@ conv3d_s2roll_kernel(const ConvArgs a) {
                 //  and the compiler keeps ONE chain of MFMAs -- the first ablation run, profiles/r05v_s2roll_ablations.txt)
                 x[q][0] = x[q][1] = __builtin_bit_cast(float4, u32x4{0x3c003c00u + (unsigned)(4 * half + q), 0x3c003c00u + (unsigned)lane, 0x3c003c00u, 0x3c003c00u});
             } else {
-                x[q][0] = *reinterpret_cast<const float4 *>(slab + xb[0][kh == 2][kw == 2] + cst + 4 * q * 128);
-                x[q][1] = *reinterpret_cast<const float4 *>(slab + xb[1][kh == 2][kw == 2] + cst + 4 * q * 128);
+                x[q][0] = *reinterpret_cast<const float4 *>(slab + xb[kw == 1 ? 1 : 0][kh == 2][kw == 2] + cst + 4 * q * 128);
+                x[q][1] = *reinterpret_cast<const float4 *>(slab + xb[kw == 1 ? 0 : 1][kh == 2][kw == 2] + cst + 4 * q * 128);
             }
         }
     };
