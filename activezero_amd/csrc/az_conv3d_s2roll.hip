@@ -54,12 +54,13 @@
 #define S2R_SUB_BYTES ((S2R_TY + 1) * S2R_PITCH * 128)  // 19 584
 #define S2R_LDS (4 * S2R_SUB_BYTES)        // 78 336
 #define S2R_TAPB (4 * 2 * 64 * 16)         // bytes per tap of the packed image [tap][cout/16 (4)][part (2)][lane][16 B]
+#define S2R_SYNC() do { if (!(S2R_ABL & 32)) __syncthreads(); } while (0)
 #ifndef S2R_KIND_FIRST  // (experiments: 1 = the first / last plane of a segment multiply all eighteen taps, nine of them dropped)
 #define S2R_KIND_FIRST 2
 #define S2R_KIND_LAST 3
 #endif
 #ifndef S2R_ABL
-#define S2R_ABL 0  // timing-only ablations: 1 no output stores, 2 no weight loads after the first tap, 4 no slab staging, 8 no fragment reads
+#define S2R_ABL 0  // timing-only ablations: 1 no output stores, 2 no weight loads after the first tap, 4 no slab staging, 8 no fragment reads, 16 no split / LDS writes, 32 no barriers
 #endif
 
 // Diagnostic build only (-DS2R_STAMP): per-phase cycle sums of every wave, added to a global array nothing else reads
@@ -157,16 +158,20 @@ conv3d_s2roll_kernel(const ConvArgs a) {
             const int base = (it & 1) * 2 * S2R_SUB_BYTES + r * S2R_PITCH * 128;
             uint2 hi, lo;
             az_stage_f16x4<PS>(pre[it], in_scale, hi, lo);
-            *reinterpret_cast<uint2 *>(slab + base + d_hi) = hi;
-            *reinterpret_cast<uint2 *>(slab + base + d_lo) = lo;
+            if (!(S2R_ABL & 16)) {
+                *reinterpret_cast<uint2 *>(slab + base + d_hi) = hi;
+                *reinterpret_cast<uint2 *>(slab + base + d_lo) = lo;
+            }
         }
         if (pc < S2R_FY) {
             const int r = pc >> 1;  // column 32 = c 16 of the even-column sub-slabs: part swap bit (16 >> 1) & 1 = 0
             unsigned char *dst = slab + (pc & 1) * 2 * S2R_SUB_BYTES + (r * S2R_PITCH + 16) * 128 + (pj & 1) * 8 + ((r & 1) ? oct_o : oct_e);  // (128-byte aligned base: + 64 below = ^ 64)
             uint2 hi, lo;
             az_stage_f16x4<PS>(pre[S2R_FY], in_scale, hi, lo);
-            *reinterpret_cast<uint2 *>(dst) = hi;
-            *reinterpret_cast<uint2 *>(dst + 64) = lo;
+            if (!(S2R_ABL & 16)) {
+                *reinterpret_cast<uint2 *>(dst) = hi;
+                *reinterpret_cast<uint2 *>(dst + 64) = lo;
+            }
         }
     };
 
@@ -306,19 +311,19 @@ conv3d_s2roll_kernel(const ConvArgs a) {
     }
     for (int t = c0; t < c1; ++t) {
         S2R_T(3);
-        __syncthreads();
+        S2R_SYNC();
         S2R_T(4);
         stage(2 * t);
         S2R_T(1);
-        __syncthreads();
+        S2R_SYNC();
         S2R_T(2);
         plane(std::integral_constant<int, 0>{});
         S2R_T(3);
-        __syncthreads();
+        S2R_SYNC();
         S2R_T(4);
         stage(2 * t + 1);
         S2R_T(1);
-        __syncthreads();
+        S2R_SYNC();
         S2R_T(2);
         if (t + 1 < c1) plane(std::integral_constant<int, 1>{});
         else plane(std::integral_constant<int, S2R_KIND_LAST>{});
