@@ -33,6 +33,8 @@ CASES = [
     ({"AZ_CONV_S2ROLL": "0"}, "tests/test_gpu_conv3d.py", "(conv_stride2 or hourglass_golden or presplit_routing) and f16x3 or presplit_routing"),  # stride-2 32 -> 64 on the gather kernel
     ({"AZ_S2ROLL_SEGLEN": "1"}, "tests/test_gpu_s2roll.py", "forward or partials or input_gradient"),
     ({"AZ_CONV_ROLL64": "0"}, "tests/test_gpu_conv3d.py", "(conv_stride1 or convbn3d_golden or hourglass_golden) and f16x3"),        # stride-1 64 -> 64 on the gather kernel                               # one output plane per depth segment
+    ({"AZ_GRU_ASSEMBLE": "0"}, "tests/test_gpu_raft_gru.py", "golden or fused_training_node"),      # the GRU's input rows by torch slice assignments
+    ({"AZ_LOOKUP_ACC": "0"}, "tests/test_gpu_raft_corr.py", "golden or vs_torch_ops"),                # one gradient buffer per lookup and level
     ({"AZ_CONV2D_ROLL_H": "0"}, "tests/test_gpu_conv2d_roll.py", ""),                                      # f16x3 64-channel 2-D layers on conv2d_roll_kernel<.., 4, 1>
     # the Python-level switches of the two-stream backward (overlap.py, conv2d.py)
     ({"AZ_SIDE_RELEASE": "record"}, "tests/test_gpu_overlap.py", "in_order_pass or partial_backward or two_forward"),  # operands released through record_stream
