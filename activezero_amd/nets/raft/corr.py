@@ -87,11 +87,16 @@ class _LevelSums:
     def __init__(self, n):
         self.task, self.bufs = None, [None] * n
 
+    def _release(self):
+        self.task, self.bufs = None, [None] * len(self.bufs)
+
     def take(self, i, like, shape):
         """(buffer of level i, True if this call created it: the caller then returns it as the gradient)"""
         task = torch._C._current_graph_task_id()
         if task != self.task:
             self.task, self.bufs = task, [None] * len(self.bufs)
+            # (the buffers belong to the engine once handed over: let go of them when this backward pass ends)
+            torch.autograd.Variable._execution_engine.queue_callback(self._release)
         fresh = self.bufs[i] is None
         if fresh:
             self.bufs[i] = like.new_zeros(shape)
