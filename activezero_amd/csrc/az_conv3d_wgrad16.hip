@@ -512,6 +512,10 @@ int az_conv3d_wgrad_r16_launch(float *ws, const float *coarse, const float *fine
     a.wgs = best;
     a.xcd = az_options().wgrad_r16_xcd;
     const dim3 grid((unsigned)(a.wgs * ntiles));
+#ifdef WG16_SKIP  // timing-only build: the launch is left out (the workspace stays zero: those weights do not move) -- what the step
+                  // would gain if these weight gradients were free (tools/abl_step_sensitivity.sh); -DWG16_SKIP=1: the V0 shapes only
+    if (WG16_SKIP == 2 || (long long)D * H * W >= 1000000) return AZ_OK;
+#endif
     if (!(coarse_amax && fine_amax)) {
         if (split_mask) return AZ_EINVAL;
         hipLaunchKernelGGL(conv3d_wgrad_r16_kernel<0>, grid, dim3(256), 0, s, a);
